@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- masked-items/sec of the BERT4Rec Cloze training step on MI355X.
+
+A step = one pass of the hot path over one synthetic batch already resident in HBM:
+embedding stage -> 4 encoder layers -> [MASK]-row gather -> SoftMaxHead trunk + 50k-way projection ->
+fused softmax / masked sparse CE -> full backward -> gradient all-reduce (N > 1) -> Adam.
+Workload (BASELINE.json configs[1]): vocab 50,000, encoder length 200 (197 items + 3 specials),
+d_model 128, 4 layers, 2 heads, dff 100 (reference-hard-coded), head [1024,512,256,128] -> V,
+batch 4096 sequences per GPU (weak scaling), 10 masked items per sequence, dropout 0.1, bf16
+storage / fp32 accumulate / fp32 master weights.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for roofline / cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=4096, help='sequences per GPU')
+    ap.add_argument('--seq', type=int, default=200, help='encoder length (items + 3 specials)')
+    ap.add_argument('--vocab', type=int, default=50000)
+    ap.add_argument('--d_model', type=int, default=128)
+    ap.add_argument('--layers', type=int, default=4)
+    ap.add_argument('--heads', type=int, default=2)
+    ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--n_batches', type=int, default=2, help='distinct resident batches cycled through')
+    ap.add_argument('--roofline_kernel', default='vocab_proj_fwd')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--cpu_rows', type=int, default=48, help='sequences in the bounded CPU-baseline sample')
+    ap.add_argument('--traffic_json', default=None, help='optional JSON with PMC-derived HBM bytes per launch')
+    return ap.parse_args()
+
+
+def build_model(a, device):
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    torch.manual_seed(1234)
+    vocab = ['i%d' % i for i in range(a.vocab)]
+    head = SoftMaxHead([1024, 512, 256, 128], a.vocab)
+    model = ClickstreamTransformer({'items': ['asin']}, {'items': vocab}, {'items': a.d_model}, head,
+                                   value_to_head='[MASK]', num_encoder_layers=a.layers, num_attention_heads=a.heads,
+                                   dropout_rate=a.dropout,
+                                   compute_dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
+    return model.to(device)
+
+
+def backward_order(model):
+    """Arena order = the order gradients appear in backward: head, encoder layers last -> first, embedding."""
+    names = {id(p): n for n, p in model.named_parameters()}
+    L = model.num_encoder_layers
+
+    def key(p):
+        n = names[id(p)]
+        if n.startswith('head.'):
+            return (0, n)
+        if 'enc_layers.' in n:
+            i = int(n.split('enc_layers.')[1].split('.')[0])
+            return (1 + (L - 1 - i), n)
+        return (L + 2, n)
+    return key
+
+
+def make_batches(a, rank, device):
+    from bert4clickpath_amd import input_pipeline
+    out = []
+    for j in range(a.n_batches):
+        b = input_pipeline.synthetic_cloze_batch(a.batch, a.seq, a.vocab, seed=4321 + rank + 1000 * j)
+        ids = torch.from_numpy(b['ids'])
+        out.append({'items': ids[:, 2:a.seq - 1].contiguous().to(device),
+                    'flat_idx': torch.from_numpy(b['flat_idx']).to(device),
+                    'labels': torch.from_numpy(b['labels']).to(device),
+                    'R': int(b['labels'].shape[0])})
+    return out
+
+
+def cpu_baseline(a):
+    """The oracle's torch-CPU restatement of the reference dataflow (materialised S x S attention and
+    (B*M) x V probabilities), full training step, on a bounded sample of the same workload."""
+    from bert4clickpath_amd import input_pipeline
+    from oracle import numpy_ref as nr
+    from oracle import torch_ref as tr
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(1234)
+    P = nr.init_params(rng, {'items': a.vocab + 11}, {'items': a.d_model}, a.layers, 100, [1024, 512, 256, 128], a.vocab)
+    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in P.items()}
+    m = {k: torch.zeros_like(v) for k, v in P.items()}
+    vv = {k: torch.zeros_like(v) for k, v in P.items()}
+    b = input_pipeline.synthetic_cloze_batch(a.cpu_rows, a.seq, a.vocab, seed=4321)
+    ids, lab = torch.from_numpy(b['ids']), torch.from_numpy(b['labels']).long()
+
+    def step(t):
+        for v in P.values():
+            v.grad = None
+        loss, _ = tr.model_loss(ids, lab, P, a.layers, a.heads, 4)
+        loss.backward()
+        with torch.no_grad():
+            for k in P:
+                tr.adam_step(P[k], P[k].grad, m[k], vv[k], t)
+    step(1)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 12.0 and n < 50:
+        step(n + 2)
+        n += 1
+    dt = (time.perf_counter() - t0) / max(n, 1)
+    return {'value': float(lab.numel() / dt), 'unit': 'masked-items/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d sequences x S=%d (R=%d masked items), %d timed steps, fp32, torch-CPU restatement of the '
+                      'reference dataflow (TF 2.3.1 not installable)' % (a.cpu_rows, a.seq, lab.numel(), n),
+            'ms_per_step': dt * 1e3}
+
+
+def roofline_for(kernel, a, R, ms):
+    """Algorithmic bytes / flops of ONE launch of the named kernel (Measurement)."""
+    es = 2 if a.dtype == 'bf16' else 4
+    V, Vp, d, T = a.vocab, (a.vocab + 7) // 8 * 8, a.d_model, a.batch * a.seq
+    if kernel == 'vocab_proj_fwd':      # logits[R][Vp] = h[R][128] . W[V][128]^T : write-bound
+        by = R * Vp * es + R * 128 * es + V * 128 * es
+        return {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': 'gemm_nt (vocab projection fwd)'}
+    if kernel == 'vocab_proj_dx':
+        by = R * Vp * es + R * 128 * es + V * 128 * es
+        return {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': 'gemm_nt (vocab projection dX)'}
+    if kernel == 'vocab_proj_dw':
+        by = R * Vp * es + R * 128 * es + V * 128 * 4
+        return {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': 'gemm_tn (vocab projection dW)'}
+    if kernel == 'softmax_ce':
+        by = 2 * R * Vp * es
+        return {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': 'softmax_ce_fused'}
+    if kernel == 'qkv_fwd':
+        by = T * d * es + T * 3 * d * es + 3 * d * d * es
+        return {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': 'gemm_nt (QKV projection fwd)'}
+    if kernel in ('attn_fwd', 'attn_bwd'):
+        S, H = a.seq, a.heads
+        fl = (4 if kernel == 'attn_fwd' else 10) * a.batch * S * S * d
+        return {'bound': 'mfma', 'achieved': fl / (ms * 1e-3) / 1e12, 'peak': MFMA_BF16_PEAK_TF if a.dtype == 'bf16' else 157.3,
+                'unit': 'TFLOP/s', 'kernel': kernel}
+    raise SystemExit('unknown roofline kernel %s' % kernel)
+
+
+def main():
+    a = parse()
+    from bert4clickpath_amd import ops, optim, parallel
+    rank, local, world = parallel.init_distributed()
+    if world != a.gpus:
+        if rank == 0:
+            print('warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (a.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU fallback)'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    model = build_model(a, device)
+    opt = optim.Adam(model.parameters(), order=backward_order(model))
+    arena = opt.arena
+    head_end = max(arena.slice_of(p)[1] for n, p in model.named_parameters() if n.startswith('head.'))
+    emb_start = min(arena.slice_of(p)[0] for n, p in model.named_parameters() if 'embedding_layers' in n)
+    reducer = parallel.GradReducer(arena, bucket_bounds=[head_end, emb_start], reduce='sum')
+    batches = make_batches(a, rank, device)
+
+    def step(i):
+        b = batches[i % len(batches)]
+        opt.zero_grad()
+        reducer.begin_backward()
+        loss = model.cloze_loss({'asin': b['items']}, b['labels'], training=True, flat_idx=b['flat_idx'])
+        loss.backward()
+        reducer.finish()
+        opt.step(reducer.grad_mul)
+        return loss
+
+    for i in range(a.warmup):
+        loss = step(i)
+    ops.enable_timer(a.roofline_kernel)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    rr = torch.tensor([sum(batches[(a.warmup + i) % len(batches)]['R'] for i in range(a.steps))], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+    dt, items = float(tt[0]), float(rr[0])
+    k_ms, k_n = ops.timer_results_ms(a.roofline_kernel)
+
+    if rank == 0:
+        R = batches[0]['R']
+        roof = roofline_for(a.roofline_kernel, a, R, k_ms)
+        roof['frac'] = roof['achieved'] / roof['peak']
+        roof['avg_launch_ms'] = k_ms
+        roof['launches_timed'] = k_n
+        roof['traffic'] = None
+        if a.traffic_json and os.path.exists(a.traffic_json):
+            with open(a.traffic_json) as f:
+                roof['traffic'] = json.load(f).get(a.roofline_kernel)
+        out = {
+            'metric': 'masked-items/sec (whole node)', 'value': items / dt, 'unit': 'masked-items/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if a.dtype == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BERT4Rec Cloze training step: vocab=%d seq_len=%d d_model=%d layers=%d heads=%d dff=100 '
+                                   'head=[1024,512,256,128]->V batch=%d seq/GPU x %d GPU, 10 masked/seq, dropout=%.2f, Zipf(1.1) ids'
+                                   % (a.vocab, a.seq, a.d_model, a.layers, a.heads, a.batch, world, a.dropout),
+                       'global_batch': a.batch * world, 'seq_len': a.seq, 'parallelism': 'dp%d' % world,
+                       'grad_reduce': 'sum (reference semantics)'},
+            'tokens_per_s': a.batch * world * a.seq * a.steps / dt,
+            'final_loss': float(loss),
+            'roofline': roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,76 @@
+"""ctypes binding of libb4c_hip.so (include/b4c.h).  There is no CPU fallback: if the
+library is missing, or a call fails, this raises -- the product path is the HIP path."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libb4c_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'b4c.h')
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+CE_TF, CE_PLAIN = 0, 1
+MAX_FEATURES, MAX_TOPK = 4, 16
+
+
+class B4CError(RuntimeError):
+    pass
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Names of every function include/b4c.h declares (used by the symbol-export test)."""
+    with open(header_path) as f:
+        src = f.read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(b4c_[a-z0-9_]+)\s*\(', src)))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise B4CError(
+                'libb4c_hip.so not found at %s: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(or `make -C bert4clickpath_amd/csrc`).  There is no CPU fallback.' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        c = ctypes
+        vp, i32, i64, f32, u64 = c.c_void_p, c.c_int, c.c_int64, c.c_float, c.c_uint64
+        pp = c.POINTER(c.c_void_p)
+        sig = {
+            'b4c_abi_version': (i32, []),
+            'b4c_last_error': (c.c_char_p, []),
+            'b4c_keep': (i32, [u64, u64, f32]),
+            'b4c_embed_concat_pe_fwd': (i32, [i32, pp, pp, c.POINTER(i32), c.POINTER(i64), vp, f32, vp, i32, vp, i32, i32, i32, f32, u64, i32, vp]),
+            'b4c_embed_concat_pe_bwd': (i32, [i32, pp, pp, c.POINTER(i32), c.POINTER(i64), f32, vp, i32, i32, i32, i32, f32, u64, i32, vp]),
+            'b4c_pack_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, vp]),
+            'b4c_gemm_nt': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
+            'b4c_gemm_tn': (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+            'b4c_attn_fwd': (i32, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+            'b4c_attn_bwd': (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+            'b4c_add_dropout_layernorm_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, u64, i32, vp]),
+            'b4c_add_dropout_layernorm_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, i32, vp]),
+            'b4c_mask_positions': (i32, [vp, i32, i32, i64, vp, vp, vp, i32, vp, vp]),
+            'b4c_padded_index': (i32, [vp, vp, vp, i32, i32, vp, vp]),
+            'b4c_gather_rows': (i32, [vp, i32, vp, vp, i32, i64, i32, i32, vp]),
+            'b4c_scatter_rows': (i32, [vp, i32, vp, vp, i32, i64, i64, i32, i32, vp]),
+            'b4c_softmax_rows': (i32, [vp, i32, vp, i32, i64, i32, i32, vp]),
+            'b4c_sparse_ce_from_probs': (i32, [vp, i32, vp, vp, vp, i64, i32, i32, i32, vp]),
+            'b4c_softmax_ce_fwd_bwd': (i32, [vp, i32, vp, vp, vp, i64, i32, i32, i32, vp]),
+            'b4c_topk_rows': (i32, [vp, i32, i64, i32, i32, vp, vp, vp, vp, i32, vp]),
+            'b4c_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise B4CError('%s failed (rc=%d): %s' % (what or 'b4c call', rc, lib().b4c_last_error().decode()))

@@ -1,0 +1,243 @@
+"""ClickstreamTransformer: the drop-in model surface (reference
+clickstream_transformer/clickstream_transformer.py:8-375), MI355X-native.
+
+Differences forced by the platform, all at the edge:
+  * PyTorch has no string tensors.  Each input feature may be a nested list / numpy array of ``str``
+    (looked up on the host exactly as the reference's StaticVocabularyTable: 10 reserved tokens +
+    vocabulary file, one OOV bucket) or an int64 tensor of already looked-up ids (no specials).
+  * ``cloze_loss`` / ``predict_topk`` are the fused training / ranking entry points: same numbers as
+    ``head(...)`` followed by ClozeMaskedLoss / top_k, without materialising (B*M) x V probabilities.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from .._lib import CE_PLAIN, CE_TF, B4CError
+from .constants import CLS, INPUT_PAD, MASK_ID, RESERVED_TOKENS, SEP, CLASSIFICATION_TOKEN, SEPARATOR_TOKEN
+from .training_utils import load_vocabulary
+from .transformer import Transformer
+
+
+def _is_string_feature(x):
+    if isinstance(x, torch.Tensor):
+        return False
+    a = np.asarray(x)
+    return a.dtype.kind in ('U', 'S', 'O')
+
+
+class TransformerInputPrep:
+    """[CLS] [SEP] seq_1 [SEP] seq_2 [SEP] ... per chained feature (reference :8-103)."""
+
+    def __init__(self, seq_chain_mapping):
+        self.seq_chain_mapping = seq_chain_mapping
+
+    @staticmethod
+    def _chain_sequences(sequences):
+        first = sequences[0]
+        if _is_string_feature(first):
+            seqs = [np.asarray(s, dtype=object) for s in sequences]
+            B = seqs[0].shape[0]
+            cls = np.full((B, 1), CLASSIFICATION_TOKEN, dtype=object)
+            sep = np.full((B, 1), SEPARATOR_TOKEN, dtype=object)
+            parts = [cls, sep]
+            for s in seqs:
+                parts += [s.reshape(B, -1), sep]
+            return np.concatenate(parts, axis=1)
+        seqs = [torch.as_tensor(s) for s in sequences]
+        B = seqs[0].shape[0]
+        cls = torch.full((B, 1), CLS, dtype=seqs[0].dtype, device=seqs[0].device)
+        sep = torch.full((B, 1), SEP, dtype=seqs[0].dtype, device=seqs[0].device)
+        parts = [cls, sep]
+        for s in seqs:
+            parts += [s, sep]
+        return torch.cat(parts, dim=1)
+
+    def __call__(self, features, keep_features=False):
+        features = dict(features)
+        lens = None
+        for new_feature, names in self.seq_chain_mapping.items():
+            seqs = [features[n] for n in names]
+            features[new_feature] = self._chain_sequences(seqs)
+            if lens is None:
+                lens = [int(np.asarray(s).shape[1]) if not isinstance(s, torch.Tensor) else int(s.shape[1]) for s in seqs]
+        # SEP positions are the same in every row (sequences are padded before chaining)
+        ends, pos = [1], 1
+        for n in lens:
+            pos += n + 1
+            ends.append(pos)
+        starts = [0] + [e + 1 for e in ends[:-1]]
+        if not keep_features:
+            drop = set()
+            for names in self.seq_chain_mapping.values():
+                drop |= set(names)
+            features = {k: v for k, v in features.items() if k not in drop}
+        return features, starts, ends
+
+
+class ClickstreamTransformer(nn.Module):
+    def __init__(self, sequential_input_config, feature_vocabs, embedding_dims, head_unit, segment_to_head=None,
+                 value_to_head=None, num_encoder_layers=1, num_attention_heads=1, dropout_rate=0.1,
+                 compute_dtype=torch.float32, **kwargs):
+        super().__init__()
+        self.sequential_input_config = sequential_input_config
+        self.feature_vocabs = feature_vocabs
+        self.embedding_dims = embedding_dims
+        self.head = head_unit
+        self.num_encoder_layers, self.num_attention_heads, self.dropout_rate = \
+            num_encoder_layers, num_attention_heads, dropout_rate
+        assert (segment_to_head is not None or value_to_head is not None) and \
+               (segment_to_head is None or value_to_head is None), \
+               "Exactly one of segment_to_head and value_to_head must be provided."
+        self.segment_to_head, self.value_to_head = segment_to_head, value_to_head
+        self.transformer_input_prep = TransformerInputPrep(self.sequential_input_config)
+        self.vocab_lookup_tables = self._create_lookup_tables(self.feature_vocabs, RESERVED_TOKENS)
+        # KeyError if a feature is embedded but has no vocabulary, as in the reference (:212-217)
+        self.embedding_sizes = {f: self.vocab_lookup_tables[f]['size'] for f in self.feature_vocabs.keys()}
+        self.transformer = Transformer(
+            embedding_sizes={f: self.embedding_sizes[f] for f in self.embedding_dims.keys()},
+            embedding_dims=self.embedding_dims, num_layers=num_encoder_layers,
+            num_attention_heads=num_attention_heads, encoder_ff_dim=100,   # hard-coded in the reference (:225)
+            dropout_rate=dropout_rate, compute_dtype=compute_dtype)
+        if hasattr(self.head, 'build'):
+            self.head.build(self.transformer.d_model)
+
+    @property
+    def compute_dtype(self):
+        return self.transformer.compute_dtype
+
+    def set_compute_dtype(self, dtype):
+        self.transformer.compute_dtype = dtype
+        return self
+
+    def get_config(self):
+        return {'sequential_input_config': self.sequential_input_config, 'feature_vocabs': self.feature_vocabs,
+                'embedding_dims': self.embedding_dims, 'head_unit': self.head, 'segment_to_head': self.segment_to_head,
+                'value_to_head': self.value_to_head, 'num_encoder_layers': self.num_encoder_layers,
+                'num_attention_heads': self.num_attention_heads, 'dropout_rate': self.dropout_rate}
+
+    @staticmethod
+    def _create_lookup_tables(vocabularies, tokens_to_prepend=None):
+        """token -> id over [reserved tokens] + vocabulary lines; one OOV bucket id == len(keys);
+        table size == len(keys) + 1 (reference :247-258, :217)."""
+        tables = {}
+        for feature_name, vocab_file in vocabularies.items():
+            keys = load_vocabulary(vocab_file) if isinstance(vocab_file, str) else [str(t).strip() for t in vocab_file]
+            if tokens_to_prepend is not None:
+                keys = list(tokens_to_prepend) + list(keys)
+            table = {}
+            for i, k in enumerate(keys):
+                table.setdefault(k, i)
+            tables[feature_name] = {'table': table, 'oov': len(keys), 'size': len(keys) + 1}
+        return tables
+
+    def lookup(self, feature_name, tokens):
+        t = self.vocab_lookup_tables[feature_name]
+        table, oov = t['table'], t['oov']
+        a = np.asarray(tokens, dtype=object)
+        flat = np.fromiter((table.get(x if isinstance(x, str) else x.decode(), oov) for x in a.reshape(-1)),
+                           dtype=np.int64, count=a.size)
+        return flat.reshape(a.shape)
+
+    # ---- shared front half: chain, look up, encode -------------------------------------------
+    def _encode(self, inputs, training):
+        raw_features, seg_starts, seg_ends = self.transformer_input_prep(features=inputs)
+        dev = self.transformer.pos_encoding.device
+        if dev.type != 'cuda':
+            raise B4CError('model is on %s: move it to the HIP device with .to("cuda") (no CPU path)' % dev)
+        features = dict(raw_features)
+        for name in self.vocab_lookup_tables.keys():
+            if name not in features:
+                continue
+            x = features[name]
+            if _is_string_feature(x):
+                x = torch.from_numpy(self.lookup(name, x))
+            features[name] = torch.as_tensor(x).to(device=dev, dtype=torch.int64)
+        seq = {name: features[name] for name in self.sequential_input_config.keys()}
+        enc, key_pad = self.transformer(seq, training, None, return_key_pad=True)
+        first = list(self.sequential_input_config.keys())[0]
+        return enc, seq[first], raw_features[first], seg_starts, seg_ends
+
+    def _match_positions(self, ids_first, raw_first, cap=None):
+        """Flat (b*S+s) indices, row-major, where the first feature's RAW value == value_to_head."""
+        name = list(self.sequential_input_config.keys())[0]
+        t = self.vocab_lookup_tables[name]
+        vid = t['table'].get(self.value_to_head, t['oov'])
+        if vid == t['oov'] and _is_string_feature(raw_first):
+            # value_to_head is not a vocabulary entry: ids cannot tell it from other OOV tokens,
+            # so match the raw strings on the host (index generation only).
+            hit = (np.asarray(raw_first, dtype=object) == self.value_to_head)
+            ids_first = torch.from_numpy(np.where(hit, -7, 0).astype(np.int64)).to(ids_first.device)
+            vid = -7
+        return ops.mask_positions(ids_first.contiguous(), int(vid), cap)
+
+    # ---- reference call ------------------------------------------------------------------------
+    def forward(self, inputs, training=None, mask=None, max_matches=None):
+        """inputs: dict feature-name -> (B, Li) strings or int64 ids (+ optional 'instance_id').
+        Returns head_unit(head_input), or {'instance_id', 'logits'} when 'instance_id' is present."""
+        enc, ids_first, raw_first, seg_starts, seg_ends = self._encode(
+            {k: v for k, v in inputs.items() if k != 'instance_id'}, training)
+        B, S, d = enc.shape
+        if self.segment_to_head is not None:
+            head_input = enc[:, seg_starts[self.segment_to_head]:seg_ends[self.segment_to_head], :].contiguous()
+        elif self.value_to_head is not None:
+            counts, offsets, flat, mx = self._match_positions(ids_first, raw_first)
+            M = int(mx.item()) if max_matches is None else int(max_matches)   # .item(): the padded width
+            if M == 0:
+                head_input = enc.new_zeros(B, 0, d)
+            else:
+                pidx = ops.padded_index(counts, offsets, flat, B, M)
+                head_input = ops.GatherRowsFn.apply(enc.reshape(B * S, d), pidx, B * M).view(B, M, d)
+        else:
+            raise ValueError("One of value_to_head and segment_to_head must be provided.")
+        logits = self.head(head_input)
+        if 'instance_id' in inputs.keys():
+            return {'instance_id': inputs['instance_id'], 'logits': logits}
+        return logits
+
+    # ---- fused MI355X entry points ----------------------------------------------------------------
+    def _masked_rows(self, inputs, training, flat_idx=None):
+        enc, ids_first, raw_first, _, _ = self._encode(inputs, training)
+        B, S, d = enc.shape
+        if flat_idx is None:
+            _, offsets, flat, _ = self._match_positions(ids_first, raw_first)
+            R = int(offsets[-1].item())
+            flat_idx = flat[:R]
+        rows = ops.GatherRowsFn.apply(enc.reshape(B * S, d), flat_idx, flat_idx.shape[0])
+        return rows
+
+    def cloze_loss(self, inputs, labels, training=True, flat_idx=None, variant='tf', unit_grad=True):
+        """Masked-item training loss == ClozeMaskedLoss(sparse_categorical_crossentropy)(labels, self(inputs)).
+        labels: (B, M) float32 padded with -1 (reference format) or compact (R,) int ids in row-major
+        mask order.  flat_idx (R,) int32 skips the device-side index generation + host sync."""
+        rows = self._masked_rows(inputs, training, flat_idx)
+        lab = torch.as_tensor(labels, device=rows.device)
+        if lab.dim() == 2:
+            lab = lab[lab != -1.0]
+        lab = lab.to(torch.int32).contiguous()
+        if lab.shape[0] != rows.shape[0]:
+            raise ValueError('%d labels for %d masked positions' % (lab.shape[0], rows.shape[0]))
+        logits = self.head.logits(rows)
+        V = self.head.output_vocab_size
+        return ops.FusedSoftmaxCEFn.apply(logits, lab, V, CE_TF if variant == 'tf' else CE_PLAIN, unit_grad)
+
+    @torch.no_grad()
+    def predict_topk(self, inputs, k, labels=None, flat_idx=None):
+        """Top-k item ids (label space) at every masked position, ranked over all V items.  Ranks the
+        logits (softmax is monotone); returns (topk_idx (R,k) int32, hit (R,), ndcg (R,)) -- the
+        latter two when labels are given."""
+        rows = self._masked_rows(inputs, False, flat_idx)
+        logits = self.head.logits(rows, out_fp32=True)
+        lab = None
+        if labels is not None:
+            lab = torch.as_tensor(labels, device=rows.device)
+            if lab.dim() == 2:
+                lab = lab[lab != -1.0]
+            lab = lab.to(torch.int32).contiguous()
+        return ops.topk_rows(logits, self.head.output_vocab_size, k, lab)
+
+    def get_serving_signature(self):
+        names = []
+        for chain in self.sequential_input_config.values():
+            names.extend(chain)
+        return {n: ('string', [None, None]) for n in names}

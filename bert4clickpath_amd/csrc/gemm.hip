@@ -1,0 +1,371 @@
+// MFMA GEMMs for the dense layers (QKV / out-proj / FFN / head MLP / vocab projection).
+//
+//  gemm_nt : C[M][N]  = epilogue(A[M][K] . Bt[N][K]^T)       forward and backward-dX
+//  gemm_tn : dW[K][N] += A[M][K]^T . G[M][N], db += colsum(G)  backward-dW (reduce over tokens)
+//
+// Both run the same LDS-tiled core: a 128 x 128 output tile per 256-thread workgroup (4 waves as
+// 2 x 2, each wave 64 x 64 = 2 x 2 MFMA 32x32 tiles), operands staged through LDS as
+// [128 rows][128 B of K] with a 16-B row pad (144-B stride: conflict-free ds_read_b128), two LDS
+// stages with register prefetch (global loads for tile t+1 are in flight while tile t is multiplied).
+//   bf16: v_mfma_f32_32x32x16_bf16, 64 K-elements per stage;  fp32: v_mfma_f32_32x32x2_f32 (exact
+//   fp32 FMA chain, parity path), 32 K-elements per stage.
+// gemm_tn stages its operands TRANSPOSED (token-major global rows -> feature-major LDS rows) so the
+// reduction axis (tokens) is contiguous for the fragment reads.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (once per process).
+template <typename K> static void allow_lds(K kernel, size_t bytes) {
+    static thread_local const void *done[16];
+    static thread_local int ndone = 0;
+    for (int i = 0; i < ndone; ++i)
+        if (done[i] == (const void *)kernel) return;
+    (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (ndone < 16) done[ndone++] = (const void *)kernel;
+}
+
+#define TILE 128
+#define LDS_STRIDE 144                     // bytes per tile row (128 + 16 pad)
+#define TILE_BYTES (TILE * LDS_STRIDE)     // 18432
+#define STAGE_BYTES (2 * TILE_BYTES)       // A tile + B tile
+
+template <typename T> struct MM;
+template <> struct MM<bf16_t> {
+    static constexpr int VE = 8;       // elements per 16 B
+    static constexpr int BKE = 64;     // K elements per stage
+    static constexpr int KSTEPS = 4;   // MFMAs per stage along K (16 each)
+    typedef bf16x8 frag_t;
+    static __device__ __forceinline__ frag_t ldfrag(const char *row, int kk, int h) {
+        return *reinterpret_cast<const bf16x8 *>(row + kk * 32 + h * 16);
+    }
+    static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct MM<float> {
+    static constexpr int VE = 4;
+    static constexpr int BKE = 32;
+    static constexpr int KSTEPS = 16;  // 2 each
+    typedef float frag_t;
+    static __device__ __forceinline__ frag_t ldfrag(const char *row, int kk, int h) {
+        return *reinterpret_cast<const float *>(row + (kk * 2 + h) * 4);
+    }
+    static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+};
+
+// one stage of MFMAs: acc[i][j] += A_tile(rows wm*64+i*32..) . B_tile(rows wn*64+j*32..)^T
+template <typename T>
+__device__ __forceinline__ void mma_stage(const char *sA, const char *sB, int wm, int wn, int r, int h, f32x16 (&acc)[2][2]) {
+    const char *a0 = sA + (wm * 64 + r) * LDS_STRIDE;
+    const char *b0 = sB + (wn * 64 + r) * LDS_STRIDE;
+#pragma unroll
+    for (int kk = 0; kk < MM<T>::KSTEPS; ++kk) {
+        const typename MM<T>::frag_t fa0 = MM<T>::ldfrag(a0, kk, h);
+        const typename MM<T>::frag_t fa1 = MM<T>::ldfrag(a0 + 32 * LDS_STRIDE, kk, h);
+        const typename MM<T>::frag_t fb0 = MM<T>::ldfrag(b0, kk, h);
+        const typename MM<T>::frag_t fb1 = MM<T>::ldfrag(b0 + 32 * LDS_STRIDE, kk, h);
+        acc[0][0] = MM<T>::mma(fa0, fb0, acc[0][0]);
+        acc[0][1] = MM<T>::mma(fa0, fb1, acc[0][1]);
+        acc[1][0] = MM<T>::mma(fa1, fb0, acc[1][0]);
+        acc[1][1] = MM<T>::mma(fa1, fb1, acc[1][1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// NT
+// ------------------------------------------------------------------------------------------
+// K-contiguous staging: 128 rows x 128 B = 1024 16-B chunks, 4 per thread; 8 lanes cover one row.
+template <typename T>
+__device__ __forceinline__ void nt_load(const T *__restrict__ P, int ld, int row0, int nrows, int k0, int K, int tid, u32x4 (&reg)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        const int row = c >> 3, cc = c & 7;
+        const int gr = row0 + row, gk = k0 + cc * MM<T>::VE;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (gr < nrows && gk < K) v = *reinterpret_cast<const u32x4 *>(P + (int64_t)gr * ld + gk);
+        reg[i] = v;
+    }
+}
+__device__ __forceinline__ void nt_store(char *s, int tid, const u32x4 (&reg)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        *reinterpret_cast<u32x4 *>(s + (c >> 3) * LDS_STRIDE + (c & 7) * 16) = reg[i];
+    }
+}
+
+template <typename T, typename OutT>
+__global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, int lda, const T *__restrict__ Bt, int ldb,
+                                                      OutT *__restrict__ C, int ldc, int M, int N, int K,
+                                                      const float *__restrict__ bias, int act, const T *__restrict__ gate,
+                                                      int ldg, const T *__restrict__ residual, int ldr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+
+    const int nk = (K + MM<T>::BKE - 1) / MM<T>::BKE;
+    u32x4 ra[4], rb[4];
+    nt_load<T>(A, lda, m0, M, 0, K, tid, ra);
+    nt_load<T>(Bt, ldb, n0, N, 0, K, tid, rb);
+    nt_store(smem, tid, ra);
+    nt_store(smem + TILE_BYTES, tid, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        char *cur = smem + (kt & 1) * STAGE_BYTES;
+        char *nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            nt_load<T>(A, lda, m0, M, (kt + 1) * MM<T>::BKE, K, tid, ra);
+            nt_load<T>(Bt, ldb, n0, N, (kt + 1) * MM<T>::BKE, K, tid, rb);
+        }
+        mma_stage<T>(cur, cur + TILE_BYTES, wm, wn, r, h, acc);
+        if (more) {
+            nt_store(nxt, tid, ra);
+            nt_store(nxt + TILE_BYTES, tid, rb);
+        }
+        __syncthreads();
+    }
+    // epilogue.  acc register t of tile (i,j): row = (t&3) + 8*(t>>2) + 4*h, col = lane&31.
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+            const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int row = m0 + wm * 64 + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+                if (row < M && col < N) {
+                    float v = acc[i][j][t] + bv;
+                    if (act == B4C_ACT_RELU) v = fmaxf(v, 0.f);
+                    if (gate) v = ((float)gate[(int64_t)row * ldg + col] > 0.f) ? v : 0.f;
+                    if (residual) v += (float)residual[(int64_t)row * ldr + col];
+                    C[(int64_t)row * ldc + col] = (OutT)v;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void *C, int ldc, int M, int N, int K,
+                           const float *bias, int act, const void *gate, int ldg, const void *residual, int ldr,
+                           int dtype, int out_dtype, void *stream) {
+    B4C_REQUIRE(A && Bt && C && M > 0 && N > 0 && K > 0, "gemm_nt: null pointer / empty (M=%d N=%d K=%d)", M, N, K);
+    B4C_REQUIRE(dtype == B4C_F32 || dtype == B4C_BF16, "gemm_nt: dtype %d", dtype);
+    const int ve = dtype == B4C_BF16 ? 8 : 4;
+    B4C_REQUIRE(K % ve == 0 && lda % ve == 0 && ldb % ve == 0 && lda >= K && ldb >= K,
+                "gemm_nt: K=%d lda=%d ldb=%d must be multiples of %d with ld >= K", K, lda, ldb, ve);
+    B4C_REQUIRE(ldc >= N, "gemm_nt: ldc %d < N %d", ldc, N);
+    B4C_REQUIRE((((uintptr_t)A | (uintptr_t)Bt) & 15) == 0, "gemm_nt: operands must be 16-byte aligned");
+    B4C_REQUIRE(out_dtype == dtype || out_dtype == B4C_F32, "gemm_nt: out_dtype %d", out_dtype);
+    B4C_REQUIRE(act == B4C_ACT_NONE || act == B4C_ACT_RELU, "gemm_nt: act %d", act);
+    dim3 grid((M + TILE - 1) / TILE, (N + TILE - 1) / TILE);
+    B4C_REQUIRE(grid.y <= 65535, "gemm_nt: N too large");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t shm = 2 * STAGE_BYTES;
+    allow_lds(gemm_nt_kernel<float, float>, shm);
+    allow_lds(gemm_nt_kernel<bf16_t, float>, shm);
+    allow_lds(gemm_nt_kernel<bf16_t, bf16_t>, shm);
+    if (dtype == B4C_F32)
+        gemm_nt_kernel<float, float><<<grid, 256, shm, st>>>((const float *)A, lda, (const float *)Bt, ldb, (float *)C, ldc, M, N, K, bias, act, (const float *)gate, ldg, (const float *)residual, ldr);
+    else if (out_dtype == B4C_F32)
+        gemm_nt_kernel<bf16_t, float><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (float *)C, ldc, M, N, K, bias, act, (const bf16_t *)gate, ldg, (const bf16_t *)residual, ldr);
+    else
+        gemm_nt_kernel<bf16_t, bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, act, (const bf16_t *)gate, ldg, (const bf16_t *)residual, ldr);
+    return b4c_check_launch("gemm_nt");
+}
+
+// ------------------------------------------------------------------------------------------
+// TN (dW): transposing stage.  Per step a workgroup consumes TOK tokens x 128 features of each
+// operand.  Global rows are token-major; a wave reads whole 256-B / 512-B feature rows (coalesced),
+// each lane keeps its feature(s) for 8 (bf16) / 4 (fp32) consecutive tokens and writes them as one
+// 16-B token-contiguous LDS chunk.
+// ------------------------------------------------------------------------------------------
+template <typename T> struct TNStage;
+
+template <> struct TNStage<bf16_t> {
+    static constexpr int TOK = 64;  // tokens per step; wave w owns tokens [16w, 16w+16)
+    unsigned v[2][8];               // [group of 8 tokens][token] -> features (2*lane, 2*lane+1) packed
+    __device__ __forceinline__ void load(const bf16_t *__restrict__ P, int ld, int f0, int64_t tok0, int64_t tok_end, int lane, int wave) {
+        const int f = f0 + 2 * lane;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t t = tok0 + wave * 16 + g * 8 + j;
+                v[g][j] = (t < tok_end && f < ld) ? *reinterpret_cast<const unsigned *>(P + t * ld + f) : 0u;
+            }
+    }
+    __device__ __forceinline__ void store(char *s, int lane, int wave) const {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            u32x4 lo, hi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned a = v[g][2 * q], b = v[g][2 * q + 1];
+                lo[q] = (a & 0xFFFFu) | (b << 16);
+                hi[q] = (a >> 16) | (b & 0xFFFF0000u);
+            }
+            char *base = s + (2 * lane) * LDS_STRIDE + (wave * 16 + g * 8) * 2;
+            *reinterpret_cast<u32x4 *>(base) = lo;
+            *reinterpret_cast<u32x4 *>(base + LDS_STRIDE) = hi;
+        }
+    }
+    // column sums of this thread's two features over its 16 tokens
+    __device__ __forceinline__ void colsum(float &s0, float &s1) const {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s0 += __uint_as_float(v[g][j] << 16);
+                s1 += __uint_as_float(v[g][j] & 0xFFFF0000u);
+            }
+    }
+    static __device__ __forceinline__ int feat0(int lane) { return 2 * lane; }
+    static __device__ __forceinline__ int feat1(int lane) { return 2 * lane + 1; }
+};
+
+template <> struct TNStage<float> {
+    static constexpr int TOK = 32;  // wave w owns tokens [8w, 8w+8)
+    float v[2][4][2];               // [group of 4 tokens][token][feature lane / lane+64]
+    __device__ __forceinline__ void load(const float *__restrict__ P, int ld, int f0, int64_t tok0, int64_t tok_end, int lane, int wave) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t t = tok0 + wave * 8 + g * 4 + j;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int f = f0 + lane + 64 * q;
+                    v[g][j][q] = (t < tok_end && f < ld) ? P[t * ld + f] : 0.f;
+                }
+            }
+    }
+    __device__ __forceinline__ void store(char *s, int lane, int wave) const {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4 w = {v[g][0][q], v[g][1][q], v[g][2][q], v[g][3][q]};
+                *reinterpret_cast<f32x4 *>(s + (lane + 64 * q) * LDS_STRIDE + (wave * 8 + g * 4) * 4) = w;
+            }
+    }
+    __device__ __forceinline__ void colsum(float &s0, float &s1) const {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s0 += v[g][j][0]; s1 += v[g][j][1]; }
+    }
+    static __device__ __forceinline__ int feat0(int lane) { return lane; }
+    static __device__ __forceinline__ int feat1(int lane) { return lane + 64; }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(const T *__restrict__ A, int lda, const T *__restrict__ G, int ldg,
+                                                      float *__restrict__ dW, int ldw, float *__restrict__ db, int64_t M,
+                                                      int K, int N, int64_t chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    const int k0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
+    const int64_t m_begin = blockIdx.z * chunk;
+    const int64_t m_end = (m_begin + chunk < M) ? m_begin + chunk : M;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+    float bs0 = 0.f, bs1 = 0.f;
+    const bool want_db = (db != nullptr) && blockIdx.x == 0;
+
+    constexpr int TOK = TNStage<T>::TOK;
+    const int nsteps = (int)((m_end - m_begin + TOK - 1) / TOK);
+    TNStage<T> sa, sg;
+    if (nsteps > 0) {
+        sa.load(A, lda, k0, m_begin, m_end, lane, wave);
+        sg.load(G, ldg, n0, m_begin, m_end, lane, wave);
+        sa.store(smem, lane, wave);
+        sg.store(smem + TILE_BYTES, lane, wave);
+        if (want_db) sg.colsum(bs0, bs1);
+    }
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        char *cur = smem + (st & 1) * STAGE_BYTES;
+        char *nxt = smem + ((st + 1) & 1) * STAGE_BYTES;
+        const bool more = st + 1 < nsteps;
+        if (more) {
+            sa.load(A, lda, k0, m_begin + (int64_t)(st + 1) * TOK, m_end, lane, wave);
+            sg.load(G, ldg, n0, m_begin + (int64_t)(st + 1) * TOK, m_end, lane, wave);
+        }
+        mma_stage<T>(cur, cur + TILE_BYTES, wm, wn, r, h, acc);
+        if (more) {
+            sa.store(nxt, lane, wave);
+            sg.store(nxt + TILE_BYTES, lane, wave);
+            if (want_db) sg.colsum(bs0, bs1);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int row = k0 + wm * 64 + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+                if (row < K && col < N) atomicAdd(dW + (int64_t)row * ldw + col, acc[i][j][t]);
+            }
+        }
+    if (want_db) {
+        // the 4 waves hold partial sums of the same features over different tokens
+        float *red = reinterpret_cast<float *>(smem);  // all MFMA reads are behind the last barrier
+        red[wave * 128 + TNStage<T>::feat0(lane)] = bs0;
+        red[wave * 128 + TNStage<T>::feat1(lane)] = bs1;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N)
+            atomicAdd(db + n0 + tid, red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid]);
+    }
+}
+
+extern "C" int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float *dW, int ldw, float *db, int M, int K,
+                           int N, int dtype, void *stream) {
+    B4C_REQUIRE(A && G && dW && M > 0 && K > 0 && N > 0, "gemm_tn: null pointer / empty");
+    B4C_REQUIRE(dtype == B4C_F32 || dtype == B4C_BF16, "gemm_tn: dtype %d", dtype);
+    B4C_REQUIRE(lda >= K && ldg >= N && ldw >= N, "gemm_tn: pitches too small (lda=%d K=%d ldg=%d N=%d ldw=%d)", lda, K, ldg, N, ldw);
+    B4C_REQUIRE(lda % 2 == 0 && ldg % 2 == 0, "gemm_tn: operand pitches must be even");
+    B4C_REQUIRE((((uintptr_t)A | (uintptr_t)G) & 3) == 0, "gemm_tn: operands must be 4-byte aligned");
+    const int tk = (K + TILE - 1) / TILE, tn = (N + TILE - 1) / TILE;
+    const int tok = dtype == B4C_BF16 ? 64 : 32;
+    int64_t nsplit = 2048 / ((int64_t)tk * tn);
+    const int64_t max_split = ceil_div64(M, (int64_t)tok * 4);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 65535) nsplit = 65535;
+    int64_t chunk = ceil_div64(ceil_div64(M, nsplit), tok) * tok;
+    nsplit = ceil_div64(M, chunk);
+    dim3 grid(tk, tn, (unsigned)nsplit);
+    B4C_REQUIRE(tn <= 65535, "gemm_tn: N too large");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t shm = 2 * STAGE_BYTES;
+    allow_lds(gemm_tn_kernel<float>, shm);
+    allow_lds(gemm_tn_kernel<bf16_t>, shm);
+    if (dtype == B4C_F32)
+        gemm_tn_kernel<float><<<grid, 256, shm, st>>>((const float *)A, lda, (const float *)G, ldg, dW, ldw, db, M, K, N, chunk);
+    else
+        gemm_tn_kernel<bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, dW, ldw, db, M, K, N, chunk);
+    return b4c_check_launch("gemm_tn");
+}

@@ -1,0 +1,387 @@
+// Vocabulary-wide row kernels of the MLM head: softmax, masked sparse cross-entropy (the
+// reference's clip -> log -> log-softmax form, and the fused training form that turns logits into
+// their gradient in place), top-k item ids with HitRate / NDCG terms.
+// One workgroup per row; a row of V <= 65536 logits lives in registers (8 x 8 x 1024 lanes) for
+// the fused kernel, so HBM sees each logit once in and once out.
+#include <math.h>
+
+#include "common.h"
+
+#define KERAS_EPS 1e-7f
+
+// block-wide reductions over NW waves; result broadcast to every thread.  `buf` >= NW floats.
+template <int NW> __device__ __forceinline__ float block_sum(float v, float *buf) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += buf[i];
+    return t;
+}
+template <int NW> __device__ __forceinline__ float block_max(float v, float *buf) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t = fmaxf(t, buf[i]);
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// softmax over V (materialised probabilities: the drop-in surface of SoftMaxHead)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const T *__restrict__ x, int ld_in, T *__restrict__ y, int ld_out,
+                                                           int64_t R, int V) {
+    __shared__ float buf[4];
+    const int tid = threadIdx.x;
+    const int nch = (V + 7) >> 3;
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        const T *xr = x + row * ld_in;
+        T *yr = y + row * ld_out;
+        float m = -INFINITY;
+        for (int c = tid; c < nch; c += 256) {
+            float v[8];
+            Vec8<T>::load(xr + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c * 8 + k < V) m = fmaxf(m, v[k]);
+        }
+        m = block_max<4>(m, buf);
+        float s = 0.f;
+        for (int c = tid; c < nch; c += 256) {
+            float v[8];
+            Vec8<T>::load(xr + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c * 8 + k < V) s += expf(v[k] - m);
+        }
+        s = block_sum<4>(s, buf);
+        const int nch_out = ld_out >> 3;
+        for (int c = tid; c < nch_out; c += 256) {
+            float v[8];
+            if (c < nch) Vec8<T>::load(xr + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (c * 8 + k < V) ? expf(v[k] - m) / s : 0.f;
+            Vec8<T>::store(yr + c * 8, v);
+        }
+    }
+}
+
+extern "C" int b4c_softmax_rows(const void *logits, int ld_in, void *probs, int ld_out, int64_t R, int V, int dtype,
+                                void *stream) {
+    B4C_REQUIRE(logits && probs && R >= 0 && V > 0, "softmax_rows: bad argument");
+    B4C_REQUIRE(ld_in % 8 == 0 && ld_out % 8 == 0 && ld_in >= V && ld_out >= V, "softmax_rows: pitches must be multiples of 8 and >= V");
+    if (R == 0) return B4C_OK;
+    const int grid = (int)(R < 4096 ? R : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32) softmax_rows_kernel<float><<<grid, 256, 0, st>>>((const float *)logits, ld_in, (float *)probs, ld_out, R, V);
+    else if (dtype == B4C_BF16) softmax_rows_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t *)logits, ld_in, (bf16_t *)probs, ld_out, R, V);
+    else B4C_REQUIRE(false, "softmax_rows: dtype %d", dtype);
+    return b4c_check_launch("softmax_rows");
+}
+
+// ------------------------------------------------------------------------------------------
+// masked sparse CE on probabilities (reference dataflow)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) sparse_ce_probs_kernel(const T *__restrict__ p, int ld, const float *__restrict__ labels,
+                                                              float *__restrict__ item_loss, float *__restrict__ n_valid,
+                                                              int64_t R, int V, int variant) {
+    __shared__ float buf[4];
+    const int tid = threadIdx.x;
+    const int nch = (V + 7) >> 3;
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        const float lab = labels[row];
+        if (lab == -1.0f) {   // LABEL_PAD: masked out, not counted (losses.py:50-51, 69)
+            if (tid == 0) item_loss[row] = 0.f;
+            continue;
+        }
+        const int y = (int)lab;
+        if (y < 0 || y >= V) {  // TF: InvalidArgument on CPU / NaN on GPU
+            if (tid == 0) { item_loss[row] = NAN; atomicAdd(n_valid, 1.0f); }
+            continue;
+        }
+        const T *pr = p + row * ld;
+        float loss;
+        if (variant == B4C_CE_PLAIN) {
+            loss = -logf((float)pr[y]);
+        } else {
+            float s = 0.f;
+            for (int c = tid; c < nch; c += 256) {
+                float v[8];
+                Vec8<T>::load(pr + c * 8, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c * 8 + k < V) s += fminf(fmaxf(v[k], KERAS_EPS), 1.0f - KERAS_EPS);
+            }
+            s = block_sum<4>(s, buf);
+            const float py = fminf(fmaxf((float)pr[y], KERAS_EPS), 1.0f - KERAS_EPS);
+            loss = logf(s) - logf(py);
+        }
+        if (tid == 0) { item_loss[row] = loss; atomicAdd(n_valid, 1.0f); }
+    }
+}
+
+extern "C" int b4c_sparse_ce_from_probs(const void *probs, int ld, const float *labels, float *item_loss,
+                                        float *n_valid, int64_t R, int V, int variant, int dtype, void *stream) {
+    B4C_REQUIRE(probs && labels && item_loss && n_valid && R >= 0 && V > 0, "sparse_ce_from_probs: bad argument");
+    B4C_REQUIRE(ld % 8 == 0 && ld >= V, "sparse_ce_from_probs: pitch");
+    B4C_REQUIRE(variant == B4C_CE_TF || variant == B4C_CE_PLAIN, "sparse_ce_from_probs: variant %d", variant);
+    if (R == 0) return B4C_OK;
+    const int grid = (int)(R < 4096 ? R : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32) sparse_ce_probs_kernel<float><<<grid, 256, 0, st>>>((const float *)probs, ld, labels, item_loss, n_valid, R, V, variant);
+    else if (dtype == B4C_BF16) sparse_ce_probs_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t *)probs, ld, labels, item_loss, n_valid, R, V, variant);
+    else B4C_REQUIRE(false, "sparse_ce_from_probs: dtype %d", dtype);
+    return b4c_check_launch("sparse_ce_from_probs");
+}
+
+// ------------------------------------------------------------------------------------------
+// fused training form: logits -> loss, dlogits in place.  1024 threads / row, row in registers.
+//   p = softmax(x);  tf variant (loss = log sum_j clip(p_j) - log clip(p_y)):
+//     u_j = [eps <= p_j <= 1-eps],  S = sum clip(p),  Pu = sum u p,
+//     dL/dp_j = u_j (1/S - [j=y]/clip(p_y)),   G = sum_j p_j dL/dp_j = Pu/S - u_y p_y/clip(p_y)
+//     dL/dx_j = p_j (dL/dp_j - G)
+//   plain variant: dL/dx_j = p_j - [j=y]
+// ------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ void __launch_bounds__(1024) softmax_ce_fused_kernel(T *__restrict__ x, int ld, const int32_t *__restrict__ labels,
+                                                                float *__restrict__ item_loss, const float *__restrict__ grad_scale,
+                                                                int64_t R, int V, int variant) {
+    __shared__ float buf[16];
+    __shared__ float s_py;
+    const int tid = threadIdx.x;
+    const int nch_ld = ld >> 3;
+    const float gs = grad_scale[0];
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        T *xr = x + row * ld;
+        const int y = labels[row];
+        const bool valid = y >= 0 && y < V;
+        float v[NCH][8];
+        if (!valid) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = i * 1024 + tid;
+                if (c < nch_ld) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
+                    Vec8<T>::store(xr + c * 8, v[i]);
+                }
+            }
+            if (tid == 0) item_loss[row] = (y >= V) ? NAN : 0.f;
+            continue;
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 1024 + tid;
+            if (c < nch_ld) {
+                Vec8<T>::load(xr + c * 8, v[i]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (c * 8 + k >= V) v[i][k] = -INFINITY;
+                    m = fmaxf(m, v[i][k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[i][k] = -INFINITY;
+            }
+        }
+        m = block_max<16>(m, buf);
+        float z = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[i][k] = expf(v[i][k] - m);   // exp(-inf) = 0 for pad columns
+                z += v[i][k];
+            }
+        z = block_sum<16>(z, buf);
+        const float invz = 1.0f / z;
+        float S = 0.f, Pu = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 1024 + tid;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float p = v[i][k] * invz;
+                v[i][k] = p;
+                const int j = c * 8 + k;
+                if (j < V) {
+                    S += fminf(fmaxf(p, KERAS_EPS), 1.0f - KERAS_EPS);
+                    if (p >= KERAS_EPS && p <= 1.0f - KERAS_EPS) Pu += p;
+                    if (j == y) s_py = p;
+                }
+            }
+        }
+        if (variant == B4C_CE_TF) {
+            S = block_sum<16>(S, buf);
+            Pu = block_sum<16>(Pu, buf);
+        } else {
+            __syncthreads();
+        }
+        const float py = s_py;
+        const float pyc = fminf(fmaxf(py, KERAS_EPS), 1.0f - KERAS_EPS);
+        const float uy = (py >= KERAS_EPS && py <= 1.0f - KERAS_EPS) ? 1.f : 0.f;
+        float loss, G = 0.f, invS = 0.f;
+        if (variant == B4C_CE_TF) {
+            loss = logf(S) - logf(pyc);
+            invS = 1.0f / S;
+            G = Pu * invS - uy * py / pyc;
+        } else {
+            loss = -logf(py);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 1024 + tid;
+            if (c < nch_ld) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int j = c * 8 + k;
+                    const float p = v[i][k];
+                    float g;
+                    if (variant == B4C_CE_TF) {
+                        const float u = (p >= KERAS_EPS && p <= 1.0f - KERAS_EPS) ? 1.f : 0.f;
+                        g = p * (u * (invS - (j == y ? 1.0f / pyc : 0.f)) - G);
+                    } else {
+                        g = p - (j == y ? 1.f : 0.f);
+                    }
+                    v[i][k] = (j < V) ? g * gs : 0.f;
+                }
+                Vec8<T>::store(xr + c * 8, v[i]);
+            }
+        }
+        if (tid == 0) item_loss[row] = loss;
+        __syncthreads();  // s_py / buf reuse by the next row
+    }
+}
+
+extern "C" int b4c_softmax_ce_fwd_bwd(void *logits, int ld, const int32_t *labels, float *item_loss,
+                                      const float *grad_scale, int64_t R, int V, int variant, int dtype, void *stream) {
+    B4C_REQUIRE(logits && labels && item_loss && grad_scale && R >= 0 && V > 0, "softmax_ce_fwd_bwd: bad argument");
+    B4C_REQUIRE(ld % 8 == 0 && ld >= V, "softmax_ce_fwd_bwd: pitch");
+    B4C_REQUIRE(variant == B4C_CE_TF || variant == B4C_CE_PLAIN, "softmax_ce_fwd_bwd: variant %d", variant);
+    B4C_REQUIRE(ld <= 8 * 8 * 1024, "softmax_ce_fwd_bwd: V=%d exceeds the register-resident limit 65536 (use a sampled head)", V);
+    if (R == 0) return B4C_OK;
+    const int nch = (int)ceil_div64(ld / 8, 1024);
+    const int grid = (int)(R < 2048 ? R : 2048);
+    hipStream_t st = (hipStream_t)stream;
+#define CE_LAUNCH(T, N) softmax_ce_fused_kernel<T, N><<<grid, 1024, 0, st>>>((T *)logits, ld, labels, item_loss, grad_scale, R, V, variant)
+#define CE_DISPATCH(T)                        \
+    if (nch <= 1) CE_LAUNCH(T, 1);            \
+    else if (nch <= 2) CE_LAUNCH(T, 2);       \
+    else if (nch <= 4) CE_LAUNCH(T, 4);       \
+    else CE_LAUNCH(T, 8);
+    if (dtype == B4C_F32) { CE_DISPATCH(float) }
+    else if (dtype == B4C_BF16) { CE_DISPATCH(bf16_t) }
+    else B4C_REQUIRE(false, "softmax_ce_fwd_bwd: dtype %d", dtype);
+    return b4c_check_launch("softmax_ce_fwd_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// top-k: per-thread sorted lists -> LDS -> k rounds of block arg-max.  Order: larger value first,
+// equal values -> lower index first (tf.math.top_k).  NaNs never enter a list.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool better(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
+
+template <typename T, int KM>
+__global__ void __launch_bounds__(256) topk_rows_kernel(const T *__restrict__ x, int ld, int64_t R, int V, int k,
+                                                        int32_t *__restrict__ topk_idx, const int32_t *__restrict__ labels,
+                                                        float *__restrict__ hit, float *__restrict__ ndcg) {
+    __shared__ float lv[256][KM + 1];
+    __shared__ int li[256][KM + 1];
+    __shared__ float wv[4];
+    __shared__ int wi[4], wo[4];
+    __shared__ int s_owner;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = (V + 7) >> 3;
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        const T *xr = x + row * ld;
+        float tv[KM];
+        int ti[KM];
+#pragma unroll
+        for (int q = 0; q < KM; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
+        for (int c = tid; c < nch; c += 256) {
+            float v[8];
+            Vec8<T>::load(xr + c * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = c * 8 + e;
+                if (j < V && better(v[e], j, tv[KM - 1], ti[KM - 1])) {
+                    tv[KM - 1] = v[e];
+                    ti[KM - 1] = j;
+#pragma unroll
+                    for (int q = KM - 1; q > 0; --q) {
+                        if (better(tv[q], ti[q], tv[q - 1], ti[q - 1])) {
+                            const float fv = tv[q]; tv[q] = tv[q - 1]; tv[q - 1] = fv;
+                            const int fi = ti[q]; ti[q] = ti[q - 1]; ti[q - 1] = fi;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KM; ++q) { lv[tid][q] = tv[q]; li[tid][q] = ti[q]; }
+        lv[tid][KM] = -INFINITY; li[tid][KM] = 0x7fffffff;
+        int hp = 0;
+        const int lab = labels ? labels[row] : -1;
+        float h_acc = 0.f, n_acc = 0.f;
+        for (int kk = 0; kk < k; ++kk) {
+            float bv = lv[tid][hp];
+            int bi = li[tid][hp], bo = tid;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const int oi = __shfl_xor(bi, o), oo = __shfl_xor(bo, o);
+                if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; bo = oo; }
+            }
+            __syncthreads();
+            if (lane == 0) { wv[wave] = bv; wi[wave] = bi; wo[wave] = bo; }
+            __syncthreads();
+            if (tid == 0) {
+                float fv = wv[0]; int fi = wi[0], fo = wo[0];
+                for (int w = 1; w < 4; ++w)
+                    if (better(wv[w], wi[w], fv, fi)) { fv = wv[w]; fi = wi[w]; fo = wo[w]; }
+                s_owner = fo;
+                topk_idx[row * k + kk] = fi == 0x7fffffff ? -1 : fi;
+                if (labels && fi == lab) {
+                    h_acc += 1.f;
+                    n_acc += 1.0f / (logf((float)(kk + 2)) / logf(2.0f));
+                }
+            }
+            __syncthreads();
+            if (tid == s_owner && hp < KM) ++hp;
+        }
+        if (tid == 0) {
+            if (hit) hit[row] = h_acc;
+            if (ndcg) ndcg[row] = n_acc;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int b4c_topk_rows(const void *scores, int ld, int64_t R, int V, int k, int32_t *topk_idx,
+                             const int32_t *labels, float *hit, float *ndcg, int dtype, void *stream) {
+    B4C_REQUIRE(scores && topk_idx && R >= 0 && V > 0, "topk_rows: bad argument");
+    B4C_REQUIRE(k >= 1 && k <= B4C_MAX_TOPK && k <= V, "topk_rows: k=%d must be in [1, min(%d, V)]", k, B4C_MAX_TOPK);
+    B4C_REQUIRE(ld % 8 == 0 && ld >= V, "topk_rows: pitch");
+    if (R == 0) return B4C_OK;
+    const int grid = (int)(R < 4096 ? R : 4096);
+    hipStream_t st = (hipStream_t)stream;
+#define TOPK_LAUNCH(T, KM) topk_rows_kernel<T, KM><<<grid, 256, 0, st>>>((const T *)scores, ld, R, V, k, topk_idx, labels, hit, ndcg)
+#define TOPK_DISPATCH(T)                  \
+    if (k <= 1) TOPK_LAUNCH(T, 1);        \
+    else if (k <= 4) TOPK_LAUNCH(T, 4);   \
+    else if (k <= 8) TOPK_LAUNCH(T, 8);   \
+    else TOPK_LAUNCH(T, 16);
+    if (dtype == B4C_F32) { TOPK_DISPATCH(float) }
+    else if (dtype == B4C_BF16) { TOPK_DISPATCH(bf16_t) }
+    else B4C_REQUIRE(false, "topk_rows: dtype %d", dtype);
+    return b4c_check_launch("topk_rows");
+}

@@ -1,0 +1,602 @@
+// HBM-bound row kernels: embedding stage, residual+dropout+LayerNorm, [MASK]-row index
+// generation / gather / scatter, weight packing, Adam.  gfx950, wave64, 16-byte accesses.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void b4c_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int b4c_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        b4c_set_error("%s: %s", what, hipGetErrorString(e));
+        return B4C_ELAUNCH;
+    }
+    return B4C_OK;
+}
+extern "C" const char *b4c_last_error(void) { return g_err; }
+extern "C" int b4c_abi_version(void) { return 1; }
+extern "C" int b4c_keep(uint64_t seed, uint64_t e, float rate) { return b4c_keep_elem(seed, e, rate) ? 1 : 0; }
+
+// ------------------------------------------------------------------------------------------
+// embedding stage
+// ------------------------------------------------------------------------------------------
+struct EmbedArgs {
+    const int64_t *ids[B4C_MAX_FEATURES];
+    float *table[B4C_MAX_FEATURES];   // const for fwd; gradient tables for bwd
+    int64_t rows[B4C_MAX_FEATURES];
+    int col0[B4C_MAX_FEATURES + 1];   // column offset of each feature in the d_model-wide row
+    int n;
+};
+
+// one thread = 8 consecutive output columns of one token (a 16-B bf16 / 32-B fp32 store)
+template <typename T>
+__global__ void __launch_bounds__(256) embed_fwd_kernel(EmbedArgs a, const float *__restrict__ pe, float scale,
+                                                        T *__restrict__ out, int ld_out, uint8_t *__restrict__ key_pad,
+                                                        int64_t T_tok, int S, int d, float rate, uint64_t seed) {
+    const int cpr = d >> 3;  // 8-column chunks per row
+    const int64_t total = T_tok * cpr;
+    const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / cpr;
+        const int c = (int)(i - t * cpr) << 3;
+        const int s = (int)(t % S);
+        int f = 0;
+#pragma unroll
+        for (int k = 1; k < B4C_MAX_FEATURES; ++k)
+            if (k < a.n && c >= a.col0[k]) f = k;
+        int64_t id = a.ids[f][t];
+        if (c == 0 && key_pad) key_pad[t] = (a.ids[0][t] == 0) ? 1 : 0;
+        id = id < 0 ? 0 : (id >= a.rows[f] ? a.rows[f] - 1 : id);
+        const int fd = a.col0[f + 1] - a.col0[f];
+        const int cf = c - a.col0[f];
+        float v[8], p[8];
+        const float *src = a.table[f] + id * fd + cf;
+        // a feature's width need not be a multiple of 8: chunks may straddle features only if the
+        // host let them; the host guarantees every feature dim % 8 == 0.
+        Vec8<float>::load(src, v);
+        Vec8<float>::load(pe + (int64_t)s * d + c, p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float x = v[k] * scale + p[k];
+            if (rate > 0.f) x = b4c_keep_elem(seed, (uint64_t)(t * d + c + k), rate) ? x * inv_keep : 0.f;
+            v[k] = x;
+        }
+        Vec8<T>::store(out + t * ld_out + c, v);
+    }
+}
+
+// scatter-add into the fp32 gradient tables; one lane = one column so that a wave-instruction
+// adds 256 contiguous bytes (MI355X float-atomic rate shape).  Exact zeros (pad rows) are skipped.
+template <typename T>
+__global__ void __launch_bounds__(256) embed_bwd_kernel(EmbedArgs a, float scale, const T *__restrict__ dout, int ld,
+                                                        int64_t T_tok, int d, float rate, uint64_t seed) {
+    const int64_t total = T_tok * d;
+    const float mul = scale * (rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / d;
+        const int c = (int)(i - t * d);
+        float g = (float)dout[t * ld + c];
+        if (g == 0.f) continue;
+        if (rate > 0.f && !b4c_keep_elem(seed, (uint64_t)i, rate)) continue;
+        int f = 0;
+#pragma unroll
+        for (int k = 1; k < B4C_MAX_FEATURES; ++k)
+            if (k < a.n && c >= a.col0[k]) f = k;
+        int64_t id = a.ids[f][t];
+        id = id < 0 ? 0 : (id >= a.rows[f] ? a.rows[f] - 1 : id);
+        const int fd = a.col0[f + 1] - a.col0[f];
+        atomicAdd(a.table[f] + id * fd + (c - a.col0[f]), g * mul);
+    }
+}
+
+static int fill_embed_args(EmbedArgs &a, int n_feat, const int64_t *const *h_ids, float *const *h_tables,
+                           const int *h_dims, const int64_t *h_rows, int d_model) {
+    B4C_REQUIRE(n_feat >= 1 && n_feat <= B4C_MAX_FEATURES, "embed: n_feat %d out of range", n_feat);
+    memset(&a, 0, sizeof(a));
+    a.n = n_feat;
+    int off = 0;
+    for (int f = 0; f < n_feat; ++f) {
+        B4C_REQUIRE(h_dims[f] > 0 && h_dims[f] % 8 == 0, "embed: feature dim %d must be a positive multiple of 8", h_dims[f]);
+        B4C_REQUIRE(h_ids[f] && h_tables[f] && h_rows[f] > 0, "embed: null pointer / empty table for feature %d", f);
+        a.ids[f] = h_ids[f];
+        a.table[f] = h_tables[f];
+        a.rows[f] = h_rows[f];
+        a.col0[f] = off;
+        off += h_dims[f];
+    }
+    for (int f = n_feat; f <= B4C_MAX_FEATURES; ++f) a.col0[f] = off;
+    B4C_REQUIRE(off == d_model, "embed: sum of feature dims %d != d_model %d", off, d_model);
+    return B4C_OK;
+}
+
+static inline int grid_for(int64_t work_items, int block) {
+    int64_t g = ceil_div64(work_items, block);
+    const int64_t cap = 256 * 8;  // 256 CUs x 8 blocks, grid-stride the rest
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" int b4c_embed_concat_pe_fwd(int n_feat, const int64_t *const *h_ids, const float *const *h_tables,
+                                       const int *h_dims, const int64_t *h_rows, const float *pe, float scale,
+                                       void *out, int ld_out, uint8_t *key_pad, int B, int S, int d_model,
+                                       float dropout_rate, uint64_t seed, int dtype, void *stream) {
+    EmbedArgs a;
+    int rc = fill_embed_args(a, n_feat, h_ids, (float *const *)h_tables, h_dims, h_rows, d_model);
+    if (rc) return rc;
+    B4C_REQUIRE(pe && out && B > 0 && S > 0 && ld_out >= d_model && ld_out % 8 == 0, "embed_fwd: bad shape");
+    B4C_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f, "embed_fwd: dropout_rate %f", dropout_rate);
+    const int64_t T_tok = (int64_t)B * S;
+    const int grid = grid_for(T_tok * (d_model / 8), 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32)
+        embed_fwd_kernel<float><<<grid, 256, 0, st>>>(a, pe, scale, (float *)out, ld_out, key_pad, T_tok, S, d_model, dropout_rate, seed);
+    else if (dtype == B4C_BF16)
+        embed_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>(a, pe, scale, (bf16_t *)out, ld_out, key_pad, T_tok, S, d_model, dropout_rate, seed);
+    else
+        B4C_REQUIRE(false, "embed_fwd: dtype %d", dtype);
+    return b4c_check_launch("embed_fwd");
+}
+
+extern "C" int b4c_embed_concat_pe_bwd(int n_feat, const int64_t *const *h_ids, float *const *h_dtables,
+                                       const int *h_dims, const int64_t *h_rows, float scale, const void *dout,
+                                       int ld_dout, int B, int S, int d_model, float dropout_rate, uint64_t seed,
+                                       int dtype, void *stream) {
+    EmbedArgs a;
+    int rc = fill_embed_args(a, n_feat, h_ids, h_dtables, h_dims, h_rows, d_model);
+    if (rc) return rc;
+    B4C_REQUIRE(dout && B > 0 && S > 0 && ld_dout >= d_model, "embed_bwd: bad shape");
+    const int64_t T_tok = (int64_t)B * S;
+    const int grid = grid_for(T_tok * d_model, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32)
+        embed_bwd_kernel<float><<<grid, 256, 0, st>>>(a, scale, (const float *)dout, ld_dout, T_tok, d_model, dropout_rate, seed);
+    else if (dtype == B4C_BF16)
+        embed_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(a, scale, (const bf16_t *)dout, ld_dout, T_tok, d_model, dropout_rate, seed);
+    else
+        B4C_REQUIRE(false, "embed_bwd: dtype %d", dtype);
+    return b4c_check_launch("embed_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// residual + dropout + LayerNorm.  A row of d elements is owned by G lanes (8 elements per lane
+// per pass); G is a power of two so rows never straddle a wave.  d <= 1024.
+// ------------------------------------------------------------------------------------------
+#define LN_MAX_PASS 2  // d <= 64 lanes * 8 elems * 2 passes = 1024 (keeps the per-lane row slice in registers)
+
+template <typename T, int G>
+__global__ void __launch_bounds__(256) add_ln_fwd_kernel(const T *__restrict__ x, const T *__restrict__ y,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         T *__restrict__ z, T *__restrict__ out, float *__restrict__ stats,
+                                                         int64_t rows, int d, float eps, float rate, uint64_t seed) {
+    const int lane_in_row = threadIdx.x & (G - 1);
+    const int rows_per_block = 256 / G;
+    const int npass = (d + G * 8 - 1) / (G * 8);
+    const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t row = blockIdx.x * (int64_t)rows_per_block + threadIdx.x / G; row < rows;
+         row += (int64_t)gridDim.x * rows_per_block) {
+        float v[LN_MAX_PASS][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int p = 0; p < LN_MAX_PASS; ++p) {
+            if (p < npass) {
+                const int c = (p * G + lane_in_row) * 8;
+                if (c < d) {
+                    float a[8], b[8];
+                    Vec8<T>::load(x + row * d + c, a);
+                    Vec8<T>::load(y + row * d + c, b);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float yy = b[k];
+                        if (rate > 0.f) yy = b4c_keep_elem(seed, (uint64_t)(row * d + c + k), rate) ? yy * inv_keep : 0.f;
+                        v[p][k] = a[k] + yy;
+                        sum += v[p][k];
+                    }
+                    if (z) Vec8<T>::store(z + row * d + c, v[p]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[p][k] = 0.f;
+                }
+            }
+        }
+        const float mean = group_sum<G>(sum) * inv_d;
+        float sq = 0.f;
+#pragma unroll
+        for (int p = 0; p < LN_MAX_PASS; ++p) {
+            if (p < npass) {
+                const int c = (p * G + lane_in_row) * 8;
+                if (c < d) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float dlt = v[p][k] - mean;
+                        sq += dlt * dlt;
+                    }
+                }
+            }
+        }
+        const float var = group_sum<G>(sq) * inv_d;
+        const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int p = 0; p < LN_MAX_PASS; ++p) {
+            if (p < npass) {
+                const int c = (p * G + lane_in_row) * 8;
+                if (c < d) {
+                    float g[8], b[8], o[8];
+                    Vec8<float>::load(gamma + c, g);
+                    Vec8<float>::load(beta + c, b);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = (v[p][k] - mean) * rstd * g[k] + b[k];
+                    Vec8<T>::store(out + row * d + c, o);
+                }
+            }
+        }
+        if (stats && lane_in_row == 0) {
+            stats[row * 2] = mean;
+            stats[row * 2 + 1] = rstd;
+        }
+    }
+}
+
+// backward: dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dout * gamma.
+// dgamma/dbeta: per-thread partials over the block's rows -> LDS -> one atomic per column per block.
+template <typename T, int G>
+__global__ void __launch_bounds__(256) add_ln_bwd_kernel(const T *__restrict__ dout, const T *__restrict__ z,
+                                                         const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                         T *__restrict__ dz, T *__restrict__ dy, float *__restrict__ dgamma,
+                                                         float *__restrict__ dbeta, int64_t rows, int d, float rate,
+                                                         uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [2][d]
+    const int lane_in_row = threadIdx.x & (G - 1);
+    const int rows_per_block = 256 / G;
+    const int npass = (d + G * 8 - 1) / (G * 8);
+    const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
+    const float inv_d = 1.0f / (float)d;
+    for (int i = threadIdx.x; i < 2 * d; i += 256) red[i] = 0.f;
+    __syncthreads();
+    float pg[LN_MAX_PASS][8], pb[LN_MAX_PASS][8];
+#pragma unroll
+    for (int p = 0; p < LN_MAX_PASS; ++p)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pg[p][k] = pb[p][k] = 0.f;
+
+    for (int64_t row = blockIdx.x * (int64_t)rows_per_block + threadIdx.x / G; row < rows;
+         row += (int64_t)gridDim.x * rows_per_block) {
+        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+        float gv[LN_MAX_PASS][8], xh[LN_MAX_PASS][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < LN_MAX_PASS; ++p) {
+            if (p < npass) {
+                const int c = (p * G + lane_in_row) * 8;
+                if (c < d) {
+                    float go[8], zz[8], gm[8];
+                    Vec8<T>::load(dout + row * d + c, go);
+                    Vec8<T>::load(z + row * d + c, zz);
+                    Vec8<float>::load(gamma + c, gm);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        xh[p][k] = (zz[k] - mean) * rstd;
+                        gv[p][k] = go[k] * gm[k];
+                        s1 += gv[p][k];
+                        s2 += gv[p][k] * xh[p][k];
+                        pg[p][k] += go[k] * xh[p][k];
+                        pb[p][k] += go[k];
+                    }
+                }
+            }
+        }
+        s1 = group_sum<G>(s1) * inv_d;
+        s2 = group_sum<G>(s2) * inv_d;
+#pragma unroll
+        for (int p = 0; p < LN_MAX_PASS; ++p) {
+            if (p < npass) {
+                const int c = (p * G + lane_in_row) * 8;
+                if (c < d) {
+                    float o[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = rstd * (gv[p][k] - s1 - xh[p][k] * s2);
+                    Vec8<T>::store(dz + row * d + c, o);
+                    if (rate > 0.f && dy) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            o[k] = b4c_keep_elem(seed, (uint64_t)(row * d + c + k), rate) ? o[k] * inv_keep : 0.f;
+                        Vec8<T>::store(dy + row * d + c, o);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < LN_MAX_PASS; ++p) {
+        if (p < npass) {
+            const int c = (p * G + lane_in_row) * 8;
+            if (c < d) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    atomicAdd(&red[c + k], pg[p][k]);
+                    atomicAdd(&red[d + c + k], pb[p][k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += 256) {
+        atomicAdd(dgamma + i, red[i]);
+        atomicAdd(dbeta + i, red[d + i]);
+    }
+}
+
+static int ln_group(int d) {
+    int g = 1;
+    while (g * 8 < d && g < 64) g <<= 1;
+    return g;
+}
+
+#define LN_DISPATCH_G(KERNEL, T, g, ...)                                         \
+    switch (g) {                                                                 \
+        case 1: KERNEL<T, 1> __VA_ARGS__; break;                                 \
+        case 2: KERNEL<T, 2> __VA_ARGS__; break;                                 \
+        case 4: KERNEL<T, 4> __VA_ARGS__; break;                                 \
+        case 8: KERNEL<T, 8> __VA_ARGS__; break;                                 \
+        case 16: KERNEL<T, 16> __VA_ARGS__; break;                               \
+        case 32: KERNEL<T, 32> __VA_ARGS__; break;                               \
+        default: KERNEL<T, 64> __VA_ARGS__; break;                               \
+    }
+
+extern "C" int b4c_add_dropout_layernorm_fwd(const void *x, const void *y, const float *gamma, const float *beta,
+                                             void *z, void *out, float *stats, int64_t rows, int d, float eps,
+                                             float dropout_rate, uint64_t seed, int dtype, void *stream) {
+    B4C_REQUIRE(x && y && gamma && beta && out && rows > 0, "add_ln_fwd: null pointer / empty");
+    B4C_REQUIRE(d > 0 && d % 8 == 0 && d <= 64 * 8 * LN_MAX_PASS, "add_ln_fwd: d=%d must be a multiple of 8, <= 1024", d);
+    B4C_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f, "add_ln_fwd: dropout_rate %f", dropout_rate);
+    const int g = ln_group(d);
+    const int grid = grid_for(rows * g, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32) {
+        LN_DISPATCH_G(add_ln_fwd_kernel, float, g, <<<grid, 256, 0, st>>>((const float *)x, (const float *)y, gamma, beta, (float *)z, (float *)out, stats, rows, d, eps, dropout_rate, seed))
+    } else if (dtype == B4C_BF16) {
+        LN_DISPATCH_G(add_ln_fwd_kernel, bf16_t, g, <<<grid, 256, 0, st>>>((const bf16_t *)x, (const bf16_t *)y, gamma, beta, (bf16_t *)z, (bf16_t *)out, stats, rows, d, eps, dropout_rate, seed))
+    } else
+        B4C_REQUIRE(false, "add_ln_fwd: dtype %d", dtype);
+    return b4c_check_launch("add_ln_fwd");
+}
+
+extern "C" int b4c_add_dropout_layernorm_bwd(const void *dout, const void *z, const float *stats, const float *gamma,
+                                             void *dz, void *dy, float *dgamma, float *dbeta, int64_t rows, int d,
+                                             float dropout_rate, uint64_t seed, int dtype, void *stream) {
+    B4C_REQUIRE(dout && z && stats && gamma && dz && dgamma && dbeta && rows > 0, "add_ln_bwd: null pointer / empty");
+    B4C_REQUIRE(d > 0 && d % 8 == 0 && d <= 64 * 8 * LN_MAX_PASS, "add_ln_bwd: d=%d must be a multiple of 8, <= 1024", d);
+    B4C_REQUIRE(dropout_rate == 0.f || dy, "add_ln_bwd: dy required when dropout_rate > 0");
+    const int g = ln_group(d);
+    int grid = grid_for(rows * g, 256);
+    if (grid > 1024) grid = 1024;  // fewer blocks -> fewer dgamma/dbeta atomics
+    const size_t shm = 2 * (size_t)d * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32) {
+        LN_DISPATCH_G(add_ln_bwd_kernel, float, g, <<<grid, 256, shm, st>>>((const float *)dout, (const float *)z, stats, gamma, (float *)dz, (float *)dy, dgamma, dbeta, rows, d, dropout_rate, seed))
+    } else if (dtype == B4C_BF16) {
+        LN_DISPATCH_G(add_ln_bwd_kernel, bf16_t, g, <<<grid, 256, shm, st>>>((const bf16_t *)dout, (const bf16_t *)z, stats, gamma, (bf16_t *)dz, (bf16_t *)dy, dgamma, dbeta, rows, d, dropout_rate, seed))
+    } else
+        B4C_REQUIRE(false, "add_ln_bwd: dtype %d", dtype);
+    return b4c_check_launch("add_ln_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// [MASK] positions: count per row (one wave per row), single-block scan, ordered write
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mask_count_kernel(const int64_t *__restrict__ ids, int B, int S, int64_t value,
+                                                         int32_t *__restrict__ counts) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B) return;
+    int c = 0;
+    for (int s = lane; s < S; s += 64) c += (ids[(int64_t)wave * S + s] == value);
+    c = (int)wave_sum((float)c);  // S < 2^24 so the float sum is exact
+    if (lane == 0) counts[wave] = c;
+}
+
+__global__ void __launch_bounds__(1024) mask_scan_kernel(const int32_t *__restrict__ counts, int B,
+                                                         int32_t *__restrict__ offsets, int32_t *__restrict__ maxcount) {
+    __shared__ int32_t part[1024];
+    __shared__ int32_t pmax[1024];
+    const int tid = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int lo = tid * per, hi = min(B, lo + per);
+    int32_t s = 0, m = 0;
+    for (int i = lo; i < hi; ++i) { s += counts[i]; m = max(m, counts[i]); }
+    part[tid] = s; pmax[tid] = m;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan / running max
+        int32_t v = tid >= o ? part[tid - o] : 0;
+        int32_t w = tid >= o ? pmax[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v; pmax[tid] = max(pmax[tid], w);
+        __syncthreads();
+    }
+    int32_t run = part[tid] - s;
+    for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
+    if (tid == 1023) { offsets[B] = part[1023]; if (maxcount) maxcount[0] = pmax[1023]; }
+}
+
+__global__ void __launch_bounds__(256) mask_write_kernel(const int64_t *__restrict__ ids, int B, int S, int64_t value,
+                                                         const int32_t *__restrict__ offsets, int32_t *__restrict__ flat_idx,
+                                                         int32_t cap) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B) return;
+    int32_t base = offsets[wave];
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool hit = s < S && ids[(int64_t)wave * S + s] == value;
+        const unsigned long long bal = __ballot(hit);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && base + before < cap) flat_idx[base + before] = wave * S + s;
+        base += __popcll(bal);
+    }
+}
+
+extern "C" int b4c_mask_positions(const int64_t *ids, int B, int S, int64_t value, int32_t *counts, int32_t *offsets,
+                                  int32_t *flat_idx, int32_t cap, int32_t *maxcount, void *stream) {
+    B4C_REQUIRE(ids && counts && offsets && flat_idx && B > 0 && S > 0 && cap >= 0, "mask_positions: bad argument");
+    B4C_REQUIRE((int64_t)B * S < (1ll << 31), "mask_positions: B*S must fit int32");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)ceil_div64((int64_t)B * 64, 256);
+    mask_count_kernel<<<grid, 256, 0, st>>>(ids, B, S, value, counts);
+    mask_scan_kernel<<<1, 1024, 0, st>>>(counts, B, offsets, maxcount);
+    mask_write_kernel<<<grid, 256, 0, st>>>(ids, B, S, value, offsets, flat_idx, cap);
+    return b4c_check_launch("mask_positions");
+}
+
+__global__ void __launch_bounds__(256) padded_index_kernel(const int32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
+                                                           const int32_t *__restrict__ flat_idx, int B, int M,
+                                                           int32_t *__restrict__ padded) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= (int64_t)B * M) return;
+    const int b = (int)(i / M), m = (int)(i % M);
+    padded[i] = m < counts[b] ? flat_idx[offsets[b] + m] : -1;
+}
+
+extern "C" int b4c_padded_index(const int32_t *counts, const int32_t *offsets, const int32_t *flat_idx, int B, int M,
+                                int32_t *padded_idx, void *stream) {
+    B4C_REQUIRE(counts && offsets && flat_idx && padded_idx && B > 0 && M > 0, "padded_index: bad argument");
+    padded_index_kernel<<<(int)ceil_div64((int64_t)B * M, 256), 256, 0, (hipStream_t)stream>>>(counts, offsets, flat_idx, B, M, padded_idx);
+    return b4c_check_launch("padded_index");
+}
+
+template <typename T, bool SCATTER>
+__global__ void __launch_bounds__(256) move_rows_kernel(const T *__restrict__ src, int ld_src, const int32_t *__restrict__ idx,
+                                                        T *__restrict__ dst, int ld_dst, int64_t n, int width) {
+    const int cpr = width >> 3;
+    const int64_t total = n * cpr;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr) << 3;
+        const int32_t j = idx[r];
+        float v[8];
+        if (SCATTER) {
+            if (j < 0) continue;
+            Vec8<T>::load(src + r * ld_src + c, v);
+            Vec8<T>::store(dst + (int64_t)j * ld_dst + c, v);
+        } else {
+            if (j >= 0) Vec8<T>::load(src + (int64_t)j * ld_src + c, v);
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = 0.f;
+            }
+            Vec8<T>::store(dst + r * ld_dst + c, v);
+        }
+    }
+}
+
+extern "C" int b4c_gather_rows(const void *in, int ld_in, const int32_t *idx, void *out, int ld_out, int64_t n_out,
+                               int width, int dtype, void *stream) {
+    B4C_REQUIRE(in && idx && out && n_out >= 0 && width > 0 && width % 8 == 0 && ld_in >= width && ld_out >= width &&
+                    ld_in % 8 == 0 && ld_out % 8 == 0, "gather_rows: bad shape");
+    if (n_out == 0) return B4C_OK;
+    const int grid = grid_for(n_out * (width / 8), 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32) move_rows_kernel<float, false><<<grid, 256, 0, st>>>((const float *)in, ld_in, idx, (float *)out, ld_out, n_out, width);
+    else if (dtype == B4C_BF16) move_rows_kernel<bf16_t, false><<<grid, 256, 0, st>>>((const bf16_t *)in, ld_in, idx, (bf16_t *)out, ld_out, n_out, width);
+    else B4C_REQUIRE(false, "gather_rows: dtype %d", dtype);
+    return b4c_check_launch("gather_rows");
+}
+
+extern "C" int b4c_scatter_rows(const void *src, int ld_src, const int32_t *idx, void *dst, int ld_dst, int64_t n_src,
+                                int64_t n_dst, int width, int dtype, void *stream) {
+    B4C_REQUIRE(src && idx && dst && n_src >= 0 && n_dst > 0 && width > 0 && width % 8 == 0 && ld_src >= width &&
+                    ld_dst >= width && ld_src % 8 == 0 && ld_dst % 8 == 0, "scatter_rows: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t esz = dtype == B4C_F32 ? 4 : 2;
+    B4C_REQUIRE(dtype == B4C_F32 || dtype == B4C_BF16, "scatter_rows: dtype %d", dtype);
+    if (hipMemsetAsync(dst, 0, (size_t)n_dst * ld_dst * esz, st) != hipSuccess) return b4c_check_launch("scatter_rows memset");
+    if (n_src == 0) return B4C_OK;
+    const int grid = grid_for(n_src * (width / 8), 256);
+    if (dtype == B4C_F32) move_rows_kernel<float, true><<<grid, 256, 0, st>>>((const float *)src, ld_src, idx, (float *)dst, ld_dst, n_src, width);
+    else move_rows_kernel<bf16_t, true><<<grid, 256, 0, st>>>((const bf16_t *)src, ld_src, idx, (bf16_t *)dst, ld_dst, n_src, width);
+    return b4c_check_launch("scatter_rows");
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: fp32 Keras kernel [K][N] -> T compute copy, optionally transposed (32x32 LDS tile)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) pack_weight_kernel(const float *__restrict__ src, int K, int N, T *__restrict__ dst,
+                                                          int ld_dst, int transpose) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    if (!transpose) {
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r, n = n0 + tx;
+            if (k < K && n < N) dst[(int64_t)k * ld_dst + n] = (T)src[(int64_t)k * N + n];
+        }
+        return;
+    }
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        tile[r][tx] = (k < K && n < N) ? src[(int64_t)k * N + n] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < K) dst[(int64_t)n * ld_dst + k] = (T)tile[tx][r];
+    }
+}
+
+extern "C" int b4c_pack_weight(const float *src, int K, int N, void *dst, int ld_dst, int transpose, int dtype,
+                               void *stream) {
+    B4C_REQUIRE(src && dst && K > 0 && N > 0, "pack_weight: bad argument");
+    B4C_REQUIRE(ld_dst >= (transpose ? K : N), "pack_weight: ld_dst %d too small", ld_dst);
+    dim3 grid((N + 31) / 32, (K + 31) / 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32) pack_weight_kernel<float><<<grid, 256, 0, st>>>(src, K, N, (float *)dst, ld_dst, transpose);
+    else if (dtype == B4C_BF16) pack_weight_kernel<bf16_t><<<grid, 256, 0, st>>>(src, K, N, (bf16_t *)dst, ld_dst, transpose);
+    else B4C_REQUIRE(false, "pack_weight: dtype %d", dtype);
+    return b4c_check_launch("pack_weight");
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam over a flat fp32 arena
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n, float lr_t, float b1, float b2,
+                                                   float eps, float gmul) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pp = reinterpret_cast<f32x4 *>(p)[i], gg = reinterpret_cast<const f32x4 *>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4 *>(m)[i], vv = reinterpret_cast<f32x4 *>(v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * gmul;
+            mm[k] = mm[k] * b1 + gk * (1.f - b1);
+            vv[k] = vv[k] * b2 + gk * gk * (1.f - b2);
+            pp[k] = pp[k] - lr_t * mm[k] / (sqrtf(vv[k]) + eps);
+        }
+        reinterpret_cast<f32x4 *>(p)[i] = pp;
+        reinterpret_cast<f32x4 *>(m)[i] = mm;
+        reinterpret_cast<f32x4 *>(v)[i] = vv;
+    }
+    // tail
+    for (int64_t i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gk = g[i] * gmul;
+        const float mk = m[i] * b1 + gk * (1.f - b1);
+        const float vk = v[i] * b2 + gk * gk * (1.f - b2);
+        m[i] = mk; v[i] = vk;
+        p[i] = p[i] - lr_t * mk / (sqrtf(vk) + eps);
+    }
+}
+
+extern "C" int b4c_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float beta1,
+                             float beta2, float eps, float grad_mul, void *stream) {
+    B4C_REQUIRE(p && g && m && v && n > 0, "adam_step: bad argument");
+    B4C_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: pointers must be 16-byte aligned");
+    adam_kernel<<<grid_for(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr_t, beta1, beta2, eps, grad_mul);
+    return b4c_check_launch("adam_step");
+}

@@ -1,0 +1,545 @@
+"""Host-side operators over libb4c_hip.so: raw launch wrappers plus the block-level
+``torch.autograd.Function``s the modules are made of.  PyTorch is used for device
+memory, streams and the autograd tape only -- every FLOP and byte below runs in the
+hand-written HIP kernels.  No CPU path exists: CPU tensors raise ``B4CError``."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from ._lib import B4CError
+
+LN_EPS = 1e-6
+
+_weights_epoch = 0      # bumped by optimizers that write parameters through raw pointers
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def rup8(n):
+    return (n + 7) // 8 * 8
+
+
+# ---- optional per-launch timers (bench.py: HIP events on the launch stream around ONE named
+# kernel, so its roofline fraction is measured live inside the timed region) ---------------------
+_timers = {}
+
+
+def enable_timer(name):
+    _timers[name] = []
+
+
+def timer_results_ms(name):
+    """Mean / count of the recorded launches (call after a device synchronize)."""
+    ev = _timers.get(name) or []
+    ms = [a.elapsed_time(b) for a, b in ev]
+    return (sum(ms) / len(ms) if ms else None), len(ms)
+
+
+def reset_timer(name):
+    if name in _timers:
+        _timers[name] = []
+
+
+class _timed:
+    def __init__(self, name):
+        self.rec = _timers.get(name)
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.rec.append((self.a, b))
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return L.F32
+    if dtype == torch.bfloat16:
+        return L.BF16
+    raise B4CError('unsupported compute dtype %s (float32 or bfloat16)' % dtype)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise B4CError('bert4clickpath_amd runs on the HIP device only; got a CPU tensor '
+                           '(there is no CPU fallback -- move inputs and the model to "cuda")')
+
+
+# --------------------------------------------------------------------------------------
+# raw launches
+# --------------------------------------------------------------------------------------
+def _feature_arrays(ids_list, tables):
+    n = len(ids_list)
+    ids_arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ids_list])
+    tab_arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tables])
+    dims = (ctypes.c_int * n)(*[int(t.shape[1]) for t in tables])
+    rows = (ctypes.c_int64 * n)(*[int(t.shape[0]) for t in tables])
+    return n, ids_arr, tab_arr, dims, rows
+
+
+def embed_concat_pe_fwd(ids_list, tables, pe, scale, rate, seed, dtype):
+    _cuda(pe, *ids_list, *tables)
+    B, S = ids_list[0].shape
+    d = sum(int(t.shape[1]) for t in tables)
+    for i in ids_list:
+        if i.dtype != torch.int64 or not i.is_contiguous() or tuple(i.shape) != (B, S):
+            raise B4CError('embedding ids must be contiguous int64 (B,S) tensors of one shape')
+    for t in tables:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise B4CError('embedding tables must be contiguous float32')
+    if pe.shape[0] < S or pe.shape[1] != d:
+        raise B4CError('positional table (%d,%d) too small for S=%d d=%d' % (pe.shape[0], pe.shape[1], S, d))
+    out = torch.empty(B, S, d, dtype=dtype, device=pe.device)
+    key_pad = torch.empty(B, S, dtype=torch.uint8, device=pe.device)
+    n, ids_arr, tab_arr, dims, rows = _feature_arrays(ids_list, tables)
+    L.check(L.lib().b4c_embed_concat_pe_fwd(n, ids_arr, tab_arr, dims, rows, _p(pe), scale, _p(out), d, _p(key_pad),
+                                            B, S, d, rate, seed, dt_code(dtype), _st()), 'embed_concat_pe_fwd')
+    return out, key_pad
+
+
+def embed_concat_pe_bwd(ids_list, tables, dout, scale, rate, seed):
+    B, S = ids_list[0].shape
+    d = dout.shape[-1]
+    dtabs = [torch.zeros_like(t) for t in tables]
+    n, ids_arr, tab_arr, dims, rows = _feature_arrays(ids_list, dtabs)
+    L.check(L.lib().b4c_embed_concat_pe_bwd(n, ids_arr, tab_arr, dims, rows, scale, _p(dout), d, B, S, d, rate, seed,
+                                            dt_code(dout.dtype), _st()), 'embed_concat_pe_bwd')
+    return dtabs
+
+
+def gemm_nt(a, bt, n, bias=None, act=L.ACT_NONE, gate=None, residual=None, out_dtype=None):
+    """a: [M, Kp], bt: [>=n, Kp] -> [M, n]"""
+    M, K = a.shape
+    out_dtype = out_dtype or a.dtype
+    out = torch.empty(M, n, dtype=out_dtype, device=a.device)
+    if M == 0:
+        return out
+    L.check(L.lib().b4c_gemm_nt(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), n, M, n, K, _p(bias), act,
+                                _p(gate), gate.stride(0) if gate is not None else 0,
+                                _p(residual), residual.stride(0) if residual is not None else 0,
+                                dt_code(a.dtype), dt_code(out_dtype), _st()), 'gemm_nt')
+    return out
+
+
+def gemm_tn(a, g, K, N, want_bias=True):
+    """dW[K,N] = a[:, :K]^T @ g[:, :N] (fp32), db[N] = colsum(g)"""
+    M = a.shape[0]
+    dW = torch.zeros(K, N, dtype=torch.float32, device=a.device)
+    db = torch.zeros(N, dtype=torch.float32, device=a.device) if want_bias else None
+    if M == 0:
+        return dW, db
+    L.check(L.lib().b4c_gemm_tn(_p(a), a.stride(0), _p(g), g.stride(0), _p(dW), N, _p(db), M, K, N,
+                                dt_code(a.dtype), _st()), 'gemm_tn')
+    return dW, db
+
+
+def attn_fwd(qkv, key_pad, B, S, H, dh):
+    d = H * dh
+    o = torch.empty(B * S, d, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
+    L.check(L.lib().b4c_attn_fwd(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), d, _p(lse), B, S, H, dh,
+                                 dt_code(qkv.dtype), _st()), 'attn_fwd')
+    return o, lse
+
+
+def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    L.check(L.lib().b4c_attn_bwd(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), o.stride(0), _p(d_o), d_o.stride(0),
+                                 _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, dt_code(qkv.dtype), _st()),
+            'attn_bwd')
+    return dqkv
+
+
+def add_dropout_layernorm_fwd(x, y, gamma, beta, rate, seed, save=True):
+    rows, d = x.shape
+    z = torch.empty_like(x) if save else None
+    out = torch.empty_like(x)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if save else None
+    L.check(L.lib().b4c_add_dropout_layernorm_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(z), _p(out), _p(stats), rows, d,
+                                                  LN_EPS, rate, seed, dt_code(x.dtype), _st()), 'add_dropout_layernorm_fwd')
+    return z, out, stats
+
+
+def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed):
+    rows, d = z.shape
+    dz = torch.empty_like(z)
+    dy = torch.empty_like(z) if rate > 0 else None
+    dgamma = torch.zeros(d, dtype=torch.float32, device=z.device)
+    dbeta = torch.zeros(d, dtype=torch.float32, device=z.device)
+    L.check(L.lib().b4c_add_dropout_layernorm_bwd(_p(dout), _p(z), _p(stats), _p(gamma), _p(dz), _p(dy), _p(dgamma),
+                                                  _p(dbeta), rows, d, rate, seed, dt_code(z.dtype), _st()),
+            'add_dropout_layernorm_bwd')
+    return dz, (dy if dy is not None else dz), dgamma, dbeta
+
+
+def mask_positions(ids, value, cap=None):
+    """-> counts[B], offsets[B+1], flat_idx[cap], maxcount[1] (all int32, device)."""
+    _cuda(ids)
+    B, S = ids.shape
+    cap = B * S if cap is None else cap
+    dev = ids.device
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    flat = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+    mx = torch.empty(1, dtype=torch.int32, device=dev)
+    L.check(L.lib().b4c_mask_positions(_p(ids), B, S, value, _p(counts), _p(offsets), _p(flat), cap, _p(mx), _st()),
+            'mask_positions')
+    return counts, offsets, flat, mx
+
+
+def padded_index(counts, offsets, flat, B, M):
+    out = torch.empty(B * M, dtype=torch.int32, device=counts.device)
+    L.check(L.lib().b4c_padded_index(_p(counts), _p(offsets), _p(flat), B, M, _p(out), _st()), 'padded_index')
+    return out
+
+
+def gather_rows(src, idx, n_out):
+    width = src.shape[1]
+    out = torch.empty(n_out, width, dtype=src.dtype, device=src.device)
+    if n_out == 0:
+        return out
+    L.check(L.lib().b4c_gather_rows(_p(src), src.stride(0), _p(idx), _p(out), width, n_out, width, dt_code(src.dtype),
+                                    _st()), 'gather_rows')
+    return out
+
+
+def scatter_rows(src, idx, n_dst):
+    n_src, width = src.shape
+    if n_src == 0:
+        return torch.zeros(n_dst, width, dtype=src.dtype, device=src.device)
+    out = torch.empty(n_dst, width, dtype=src.dtype, device=src.device)
+    L.check(L.lib().b4c_scatter_rows(_p(src), src.stride(0), _p(idx), _p(out), width, n_src, n_dst, width,
+                                     dt_code(src.dtype), _st()), 'scatter_rows')
+    return out
+
+
+def softmax_rows(logits, V):
+    R, ld = logits.shape[0], logits.stride(0)
+    probs = torch.empty(R, ld, dtype=logits.dtype, device=logits.device)
+    if R == 0:
+        return probs
+    L.check(L.lib().b4c_softmax_rows(_p(logits), ld, _p(probs), ld, R, V, dt_code(logits.dtype), _st()), 'softmax_rows')
+    return probs
+
+
+def sparse_ce_from_probs(probs, labels_f32, V, variant=L.CE_TF):
+    R, ld = probs.shape[0], probs.stride(0)
+    item = torch.empty(R, dtype=torch.float32, device=probs.device)
+    nval = torch.zeros(1, dtype=torch.float32, device=probs.device)
+    if R == 0:
+        return item, nval
+    L.check(L.lib().b4c_sparse_ce_from_probs(_p(probs), ld, _p(labels_f32), _p(item), _p(nval), R, V, variant,
+                                             dt_code(probs.dtype), _st()), 'sparse_ce_from_probs')
+    return item, nval
+
+
+def softmax_ce_fwd_bwd_(logits, labels_i32, grad_scale, V, variant=L.CE_TF):
+    """In place: logits -> grad_scale * dloss/dlogits.  Returns per-row loss."""
+    R, ld = logits.shape[0], logits.stride(0)
+    item = torch.empty(R, dtype=torch.float32, device=logits.device)
+    if R == 0:
+        return item
+    L.check(L.lib().b4c_softmax_ce_fwd_bwd(_p(logits), ld, _p(labels_i32), _p(item), _p(grad_scale), R, V, variant,
+                                           dt_code(logits.dtype), _st()), 'softmax_ce_fwd_bwd')
+    return item
+
+
+def topk_rows(scores, V, k, labels_i32=None):
+    _cuda(scores)
+    R, ld = scores.shape[0], scores.stride(0)
+    idx = torch.empty(R, k, dtype=torch.int32, device=scores.device)
+    hit = torch.empty(R, dtype=torch.float32, device=scores.device) if labels_i32 is not None else None
+    ndcg = torch.empty(R, dtype=torch.float32, device=scores.device) if labels_i32 is not None else None
+    if R == 0:
+        return idx, hit, ndcg
+    L.check(L.lib().b4c_topk_rows(_p(scores), ld, R, V, k, _p(idx), _p(labels_i32), _p(hit), _p(ndcg),
+                                  dt_code(scores.dtype), _st()), 'topk_rows')
+    return idx, hit, ndcg
+
+
+def adam_step_(p, g, m, v, lr_t, beta1, beta2, eps, grad_mul=1.0):
+    L.check(L.lib().b4c_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr_t, beta1, beta2, eps, grad_mul, _st()),
+            'adam_step')
+
+
+def keep_mask(seed, n, rate):
+    """Host regeneration of a dropout keep-mask (tests): element e kept iff b4c_keep(seed,e,rate)."""
+    import numpy as np
+    e = np.arange(n, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        z = np.uint64(seed) + ((e >> np.uint64(1)) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    bits = np.where((e & np.uint64(1)) == 1, z >> np.uint64(40), (z >> np.uint64(8)) & np.uint64(0xFFFFFF))
+    u = bits.astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return u >= np.float32(rate)
+
+
+# --------------------------------------------------------------------------------------
+# packed compute copies of (fused) dense layers
+# --------------------------------------------------------------------------------------
+class PackedLinear:
+    """Compute-dtype copies of one dense layer whose Keras kernels [K, N_i] are fused along N:
+    ``wt`` [Np][Kp] (forward operand, K-contiguous) and ``wc`` [Kp][Np] (backward-dX operand),
+    ``bias`` fp32 [Np].  Zero-padded to multiples of 8; refreshed when the masters change."""
+
+    def __init__(self, kernels, biases):
+        self.kernels, self.biases = list(kernels), list(biases)
+        self.K = int(self.kernels[0].shape[0])
+        self.Ns = [int(k.shape[1]) for k in self.kernels]
+        self.N = sum(self.Ns)
+        self.Np = rup8(self.N)
+        self._cache = {}
+
+    def _key(self):
+        return (_weights_epoch,) + tuple(t._version for t in self.kernels + self.biases) + \
+            tuple(t.data_ptr() for t in self.kernels + self.biases)
+
+    def get(self, dtype, Kp, need_wc):
+        dev = self.kernels[0].device
+        ent = self._cache.get((dtype, Kp, dev))
+        key = self._key()
+        if ent is None:
+            ent = {'key': None, 'wc_key': None,
+                   'wt': torch.zeros(self.Np, Kp, dtype=dtype, device=dev),
+                   'wc': None,
+                   'bias': torch.zeros(self.Np, dtype=torch.float32, device=dev)}
+            self._cache[(dtype, Kp, dev)] = ent
+        lib, st, code = L.lib(), _st(), dt_code(dtype)
+        if ent['key'] != key:
+            off = 0
+            with torch.no_grad():
+                for k, b, n in zip(self.kernels, self.biases, self.Ns):
+                    kk = k.detach()
+                    if kk.dtype != torch.float32 or not kk.is_contiguous():
+                        raise B4CError('dense kernels must be contiguous float32 [in, out]')
+                    L.check(lib.b4c_pack_weight(_p(kk), self.K, n, ent['wt'].data_ptr() + off * Kp * ent['wt'].element_size(),
+                                                Kp, 1, code, st), 'pack_weight')
+                    ent['bias'][off:off + n].copy_(b.detach())
+                    off += n
+            ent['key'] = key
+        if need_wc and ent['wc_key'] != key:
+            if ent['wc'] is None:
+                ent['wc'] = torch.zeros(Kp, self.Np, dtype=dtype, device=dev)
+            off = 0
+            for k, n in zip(self.kernels, self.Ns):
+                L.check(lib.b4c_pack_weight(_p(k.detach()), self.K, n, ent['wc'].data_ptr() + off * ent['wc'].element_size(),
+                                            self.Np, 0, code, st), 'pack_weight')
+                off += n
+            ent['wc_key'] = key
+        return ent['wt'], ent['wc'], ent['bias']
+
+    def split_grads(self, dW, db):
+        """dW [K, N] / db [N] of the fused layer -> per-kernel gradients."""
+        gk, gb, off = [], [], 0
+        for n in self.Ns:
+            gk.append(dW[:, off:off + n].contiguous() if len(self.Ns) > 1 else dW)
+            gb.append(db[off:off + n].contiguous() if len(self.Ns) > 1 else db)
+            off += n
+        return gk, gb
+
+
+def _as2d(x):
+    return x.reshape(-1, x.shape[-1])
+
+
+# --------------------------------------------------------------------------------------
+# autograd blocks
+# --------------------------------------------------------------------------------------
+class EmbedFn(torch.autograd.Function):
+    """R6: gather + concat + *sqrt(d) + PE (+ input dropout).  apply(pe, scale, rate, seed, dtype, n, *ids, *tables)"""
+
+    @staticmethod
+    def forward(ctx, pe, scale, rate, seed, dtype, n, *args):
+        ids, tables = list(args[:n]), list(args[n:])
+        out, key_pad = embed_concat_pe_fwd(ids, [t.detach() for t in tables], pe, scale, rate, seed, dtype)
+        ctx.save_for_backward(*ids, *tables)
+        ctx.n, ctx.scale, ctx.rate, ctx.seed = n, scale, rate, seed
+        ctx.mark_non_differentiable(key_pad)
+        return out, key_pad
+
+    @staticmethod
+    def backward(ctx, dout, _):
+        saved = ctx.saved_tensors
+        ids, tables = list(saved[:ctx.n]), list(saved[ctx.n:])
+        dtabs = embed_concat_pe_bwd(ids, tables, dout.contiguous(), ctx.scale, ctx.rate, ctx.seed)
+        return (None,) * 6 + (None,) * ctx.n + tuple(dtabs)
+
+
+class AttnBlockFn(torch.autograd.Function):
+    """R8 + first half of R10: LN1(x + drop(MHA(x))).  x: [T, d] in the compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, key_pad, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, pk_qkv, pk_o, B, S, H, rate, seed, training):
+        T_tok, d = x.shape
+        dh = d // H
+        wt_qkv, _, b_qkv = pk_qkv.get(x.dtype, d, training)
+        wt_o, _, b_o = pk_o.get(x.dtype, d, training)
+        with _timed('qkv_fwd'):
+            qkv = gemm_nt(x, wt_qkv, 3 * d, b_qkv)
+        with _timed('attn_fwd'):
+            o, lse = attn_fwd(qkv, key_pad, B, S, H, dh)
+        y = gemm_nt(o, wt_o, d, b_o)
+        z, out, stats = add_dropout_layernorm_fwd(x, y, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
+                                                  save=training)
+        if training:
+            ctx.save_for_backward(x, key_pad, qkv, o, lse, z, stats, gamma)
+            ctx.pk = (pk_qkv, pk_o)
+            ctx.dims = (B, S, H, dh, rate, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, key_pad, qkv, o, lse, z, stats, gamma = ctx.saved_tensors
+        pk_qkv, pk_o = ctx.pk
+        B, S, H, dh, rate, seed = ctx.dims
+        d = H * dh
+        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed)
+        _, wc_o, _ = pk_o.get(x.dtype, d, True)
+        _, wc_qkv, _ = pk_qkv.get(x.dtype, d, True)
+        dWo, dbo = gemm_tn(o, dy, d, d)
+        d_o = gemm_nt(dy, wc_o, d)
+        with _timed('attn_bwd'):
+            dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh)
+        with _timed('qkv_dw'):
+            dWqkv, dbqkv = gemm_tn(x, dqkv, d, 3 * d)
+        dx = gemm_nt(dqkv, wc_qkv, d, residual=dz)
+        (gq, gk, gv), (gbq, gbk, gbv) = pk_qkv.split_grads(dWqkv, dbqkv)
+        return (dx, None, gq, gbq, gk, gbk, gv, gbv, dWo, dbo, dgamma, dbeta) + (None,) * 8
+
+
+class FFNBlockFn(torch.autograd.Function):
+    """R9 + second half of R10: LN2(x + drop(relu(x W1 + b1) W2 + b2))."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, pk1, pk2, rate, seed, training):
+        T_tok, d = x.shape
+        wt1, _, bb1 = pk1.get(x.dtype, d, training)
+        Fp = pk1.Np
+        wt2, _, bb2 = pk2.get(x.dtype, Fp, training)
+        h = gemm_nt(x, wt1, Fp, bb1, act=L.ACT_RELU)
+        y = gemm_nt(h, wt2, d, bb2)
+        z, out, stats = add_dropout_layernorm_fwd(x, y, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
+                                                  save=training)
+        if training:
+            ctx.save_for_backward(x, h, z, stats, gamma)
+            ctx.pk = (pk1, pk2)
+            ctx.dims = (rate, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h, z, stats, gamma = ctx.saved_tensors
+        pk1, pk2 = ctx.pk
+        rate, seed = ctx.dims
+        d, Fp = x.shape[1], h.shape[1]
+        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed)
+        _, wc1, _ = pk1.get(x.dtype, d, True)
+        _, wc2, _ = pk2.get(x.dtype, Fp, True)
+        dW2, db2 = gemm_tn(h, dy, pk2.K, d)
+        dh = gemm_nt(dy, wc2, Fp, gate=h)
+        dW1, db1 = gemm_tn(x, dh, d, pk1.N)
+        dx = gemm_nt(dh, wc1, d, residual=dz)
+        return (dx, dW1, db1, dW2, db2, dgamma, dbeta) + (None,) * 5
+
+
+class MLPFn(torch.autograd.Function):
+    """Chain of dense layers (relu on all but the last): the SoftMaxHead's trunk + vocabulary
+    projection (R12, logits).  apply(x, packs, training, out_fp32, *[k0, b0, k1, b1, ...])"""
+
+    @staticmethod
+    def forward(ctx, x, packs, training, out_fp32, *params):
+        acts = [x]
+        n = len(packs)
+        for i, pk in enumerate(packs):
+            a = acts[-1]
+            wt, _, bias = pk.get(x.dtype, a.shape[1], training)
+            last = i == n - 1
+            with _timed('vocab_proj_fwd' if last else 'head_mlp_fwd'):
+                acts.append(gemm_nt(a, wt, pk.Np, bias, act=L.ACT_NONE if last else L.ACT_RELU,
+                                    out_dtype=torch.float32 if (last and out_fp32) else None))
+        if training:
+            ctx.save_for_backward(*acts[:-1])
+            ctx.packs = packs
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        acts = ctx.saved_tensors
+        packs = ctx.packs
+        g = dlogits
+        if g.dtype != acts[0].dtype:
+            g = g.to(acts[0].dtype)
+        g = g.contiguous()
+        grads = [None] * (2 * len(packs))
+        dx = None
+        for i in range(len(packs) - 1, -1, -1):
+            a = acts[i]
+            pk = packs[i]
+            _, wc, _ = pk.get(a.dtype, a.shape[1], True)
+            last = i == len(packs) - 1
+            with _timed('vocab_proj_dw' if last else 'head_mlp_dw'):
+                dW, db = gemm_tn(a, g, pk.K, pk.N)
+            grads[2 * i], grads[2 * i + 1] = dW, db
+            with _timed('vocab_proj_dx' if last else 'head_mlp_dx'):
+                g = gemm_nt(g, wc, a.shape[1], gate=a if i > 0 else None)
+            dx = g
+        return (dx, None, None, None) + tuple(grads)
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """R11: rows of the encoder output at the given flat indices (idx < 0 -> zero row)."""
+
+    @staticmethod
+    def forward(ctx, src2d, idx, n_out):
+        ctx.save_for_backward(idx)
+        ctx.n_src = src2d.shape[0]
+        return gather_rows(src2d, idx, n_out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        return scatter_rows(dout.contiguous(), idx, ctx.n_src), None, None
+
+
+class FusedSoftmaxCEFn(torch.autograd.Function):
+    """R12 tail + R13 + R14 fused for training: softmax over V, masked sparse CE (mean over valid
+    rows), and d loss / d logits written in place of the logits (which are consumed)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels_i32, V, variant, unit_grad):
+        valid = ((labels_i32 >= 0) & (labels_i32 < V)).sum().to(torch.float32)
+        scale = torch.where(valid > 0, 1.0 / valid.clamp(min=1.0), torch.zeros_like(valid)).reshape(1)
+        with _timed('softmax_ce'):
+            item = softmax_ce_fwd_bwd_(logits, labels_i32, scale, V, variant)
+        ctx.save_for_backward(logits)
+        ctx.unit_grad = unit_grad
+        loss = (item.sum() * scale[0])
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        if not ctx.unit_grad:
+            dlogits = dlogits * g.to(dlogits.dtype)
+        return dlogits, None, None, None, None

@@ -1,0 +1,177 @@
+/*
+ * b4c.h -- C ABI of libb4c_hip.so: the MI355X (gfx950) hot path of BERT4ClickPath's
+ * BERT4Rec forward / Cloze-training step.
+ *
+ * The reference (MiladShahidi/BERT4ClickPath, pure Python on TensorFlow 2.3.1) has no
+ * native layer; its hot path bottoms out in TF ops.  Each entry point below replaces the
+ * TF call sites cited next to it (paths relative to the reference root).  A binding for
+ * the reference's own Python is shown in INTEGRATION.md (ctypes).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory unless named h_*;
+ *  - no allocation, no global state, no synchronisation inside: the caller owns every
+ *    buffer and passes the hipStream_t (as void*); calls are thread-safe per stream;
+ *  - return 0 on success, a negative B4C_E* code otherwise (b4c_last_error() gives text);
+ *  - dtype: B4C_F32 = exact fp32 path (parity), B4C_BF16 = bf16 storage / fp32 accumulate
+ *    (throughput).  "T" below means that element type.  Weights master copies, biases,
+ *    LayerNorm params, statistics, losses and gradients of weights are always fp32;
+ *  - ld* are row pitches in ELEMENTS.  Vector paths need pitches and inner sizes that are
+ *    multiples of 8 elements; the host pads (zeros) where the model's sizes are not.
+ */
+#ifndef B4C_H
+#define B4C_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B4C_F32 0
+#define B4C_BF16 1
+
+#define B4C_OK 0
+#define B4C_EINVAL (-1)   /* bad argument (shape / alignment / dtype)              */
+#define B4C_ELAUNCH (-2)  /* the HIP runtime refused the launch (see last_error)    */
+#define B4C_EUNSUPPORTED (-3)
+
+#define B4C_MAX_FEATURES 4
+#define B4C_MAX_TOPK 16
+
+#define B4C_ACT_NONE 0
+#define B4C_ACT_RELU 1
+
+#define B4C_CE_TF 0    /* clip[1e-7,1-1e-7] -> log -> log-softmax (tf.keras.backend, TF 2.3.1) */
+#define B4C_CE_PLAIN 1 /* -log p_y                                                            */
+
+int b4c_abi_version(void);
+const char *b4c_last_error(void);
+
+/* ---- R6 + R4: embedding stage ------------------------------------------------------
+ * replaces transformer.py:376-398 (Embedding per feature -> concat -> * sqrt(d) -> + PE)
+ * and create_padding_mask :38-41, plus Encoder.call's input dropout :263.
+ *   out[t, off_f + j] = drop( table_f[ids_f[t], j] * scale + pe[s, off_f + j] )
+ *   key_pad[t] = (ids_0[t] == 0)
+ * h_ids / h_tables / h_dims / h_rows: HOST arrays of n_feat entries (device pointers inside).
+ * ids are int64 (B*S); ids outside [0, rows) are clamped.  pe: fp32 [>=S][d_model].
+ * dropout: keep(e) from the counter hash b4c_keep(seed, e), e = t*d_model + col; rate 0 = off. */
+int b4c_embed_concat_pe_fwd(int n_feat, const int64_t *const *h_ids, const float *const *h_tables,
+                            const int *h_dims, const int64_t *h_rows, const float *pe, float scale,
+                            void *out, int ld_out, uint8_t *key_pad, int B, int S, int d_model,
+                            float dropout_rate, uint64_t seed, int dtype, void *stream);
+
+/* gradient of the above w.r.t. the tables (fp32, accumulated with float atomics into
+ * h_dtables[f], which the caller zeroes): dtable_f[id, j] += scale * dropmask * dout[t, off_f+j] */
+int b4c_embed_concat_pe_bwd(int n_feat, const int64_t *const *h_ids, float *const *h_dtables,
+                            const int *h_dims, const int64_t *h_rows, float scale, const void *dout,
+                            int ld_dout, int B, int S, int d_model, float dropout_rate, uint64_t seed,
+                            int dtype, void *stream);
+
+/* ---- dense layers (R8 projections, R9 FFN, R12 head) --------------------------------
+ * replaces tf.keras.layers.Dense call sites transformer.py:112-116,165-166; head.py:35-36.
+ * pack: fp32 Keras kernel [K][N] -> compute copy in T.
+ *   transpose=1: dst[n][k] = src[k][n]  (dst is [N][ld_dst], forward operand)
+ *   transpose=0: dst[k][n] = src[k][n]  (dst is [K][ld_dst], backward-dX operand)
+ * Only the K x N valid elements are written: the caller zero-initialises padded buffers once
+ * (pad rows / columns never change afterwards). */
+int b4c_pack_weight(const float *src, int K, int N, void *dst, int ld_dst, int transpose, int dtype,
+                    void *stream);
+
+/* C[M][N] = epilogue( A[M][K] . Bt[N][K]^T )     (both operands K-contiguous)
+ *   v = acc + bias[n]            (bias fp32 or NULL)
+ *   v = relu(v)                  if act == B4C_ACT_RELU
+ *   v = v * (gate[m][n] > 0)     if gate != NULL   (ReLU backward: gate = saved activation, pitch ldg)
+ *   v = v + residual[m][n]       if residual != NULL (T, pitch ldr)
+ * out_dtype chooses C's element type (T of `dtype`, or B4C_F32 for fp32 logits from bf16 inputs).
+ * K % 8 == 0, lda/ldb % 8 == 0 (bf16) or % 4 (fp32). */
+int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void *C, int ldc, int M, int N, int K,
+                const float *bias, int act, const void *gate, int ldg, const void *residual, int ldr,
+                int dtype, int out_dtype, void *stream);
+
+/* dW[K][N] (+)= A[M][K]^T . G[M][N]   and  db[N] (+)= colsum(G)   (fp32 outputs, float atomics:
+ * the caller zeroes dW / db; db may be NULL).  Reduction runs over the M (token) axis. */
+int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float *dW, int ldw, float *db, int M, int K,
+                int N, int dtype, void *stream);
+
+/* ---- R8: attention -------------------------------------------------------------------
+ * replaces MultiHeadAttention.split_heads + scaled_dot_product_attention + merge
+ * (transformer.py:64-97, 130-156).  qkv: [B*S][ld_qkv] with q | k | v column blocks of d_model
+ * each (head h = columns h*dh..), key_pad [B*S] from the embedding stage (key-side mask, -1e9).
+ *   o[B*S][ld_o] = softmax(q k^T / sqrt(dh) + pad * -1e9) v   (heads merged)
+ *   lse[B][H][S] = log-sum-exp of the masked, scaled logits (saved for backward) */
+int b4c_attn_fwd(const void *qkv, int ld_qkv, const uint8_t *key_pad, void *o, int ld_o, float *lse, int B,
+                 int S, int H, int dh, int dtype, void *stream);
+/* dqkv [B*S][ld_dqkv] from do; delta[B][H][S] is scratch (fp32). */
+int b4c_attn_bwd(const void *qkv, int ld_qkv, const uint8_t *key_pad, const void *o, int ld_o,
+                 const void *d_o, int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B,
+                 int S, int H, int dh, int dtype, void *stream);
+
+/* ---- R10: residual + dropout + LayerNorm ---------------------------------------------
+ * replaces EncoderLayer.call's  LN(x + dropout(y))  (transformer.py:204-206, 209-211),
+ * LayerNormalization(epsilon) :183-184 (biased variance, eps inside rsqrt).
+ *   z = x + drop(y);  out = (z - mean) * rstd * gamma + beta;  stats[row] = {mean, rstd}
+ * z (T, pitch d) is saved for backward; d % 8 == 0. */
+int b4c_add_dropout_layernorm_fwd(const void *x, const void *y, const float *gamma, const float *beta,
+                                  void *z, void *out, float *stats, int64_t rows, int d, float eps,
+                                  float dropout_rate, uint64_t seed, int dtype, void *stream);
+/* dz -> residual branch; dy = dropmask * dz (written only if dropout_rate > 0, else may be NULL);
+ * dgamma/dbeta fp32 [d], accumulated with atomics (caller zeroes). */
+int b4c_add_dropout_layernorm_bwd(const void *dout, const void *z, const float *stats, const float *gamma,
+                                  void *dz, void *dy, float *dgamma, float *dbeta, int64_t rows, int d,
+                                  float dropout_rate, uint64_t seed, int dtype, void *stream);
+
+/* ---- R11: [MASK]-position index generation and row gather -----------------------------
+ * replaces _gather_output_by_raw_value (clickstream_transformer.py:260-297):
+ * tf.where(raw == value) row-major, ragged per batch row, gather_nd, to_tensor(0).
+ * counts[B], offsets[B+1] (exclusive scan; offsets[B] = R), flat_idx[cap] = b*S+s in row-major
+ * order (entries >= R untouched), maxcount[1].  All int32 except ids (int64). */
+int b4c_mask_positions(const int64_t *ids, int B, int S, int64_t value, int32_t *counts, int32_t *offsets,
+                       int32_t *flat_idx, int32_t cap, int32_t *maxcount, void *stream);
+/* padded_idx[B*M] = flat index of the m-th match of row b, or -1 (pad slot). */
+int b4c_padded_index(const int32_t *counts, const int32_t *offsets, const int32_t *flat_idx, int B, int M,
+                     int32_t *padded_idx, void *stream);
+/* out[r][:] = idx[r] >= 0 ? in[idx[r]][:] : 0      (width % 8 == 0) */
+int b4c_gather_rows(const void *in, int ld_in, const int32_t *idx, void *out, int ld_out, int64_t n_out,
+                    int width, int dtype, void *stream);
+/* dst (n_dst rows) = 0, then dst[idx[r]][:] = src[r][:] for idx[r] >= 0 (indices unique). */
+int b4c_scatter_rows(const void *src, int ld_src, const int32_t *idx, void *dst, int ld_dst, int64_t n_src,
+                     int64_t n_dst, int width, int dtype, void *stream);
+
+/* ---- R12 tail, R13, R14: softmax, masked sparse cross-entropy --------------------------
+ * replaces Dense(V, softmax)'s activation (head.py:36), cloze_output_adaptor + MaskedLoss with
+ * tf.keras.backend.sparse_categorical_crossentropy (utils.py:56-134, losses.py:31-98, main.py:89).
+ * probs[r][0..V) = softmax(logits[r][0..V)); pad columns V..ld are written 0. */
+int b4c_softmax_rows(const void *logits, int ld_in, void *probs, int ld_out, int64_t R, int V, int dtype,
+                     void *stream);
+/* per-row loss on PROBABILITIES (the reference's dataflow): labels fp32 as the reference keeps
+ * them (-1 = pad -> loss 0, not counted).  item_loss[R], n_valid[1] (+= count). */
+int b4c_sparse_ce_from_probs(const void *probs, int ld, const float *labels, float *item_loss,
+                             float *n_valid, int64_t R, int V, int variant, int dtype, void *stream);
+/* fused training form: logits -> per-row loss and, IN PLACE, dlogits = grad_scale[0] * d loss/d logits
+ * (grad_scale is a device scalar, e.g. 1/R_valid).  labels int32 label-space ids; label < 0 or >= V
+ * -> row ignored (zero gradient).  pad columns get 0. */
+int b4c_softmax_ce_fwd_bwd(void *logits, int ld, const int32_t *labels, float *item_loss,
+                           const float *grad_scale, int64_t R, int V, int variant, int dtype, void *stream);
+
+/* ---- R15: top-k ids, HitRate@k / NDCG@k -------------------------------------------------
+ * replaces tf.math.top_k + the Recall / NDCG update_state arithmetic (utils.py:161-190, 225-255).
+ * topk_idx[R][k] int32, largest first, ties -> lower index.  labels (int32, may be NULL):
+ * hit[r] = any(topk == label), ndcg[r] = sum_k (topk[k]==label) / log2(k+2). */
+int b4c_topk_rows(const void *scores, int ld, int64_t R, int V, int k, int32_t *topk_idx,
+                  const int32_t *labels, float *hit, float *ndcg, int dtype, void *stream);
+
+/* ---- R16: Adam (Keras semantics, eps outside the sqrt) ------------------------------------
+ * replaces tf.keras.optimizers.Adam(1e-3, .9, .999, 1e-9) (main.py:87), dense update over a flat
+ * fp32 arena: m,v EMA; p -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (host).
+ * grad_mul scales g first (1/world_size for mean reduction; 1 for the reference's sum). */
+int b4c_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float beta1,
+                  float beta2, float eps, float grad_mul, void *stream);
+
+/* keep-mask hash used by every dropout site (exposed so hosts/tests can regenerate masks):
+ * returns 1 if element e is kept under (seed, rate). */
+int b4c_keep(uint64_t seed, uint64_t e, float rate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* B4C_H */
