@@ -99,7 +99,8 @@ def cpu_baseline(a):
     from bert4clickpath_amd import input_pipeline
     from oracle import numpy_ref as nr
     from oracle import torch_ref as tr
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-core share of the host (more threads only oversubscribe it)
+    threads = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
     rng = np.random.default_rng(1234)
     P = nr.init_params(rng, {'items': a.vocab + 11}, {'items': a.d_model}, a.layers, 100, [1024, 512, 256, 128], a.vocab)
@@ -227,7 +228,7 @@ def main():
                        'global_batch': a.batch * world, 'seq_len': a.seq, 'parallelism': 'dp%d' % world,
                        'grad_reduce': 'sum (reference semantics)'},
             'tokens_per_s': a.batch * world * a.seq * a.steps / dt,
-            'final_loss': float(loss),
+            'final_loss': float(loss.detach()),
             'roofline': roof,
         }
         if world == 1 and not a.no_cpu_baseline:

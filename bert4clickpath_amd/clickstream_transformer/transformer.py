@@ -234,6 +234,22 @@ class _Embedding(nn.Module):
         self.weight = nn.Parameter(torch.empty(rows, dim).uniform_(-0.05, 0.05))
 
 
+class _FeatureModules(nn.Module):
+    """name -> module container whose keys may be ANY feature name ('items', 'keys', ...), which
+    nn.ModuleDict refuses; state-dict keys stay ``embedding_layers.<feature>.weight``."""
+
+    def __init__(self, modules):
+        super().__init__()
+        for k, m in modules.items():
+            self._modules[str(k)] = m
+
+    def __getitem__(self, k):
+        return self._modules[k]
+
+    def keys(self):
+        return self._modules.keys()
+
+
 class Transformer(nn.Module):
     """Encoder-only Transformer over one or more categorical sequence features (reference :271-402):
     per-feature embedding -> concat on the last axis -> * sqrt(d_model) -> + sinusoidal PE -> Encoder."""
@@ -254,8 +270,8 @@ class Transformer(nn.Module):
                 raise B4CError('MI355X build: embedding dim of feature %r is %d; must be a multiple of 8' % (f, dim))
         self.compute_dtype = compute_dtype
         self.encoder = Encoder(num_layers, self.d_model, num_attention_heads, encoder_ff_dim, dropout_rate)
-        self.embedding_layers = nn.ModuleDict({f: _Embedding(int(embedding_sizes[f]), int(embedding_dims[f]))
-                                               for f in embedding_dims.keys()})
+        self.embedding_layers = _FeatureModules({f: _Embedding(int(embedding_sizes[f]), int(embedding_dims[f]))
+                                                 for f in embedding_dims.keys()})
         self.register_buffer('pos_encoding', positional_encoding(self.maximum_position_encoding, self.d_model)[0].clone(),
                              persistent=False)
         self.scale = float(np.sqrt(np.float32(self.d_model)))   # sqrt taken in float32 (reference :390)
