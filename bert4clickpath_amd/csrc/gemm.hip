@@ -98,11 +98,43 @@ __device__ __forceinline__ void nt_store(char *s, int tid, const u32x4 (&reg)[4]
     }
 }
 
+// Epilogue on 8 consecutive columns of one row (16-B accesses for bias / gate / residual / C).
+template <typename T, typename OutT>
+__device__ __forceinline__ void epilogue8(float (&v)[8], int64_t row, int col, OutT *__restrict__ C, int ldc,
+                                          const float *__restrict__ bias, int act, const T *__restrict__ gate, int ldg,
+                                          const T *__restrict__ residual, int ldr) {
+    if (bias) {
+        float bv[8];
+        Vec8<float>::load(bias + col, bv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += bv[k];
+    }
+    if (act == B4C_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    if (gate) {
+        float g[8];
+        Vec8<T>::load(gate + row * ldg + col, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
+    }
+    if (residual) {
+        float rr[8];
+        Vec8<T>::load(residual + row * ldr + col, rr);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += rr[k];
+    }
+    Vec8<OutT>::store(C + row * ldc + col, v);
+}
+
+// One LDS stage (36.9 KB -> 4 workgroups per CU) with register prefetch of the next K tile; 2-byte outputs
+// leave through an LDS transpose so that every global store / gate / residual access is a 16-B row chunk.
 template <typename T, typename OutT>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, int lda, const T *__restrict__ Bt, int ldb,
                                                       OutT *__restrict__ C, int ldc, int M, int N, int K,
                                                       const float *__restrict__ bias, int act, const T *__restrict__ gate,
-                                                      int ldg, const T *__restrict__ residual, int ldr) {
+                                                      int ldg, const T *__restrict__ residual, int ldr, int vec_ok) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
@@ -123,21 +155,47 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, i
     nt_store(smem + TILE_BYTES, tid, rb);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        char *cur = smem + (kt & 1) * STAGE_BYTES;
-        char *nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
         const bool more = kt + 1 < nk;
         if (more) {
             nt_load<T>(A, lda, m0, M, (kt + 1) * MM<T>::BKE, K, tid, ra);
             nt_load<T>(Bt, ldb, n0, N, (kt + 1) * MM<T>::BKE, K, tid, rb);
         }
-        mma_stage<T>(cur, cur + TILE_BYTES, wm, wn, r, h, acc);
-        if (more) {
-            nt_store(nxt, tid, ra);
-            nt_store(nxt + TILE_BYTES, tid, rb);
-        }
+        mma_stage<T>(smem, smem + TILE_BYTES, wm, wn, r, h, acc);
         __syncthreads();
+        if (more) {
+            nt_store(smem, tid, ra);
+            nt_store(smem + TILE_BYTES, tid, rb);
+            __syncthreads();
+        }
     }
-    // epilogue.  acc register t of tile (i,j): row = (t&3) + 8*(t>>2) + 4*h, col = lane&31.
+    // acc register t of tile (i,j): row = (t&3) + 8*(t>>2) + 4*h, col = lane&31.
+    if (sizeof(OutT) == 2 && vec_ok) {
+        // wave-private 64 x 64 tile -> LDS [64][144 B] -> 16-B row chunks
+        char *ws = smem + wave * (64 * LDS_STRIDE);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int row = i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+                    *reinterpret_cast<OutT *>(ws + row * LDS_STRIDE + (j * 32 + r) * 2) = (OutT)acc[i][j][t];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = lane + q * 64;
+            const int row = c >> 3, part = c & 7;
+            const int64_t grow = m0 + wm * 64 + row;
+            const int gcol = n0 + wn * 64 + part * 8;
+            if (grow < M && gcol < N) {
+                float v[8];
+                Vec8<OutT>::load(reinterpret_cast<const OutT *>(ws + row * LDS_STRIDE + part * 16), v);
+                epilogue8<T, OutT>(v, grow, gcol, C, ldc, bias, act, gate, ldg, residual, ldr);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -174,16 +232,18 @@ extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void
     dim3 grid((M + TILE - 1) / TILE, (N + TILE - 1) / TILE);
     B4C_REQUIRE(grid.y <= 65535, "gemm_nt: N too large");
     hipStream_t st = (hipStream_t)stream;
-    const size_t shm = 2 * STAGE_BYTES;
-    allow_lds(gemm_nt_kernel<float, float>, shm);
-    allow_lds(gemm_nt_kernel<bf16_t, float>, shm);
-    allow_lds(gemm_nt_kernel<bf16_t, bf16_t>, shm);
+    const size_t shm = STAGE_BYTES;
+    // the 16-byte epilogue needs whole, aligned 8-column chunks in C / gate / residual / bias
+    const int vec_ok = (N % 8 == 0) && (ldc % 8 == 0) && (((uintptr_t)C & 15) == 0) &&
+                       (!gate || (ldg % 8 == 0 && ((uintptr_t)gate & 15) == 0)) &&
+                       (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0)) &&
+                       (!bias || ((uintptr_t)bias & 15) == 0);
     if (dtype == B4C_F32)
-        gemm_nt_kernel<float, float><<<grid, 256, shm, st>>>((const float *)A, lda, (const float *)Bt, ldb, (float *)C, ldc, M, N, K, bias, act, (const float *)gate, ldg, (const float *)residual, ldr);
+        gemm_nt_kernel<float, float><<<grid, 256, shm, st>>>((const float *)A, lda, (const float *)Bt, ldb, (float *)C, ldc, M, N, K, bias, act, (const float *)gate, ldg, (const float *)residual, ldr, vec_ok);
     else if (out_dtype == B4C_F32)
-        gemm_nt_kernel<bf16_t, float><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (float *)C, ldc, M, N, K, bias, act, (const bf16_t *)gate, ldg, (const bf16_t *)residual, ldr);
+        gemm_nt_kernel<bf16_t, float><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (float *)C, ldc, M, N, K, bias, act, (const bf16_t *)gate, ldg, (const bf16_t *)residual, ldr, vec_ok);
     else
-        gemm_nt_kernel<bf16_t, bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, act, (const bf16_t *)gate, ldg, (const bf16_t *)residual, ldr);
+        gemm_nt_kernel<bf16_t, bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, act, (const bf16_t *)gate, ldg, (const bf16_t *)residual, ldr, vec_ok);
     return b4c_check_launch("gemm_nt");
 }
 
@@ -304,20 +364,19 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T *__restrict__ A, i
     }
     __syncthreads();
     for (int st = 0; st < nsteps; ++st) {
-        char *cur = smem + (st & 1) * STAGE_BYTES;
-        char *nxt = smem + ((st + 1) & 1) * STAGE_BYTES;
         const bool more = st + 1 < nsteps;
         if (more) {
             sa.load(A, lda, k0, m_begin + (int64_t)(st + 1) * TOK, m_end, lane, wave);
             sg.load(G, ldg, n0, m_begin + (int64_t)(st + 1) * TOK, m_end, lane, wave);
         }
-        mma_stage<T>(cur, cur + TILE_BYTES, wm, wn, r, h, acc);
-        if (more) {
-            sa.store(nxt, lane, wave);
-            sg.store(nxt + TILE_BYTES, lane, wave);
-            if (want_db) sg.colsum(bs0, bs1);
-        }
+        mma_stage<T>(smem, smem + TILE_BYTES, wm, wn, r, h, acc);
         __syncthreads();
+        if (more) {
+            sa.store(smem, lane, wave);
+            sg.store(smem + TILE_BYTES, lane, wave);
+            if (want_db) sg.colsum(bs0, bs1);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -360,9 +419,7 @@ extern "C" int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float
     dim3 grid(tk, tn, (unsigned)nsplit);
     B4C_REQUIRE(tn <= 65535, "gemm_tn: N too large");
     hipStream_t st = (hipStream_t)stream;
-    const size_t shm = 2 * STAGE_BYTES;
-    allow_lds(gemm_tn_kernel<float>, shm);
-    allow_lds(gemm_tn_kernel<bf16_t>, shm);
+    const size_t shm = STAGE_BYTES;
     if (dtype == B4C_F32)
         gemm_tn_kernel<float><<<grid, 256, shm, st>>>((const float *)A, lda, (const float *)G, ldg, dW, ldw, db, M, K, N, chunk);
     else

@@ -176,7 +176,8 @@ def _attn_ref(qkv, pad, B, S, H, dh):
 
 
 @pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('B,S,H,dh', [(3, 13, 2, 32), (2, 200, 2, 64), (2, 70, 1, 16), (1, 300, 2, 128)])
+@pytest.mark.parametrize('B,S,H,dh', [(3, 13, 2, 32), (2, 200, 2, 64), (2, 70, 1, 16), (1, 300, 2, 128), (2, 256, 2, 64),
+                                      (3, 32, 1, 64), (2, 33, 4, 32), (5, 53, 2, 32), (2, 129, 3, 64)])
 def test_attention_fwd_bwd(ops, dtype, B, S, H, dh):
     g = torch.Generator().manual_seed(S + dh)
     d = H * dh
