@@ -1,9 +1,10 @@
-// bf16 MFMA attention for gfx950 (throughput path).  One 256-thread workgroup per (sequence, head);
+// bf16 MFMA attention for gfx950 (throughput path).  One 512-thread workgroup per (sequence, head);
 // the whole K / V of that head lives in LDS (S <= 256), scores stay in MFMA accumulators.
 //
 // forward : S^T = K Q^T with the KEY on the accumulator rows and the QUERY on the lane, so the softmax
 //           row statistics are lane-local (one xor-32 exchange), and P^T feeds O^T = V^T P^T straight
-//           from the accumulator registers (no LDS round trip).  V is staged transposed.
+//           from the accumulator registers (no LDS round trip).  V^T fragments come from the row-major V image
+//           through ds_read_b64_tr_b16 (no transposed staging).
 // backward: S = Q K^T and dP = dO V^T with the KEY on the lane; P and dS feed dV^T = dO^T P and
 //           dK^T = Q^T dS from registers; only dS crosses LDS once, for dQ = dS K.
 //           Waves own key tiles (dK^T / dV^T never leave registers), queries stream in 32-row tiles.
@@ -68,186 +69,56 @@ __device__ __forceinline__ void stage_transposed8(const bf16_t *__restrict__ src
     *reinterpret_cast<u32x2 *>(b + str + 8) = hi1;
 }
 
+// 4 rows x 16 columns of bf16 read transposed (ds_read_b64_tr_b16): lane i of each 16-lane group gets
+// column (col0 + i) of rows row0..row0+3; the lane supplies the address of row (i>>2), columns 4(i&3)...
+// Checked on MI355X with integer data (scratch/trtest.hip).  EXEC must be full.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ s16x4 tr_read(const char *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(p));
+}
+__device__ __forceinline__ bf16x8 frag_tr(const char *p, int second_off) {
+    const s16x4 a = tr_read(p), b = tr_read(p + second_off);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 w = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, w);
+}
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
 // ------------------------------------------------------------------------------------------
-// forward
+// forward: 512 threads, wave w owns query tile w (S <= 256 -> at most 8 tiles)
 // ------------------------------------------------------------------------------------------
 template <int DH>
-__global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
+__global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
                                                             bf16_t *__restrict__ o, int ld_o, float *__restrict__ lse, int S, int H,
                                                             float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSTR = DH * 2 + 16;
-    constexpr int NKS = DH / 16, NDT = DH / 32, DWR = DH / 2;
+    constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8;
     const int nkt = (S + 31) >> 5, S_pad = nkt * 32;
-    const int VSTR = S_pad * 2 + 8;
     char *sK = smem;
-    char *sVt = sK + S_pad * KSTR;
-    float *sMask = reinterpret_cast<float *>(sVt + ((DH * VSTR + 15) & ~15));
+    char *sV = sK + S_pad * KSTR;
+    float *sMask = reinterpret_cast<float *>(sV + S_pad * KSTR);
+    int *sLive = reinterpret_cast<int *>(sMask + S_pad);          // per key tile: any unmasked key?
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int li = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
     const int64_t tok0 = (int64_t)b * S;
     const bf16_t *kbase = qkv + tok0 * ld + dm + hh * DH;
-    const bf16_t *vbase = qkv + tok0 * ld + 2 * dm + hh * DH;
+    const bf16_t *vbase = kbase + dm;
 
-    for (int c = tid; c < S_pad * (DH / 8); c += 256) {
-        const int row = c / (DH / 8), part = c % (DH / 8);
+    // every global load of the workgroup is issued up front: Q fragments, then K / V rows
+    const int qrow = wave * 32 + r;
+    const bool qvalid = wave < nkt && qrow < S;
+    bf16x8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < S) v = *reinterpret_cast<const u32x4 *>(kbase + (int64_t)row * ld + part * 8);
-        *reinterpret_cast<u32x4 *>(sK + row * KSTR + part * 16) = v;
+        if (qvalid) v = *reinterpret_cast<const u32x4 *>(qkv + (tok0 + qrow) * ld + hh * DH + ks * 16 + hf * 8);
+        qf[ks] = __builtin_bit_cast(bf16x8, v);
     }
-    {
-        constexpr int G = 64 / DWR;
-        const int dl = lane % DWR;
-        for (int grp = wave * G + lane / DWR; grp * 8 < S_pad; grp += 4 * G)
-            stage_transposed8<DH>(vbase, ld, 0, S, sVt, VSTR, grp, dl);
-    }
-    for (int k = tid; k < S_pad; k += 256) sMask[k] = (k >= S) ? -INFINITY : (key_pad[tok0 + k] ? -1e9f : 0.f);
-    __syncthreads();
-
-    for (int qt = wave; qt < nkt; qt += 4) {
-        const int qrow = qt * 32 + r;
-        const bool qvalid = qrow < S;
-        bf16x8 qf[NKS];
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (qvalid) v = *reinterpret_cast<const u32x4 *>(qkv + (tok0 + qrow) * ld + hh * DH + ks * 16 + hf * 8);
-            qf[ks] = __builtin_bit_cast(bf16x8, v);
-        }
-        f32x16 acc[ATT_MAX_KT];
-        float m = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < ATT_MAX_KT; ++kt) {
-            if (kt < nkt) {
-#pragma unroll
-                for (int t = 0; t < 16; ++t) acc[kt][t] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sK + (kt * 32 + r) * KSTR + ks * 32 + hf * 16);
-                    acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc[kt], 0, 0, 0);
-                }
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const float s = acc[kt][t] * scale + sMask[kt * 32 + rowmap(t, hf)];
-                    acc[kt][t] = s;
-                    m = fmaxf(m, s);
-                }
-            }
-        }
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < ATT_MAX_KT; ++kt) {
-            if (kt < nkt) {
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const float p = __expf(acc[kt][t] - m);
-                    acc[kt][t] = p;
-                    l += p;
-                }
-            }
-        }
-        l += __shfl_xor(l, 32);
-        f32x16 oacc[NDT];
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) oacc[dt][t] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < ATT_MAX_KT; ++kt) {
-            if (kt < nkt) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    float pv[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pv[j] = acc[kt][8 * s2 + j];
-                    const bf16x8 pf = pack8(pv);
-#pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt) {
-                        const char *vb = sVt + (dt * 32 + r) * VSTR + (kt * 32 + 16 * s2 + 4 * hf) * 2;
-                        const bf16x8 vf = frag_from_2x8B(vb, vb + 16);
-                        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (qvalid) {
-            const float inv = 1.0f / l;
-            bf16_t *orow = o + (tok0 + qrow) * ld_o + hh * DH;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                for (int tq = 0; tq < 4; ++tq) {
-                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-                    bf16x4 w;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(oacc[dt][4 * tq + j] * inv);
-                    *reinterpret_cast<bf16x4 *>(orow + dt * 32 + 8 * tq + 4 * hf) = w;
-                }
-            if (hf == 0 && lse) lse[((int64_t)b * H + hh) * S + qrow] = m + logf(l);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// backward
-// ------------------------------------------------------------------------------------------
-template <int DH>
-__global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o, int ld_do,
-                                                         float *__restrict__ delta, int B, int S, int H) {
-    constexpr int LPR = DH / 8;  // lanes per (token, head)
-    const int64_t gid = (blockIdx.x * 256ll + threadIdx.x) / LPR;
-    const int part = threadIdx.x % LPR;
-    const int64_t total = (int64_t)B * S * H;
-    float s = 0.f;
-    if (gid < total) {
-        const int64_t tok = gid / H;
-        const int hh = (int)(gid % H);
-        float a[8], g[8];
-        Vec8<bf16_t>::load(o + tok * ld_o + hh * DH + part * 8, a);
-        Vec8<bf16_t>::load(d_o + tok * ld_do + hh * DH + part * 8, g);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += a[k] * g[k];
-    }
-    s = group_sum<LPR>(s);
-    if (gid < total && part == 0) {
-        const int64_t tok = gid / H;
-        const int hh = (int)(gid % H);
-        delta[((tok / S) * H + hh) * S + tok % S] = s;
-    }
-}
-
-template <int DH>
-__global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
-                                                            const bf16_t *__restrict__ d_o, int ld_do, const float *__restrict__ lse,
-                                                            const float *__restrict__ delta, bf16_t *__restrict__ dqkv, int ld_dq,
-                                                            int S, int H, float scale) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KSTR = DH * 2 + 16;   // row-major [row][DH] images
-    constexpr int QSTR = 32 * 2 + 8;    // transposed 32-query tiles [DH][32]
-    constexpr int NKS = DH / 16, NDT = DH / 32, DWR = DH / 2;
-    const int nkt = (S + 31) >> 5, S_pad = nkt * 32;
-    const int TSTR = S_pad * 2 + 16;    // [DH][S_pad] (K^T) and [32][S_pad] (dS) images, 16-B aligned rows
-    char *sK = smem;
-    char *sV = sK + S_pad * KSTR;
-    char *sKt = sV + S_pad * KSTR;
-    char *sQ = sKt + DH * TSTR;
-    char *sdO = sQ + 32 * KSTR;
-    char *sQt = sdO + 32 * KSTR;
-    char *sdOt = sQt + ((DH * QSTR + 15) & ~15);
-    char *sDS = sdOt + ((DH * QSTR + 15) & ~15);
-    float *sLse = reinterpret_cast<float *>(sDS + 32 * TSTR);
-    float *sDelta = sLse + 32;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
-    const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
-    const int64_t tok0 = (int64_t)b * S;
-    const bf16_t *qbase = qkv + tok0 * ld + hh * DH;
-    const bf16_t *kbase = qbase + dm;
-    const bf16_t *vbase = qbase + 2 * dm;
-    const bf16_t *gbase = d_o + tok0 * ld_do + hh * DH;
-
-    for (int c = tid; c < S_pad * (DH / 8); c += 256) {
-        const int row = c / (DH / 8), part = c % (DH / 8);
+    if (tid < ATT_MAX_KT) sLive[tid] = 0;
+    for (int c = tid; c < S_pad * CH; c += 512) {
+        const int row = c / CH, part = c % CH;
         u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
         if (row < S) {
             kv = *reinterpret_cast<const u32x4 *>(kbase + (int64_t)row * ld + part * 8);
@@ -256,48 +127,194 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const bf16_t *__rest
         *reinterpret_cast<u32x4 *>(sK + row * KSTR + part * 16) = kv;
         *reinterpret_cast<u32x4 *>(sV + row * KSTR + part * 16) = vv;
     }
-    constexpr int G = 64 / DWR;
-    const int dl = lane % DWR, slot = wave * G + lane / DWR;
-    for (int grp = slot; grp * 8 < S_pad; grp += 4 * G) stage_transposed8<DH>(kbase, ld, 0, S, sKt, TSTR, grp, dl);
-
-    // this wave's key tiles: kt = wave and wave + 4; key of this lane inside a tile = r
-    float madd[2];
-    f32x16 dk[2][NDT], dv[2][NDT];
+    __syncthreads();
+    for (int k = tid; k < S_pad; k += 512) {
+        const bool live = k < S && !key_pad[tok0 + k];
+        sMask[k] = (k >= S) ? -INFINITY : (live ? 0.f : -1e9f);
+        if (live) sLive[k >> 5] = 1;     // benign race: every writer stores 1
+    }
+    __syncthreads();
+    if (wave >= nkt) return;            // wave-uniform; no barrier below
+    // Fully padded key tiles contribute exp(-1e9 - m) == 0 and are skipped -- unless the sequence has no
+    // unmasked key at all (never the case for chained inputs: [CLS]/[SEP] are real tokens), where the
+    // reference's softmax degenerates to uniform weights: then every tile is processed.
+    int any_live = 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int key = (wave + 4 * i) * 32 + r;
-        madd[i] = (key >= S) ? -INFINITY : (key_pad[tok0 + key] ? -1e9f : 0.f);
+    for (int kt = 0; kt < ATT_MAX_KT; ++kt) any_live |= (kt < nkt) ? sLive[kt] : 0;
+    const int force = !any_live;
+
+    f32x16 acc[ATT_MAX_KT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MAX_KT; ++kt) {
+        if (kt < nkt && (sLive[kt] | force)) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[kt][t] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sK + (kt * 32 + r) * KSTR + ks * 32 + hf * 16);
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc[kt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float sc = acc[kt][t] * scale + sMask[kt * 32 + rowmap(t, hf)];
+                acc[kt][t] = sc;
+                m = fmaxf(m, sc);
+            }
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MAX_KT; ++kt) {
+        if (kt < nkt && (sLive[kt] | force)) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float p = __expf(acc[kt][t] - m);
+                acc[kt][t] = p;
+                l += p;
+            }
+        }
+    }
+    l += __shfl_xor(l, 32);
+    f32x16 oacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) oacc[dt][t] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MAX_KT; ++kt) {
+        if (kt < nkt && (sLive[kt] | force)) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = acc[kt][8 * s2 + j];
+                const bf16x8 pf = pack8(pv);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    // V^T[dh = dt*32 + r][keys kt*32 + 16 s2 + 4 hf + {0..3, 8..11}] from row-major V
+                    const char *vb = sV + (kt * 32 + 16 * s2 + 4 * hf + (li >> 2)) * KSTR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
+                    const bf16x8 vf = frag_tr(vb, 8 * KSTR);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (qvalid) {
+        const float inv = 1.0f / l;
+        bf16_t *orow = o + (tok0 + qrow) * ld_o + hh * DH;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { dk[i][dt][t] = 0.f; dv[i][dt][t] = 0.f; }
+            for (int tq = 0; tq < 4; ++tq) {
+                bf16x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(oacc[dt][4 * tq + j] * inv);
+                *reinterpret_cast<bf16x4 *>(orow + dt * 32 + 8 * tq + 4 * hf) = w;
+            }
+        if (hf == 0 && lse) lse[((int64_t)b * H + hh) * S + qrow] = m + logf(l);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: 512 threads; wave w owns key tile w (dK^T / dV^T stay in its registers); 32-query tiles
+// stream through a double-buffered LDS image with register prefetch; delta = rowsum(dO * O) is
+// computed while staging; dQ tile = 8 (16 x 16) MFMA tiles, one per wave.
+// ------------------------------------------------------------------------------------------
+template <int DH>
+__global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
+                                                            const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o,
+                                                            int ld_do, const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
+                                                            int ld_dq, int S, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KSTR = DH * 2 + 16;
+    constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8;
+    constexpr int QBUF = 2 * 32 * KSTR + 256;          // sQ | sdO | lse[32] | delta[32]
+    const int nkt = (S + 31) >> 5, S_pad = nkt * 32;
+    const int TSTR = S_pad * 2 + 16;
+    char *sK = smem;
+    char *sV = sK + S_pad * KSTR;
+    char *sQB = sV + S_pad * KSTR;                       // 2 query-tile buffers
+    char *sDS = sQB + 2 * QBUF;                          // [32][TSTR] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
+    const int64_t tok0 = (int64_t)b * S;
+    const bf16_t *qbase = qkv + tok0 * ld + hh * DH;
+    const bf16_t *kbase = qbase + dm;
+    const bf16_t *vbase = qbase + 2 * dm;
+    const bf16_t *gbase = d_o + tok0 * ld_do + hh * DH;
+    const bf16_t *obase = o + tok0 * ld_o + hh * DH;
+    const float *lbase = lse + ((int64_t)b * H + hh) * S;
+
+    // staging roles for a 32-query tile: threads [0, 32 CH) carry Q chunks, [256, 256 + 32 CH) carry dO (+ O for delta)
+    const bool roleQ = tid < 32 * CH, roleG = tid >= 256 && tid < 256 + 32 * CH;
+    const int srow = (roleG ? tid - 256 : tid) / CH, spart = (roleG ? tid - 256 : tid) % CH;
+    u32x4 pre = {0u, 0u, 0u, 0u};
+    float pre_delta = 0.f, pre_lse = INFINITY;
+    auto prefetch = [&](int q0) {
+        pre = (u32x4){0u, 0u, 0u, 0u};
+        pre_delta = 0.f;
+        const bool ok = q0 + srow < S;
+        if (roleQ && ok) pre = *reinterpret_cast<const u32x4 *>(qbase + (int64_t)(q0 + srow) * ld + spart * 8);
+        if (roleG) {
+            float part = 0.f;
+            if (ok) {
+                pre = *reinterpret_cast<const u32x4 *>(gbase + (int64_t)(q0 + srow) * ld_do + spart * 8);
+                const bf16x8 gv = __builtin_bit_cast(bf16x8, pre);
+                const bf16x8 ov = *reinterpret_cast<const bf16x8 *>(obase + (int64_t)(q0 + srow) * ld_o + spart * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) part += (float)gv[k] * (float)ov[k];
+            }
+            pre_delta = group_sum<CH>(part);
+        }
+        if (tid < 32) pre_lse = (q0 + tid < S) ? lbase[q0 + tid] : INFINITY;
+    };
+    auto commit = [&](char *buf) {
+        if (roleQ) *reinterpret_cast<u32x4 *>(buf + srow * KSTR + spart * 16) = pre;
+        if (roleG) {
+            *reinterpret_cast<u32x4 *>(buf + 32 * KSTR + srow * KSTR + spart * 16) = pre;
+            if (spart == 0) reinterpret_cast<float *>(buf + 2 * 32 * KSTR)[32 + srow] = pre_delta;
+        }
+        if (tid < 32) reinterpret_cast<float *>(buf + 2 * 32 * KSTR)[tid] = pre_lse;
+    };
+
+    prefetch(0);
+    for (int c = tid; c < S_pad * CH; c += 512) {
+        const int row = c / CH, part = c % CH;
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (row < S) {
+            kv = *reinterpret_cast<const u32x4 *>(kbase + (int64_t)row * ld + part * 8);
+            vv = *reinterpret_cast<const u32x4 *>(vbase + (int64_t)row * ld + part * 8);
+        }
+        *reinterpret_cast<u32x4 *>(sK + row * KSTR + part * 16) = kv;
+        *reinterpret_cast<u32x4 *>(sV + row * KSTR + part * 16) = vv;
+    }
+    commit(sQB);
+
+    // this wave's key tile; the lane's key inside it is r
+    const int kt = wave;
+    const int key = kt * 32 + r;
+    const bool key_live = kt < nkt && key < S && !key_pad[tok0 + key];
+    const float madd = (kt >= nkt || key >= S) ? -INFINITY : (key_live ? 0.f : -1e9f);
+    const bool tile_live = __any(key_live);           // ballot over the wave's 64 lanes (both halves hold the same keys)
+    f32x16 dk[NDT], dv[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { dk[dt][t] = 0.f; dv[dt][t] = 0.f; }
+    __syncthreads();
 
     for (int qt = 0; qt < nkt; ++qt) {
         const int q0 = qt * 32;
-        __syncthreads();   // previous tile's dQ phase has finished with sDS / sQ / sdO
-        for (int c = tid; c < 32 * (DH / 8); c += 256) {
-            const int row = c / (DH / 8), part = c % (DH / 8);
-            u32x4 qv = {0u, 0u, 0u, 0u}, gv = {0u, 0u, 0u, 0u};
-            if (q0 + row < S) {
-                qv = *reinterpret_cast<const u32x4 *>(qbase + (int64_t)(q0 + row) * ld + part * 8);
-                gv = *reinterpret_cast<const u32x4 *>(gbase + (int64_t)(q0 + row) * ld_do + part * 8);
-            }
-            *reinterpret_cast<u32x4 *>(sQ + row * KSTR + part * 16) = qv;
-            *reinterpret_cast<u32x4 *>(sdO + row * KSTR + part * 16) = gv;
-        }
-        if (slot < 4) stage_transposed8<DH>(qbase + (int64_t)q0 * ld, ld, 0, S - q0, sQt, QSTR, slot, dl);
-        else if (slot < 8) stage_transposed8<DH>(gbase + (int64_t)q0 * ld_do, ld_do, 0, S - q0, sdOt, QSTR, slot - 4, dl);
-        if (tid < 32) {
-            const bool ok = q0 + tid < S;
-            sLse[tid] = ok ? lse[((int64_t)b * H + hh) * S + q0 + tid] : INFINITY;
-            sDelta[tid] = ok ? delta[((int64_t)b * H + hh) * S + q0 + tid] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int kt = wave + 4 * i;
-            if (kt < nkt) {
+        char *cur = sQB + (qt & 1) * QBUF;
+        const char *sQ = cur, *sdO = cur + 32 * KSTR;
+        const float *sLse = reinterpret_cast<const float *>(cur + 2 * 32 * KSTR), *sDelta = sLse + 32;
+        const bool more = qt + 1 < nkt;
+        if (more) prefetch(q0 + 32);
+        if (kt < nkt) {
+            if (tile_live) {
                 f32x16 sa, pa;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) { sa[t] = 0.f; pa[t] = 0.f; }
@@ -314,7 +331,7 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const bf16_t *__rest
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const int q = rowmap(t, hf);
-                    const float p = __expf(sa[t] * scale + madd[i] - sLse[q]);
+                    const float p = __expf(sa[t] * scale + madd - sLse[q]);
                     pv[t] = p;
                     dsv[t] = p * (pa[t] - sDelta[q]);
                     *reinterpret_cast<bf16_t *>(sDS + q * TSTR + (kt * 32 + r) * 2) = (bf16_t)dsv[t];
@@ -325,54 +342,56 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const bf16_t *__rest
                     const bf16x8 df = pack8(dsv + 8 * s2);
 #pragma unroll
                     for (int dt = 0; dt < NDT; ++dt) {
-                        const int off = (dt * 32 + r) * QSTR + (16 * s2 + 4 * hf) * 2;
-                        const bf16x8 fgt = frag_from_2x8B(sdOt + off, sdOt + off + 16);
-                        dv[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fgt, pf, dv[i][dt], 0, 0, 0);
-                        const bf16x8 fqt = frag_from_2x8B(sQt + off, sQt + off + 16);
-                        dk[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fqt, df, dk[i][dt], 0, 0, 0);
+                        // dO^T / Q^T [dh = dt*32 + r][queries 16 s2 + 4 hf + {0..3, 8..11}] from the row-major tiles
+                        const int off = (16 * s2 + 4 * hf + (li >> 2)) * KSTR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
+                        const bf16x8 fgt = frag_tr(sdO + off, 8 * KSTR);
+                        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fgt, pf, dv[dt], 0, 0, 0);
+                        const bf16x8 fqt = frag_tr(sQ + off, 8 * KSTR);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fqt, df, dk[dt], 0, 0, 0);
                     }
                 }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    *reinterpret_cast<bf16_t *>(sDS + rowmap(t, hf) * TSTR + (kt * 32 + r) * 2) = (bf16_t)0.f;
             }
         }
-        __syncthreads();
-        if (wave < NDT) {   // dQ tile: [32 q][32 dh] per wave, summed over all keys
-            f32x16 qa;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) qa[t] = 0.f;
-            for (int ks = 0; ks < S_pad / 16; ++ks) {
-                const bf16x8 fs = *reinterpret_cast<const bf16x8 *>(sDS + r * TSTR + ks * 32 + hf * 16);
-                const bf16x8 fk = *reinterpret_cast<const bf16x8 *>(sKt + (wave * 32 + r) * TSTR + ks * 32 + hf * 16);
-                qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fs, fk, qa, 0, 0, 0);
+        __syncthreads();                                  // dS tile complete
+        if (wave < 2 * (DH / 16)) {                       // dQ[32 q][DH] as (16 q) x (16 dh) tiles, one per wave
+            const int qi = wave / (DH / 16), di = wave % (DH / 16);
+            f32x4 qa = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < nkt; ++ks) {
+                const bf16x8 fs = *reinterpret_cast<const bf16x8 *>(sDS + (qi * 16 + li) * TSTR + (ks * 32 + 8 * g) * 2);
+                // K^T: B[k = key ks*32 + 8 g + j][col = dh di*16 + li] via two transposed 4-key reads
+                const char *kb = sK + (ks * 32 + 8 * g + (li >> 2)) * KSTR + (di * 16 + 4 * (li & 3)) * 2;
+                const bf16x8 fk = frag_tr(kb, 4 * KSTR);
+                qa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fs, fk, qa, 0, 0, 0);
             }
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int q = q0 + rowmap(t, hf);
-                if (q < S) dqkv[(tok0 + q) * ld_dq + hh * DH + wave * 32 + r] = (bf16_t)(qa[t] * scale);
+            for (int t = 0; t < 4; ++t) {
+                const int q = q0 + qi * 16 + 4 * g + t;
+                if (q < S) dqkv[(tok0 + q) * ld_dq + hh * DH + di * 16 + li] = (bf16_t)(qa[t] * scale);
             }
         }
+        if (more) commit(sQB + ((qt + 1) & 1) * QBUF);
+        __syncthreads();                                  // dS consumed; next query tile visible
     }
-    // dK^T / dV^T accumulators: rows = dh (registers), col = key (lane)
+    if (kt < nkt && key < S) {
+        bf16_t *krow = dqkv + (tok0 + key) * ld_dq + dm + hh * DH;
+        bf16_t *vrow = krow + dm;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int key = (wave + 4 * i) * 32 + r;
-        if (wave + 4 * i < nkt && key < S) {
-            bf16_t *krow = dqkv + (tok0 + key) * ld_dq + dm + hh * DH;
-            bf16_t *vrow = krow + dm;
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
+            for (int tq = 0; tq < 4; ++tq) {
+                bf16x4 wk, wv;
 #pragma unroll
-                for (int tq = 0; tq < 4; ++tq) {
-                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-                    bf16x4 wk, wv;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        wk[j] = (bf16_t)(dk[i][dt][4 * tq + j] * scale);
-                        wv[j] = (bf16_t)dv[i][dt][4 * tq + j];
-                    }
-                    *reinterpret_cast<bf16x4 *>(krow + dt * 32 + 8 * tq + 4 * hf) = wk;
-                    *reinterpret_cast<bf16x4 *>(vrow + dt * 32 + 8 * tq + 4 * hf) = wv;
+                for (int j = 0; j < 4; ++j) {
+                    wk[j] = (bf16_t)(dk[dt][4 * tq + j] * scale);
+                    wv[j] = (bf16_t)dv[dt][4 * tq + j];
                 }
-        }
+                *reinterpret_cast<bf16x4 *>(krow + dt * 32 + 8 * tq + 4 * hf) = wk;
+                *reinterpret_cast<bf16x4 *>(vrow + dt * 32 + 8 * tq + 4 * hf) = wv;
+            }
     }
 }
 
@@ -383,14 +402,14 @@ int b4c_attn_fwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, void 
                       int H, int dh, hipStream_t st) {
     if (!mfma_shape_ok(S, dh)) return B4C_EUNSUPPORTED;
     const int S_pad = (S + 31) / 32 * 32;
-    const size_t shm = (size_t)S_pad * (dh * 2 + 16) + (((size_t)dh * (S_pad * 2 + 8) + 15) & ~(size_t)15) + (size_t)S_pad * 4;
+    const size_t shm = 2 * (size_t)S_pad * (dh * 2 + 16) + (size_t)S_pad * 4 + ATT_MAX_KT * 4;
     const float scale = 1.0f / sqrtf((float)dh);
     if (dh == 64) {
         allow_lds_attn(attn_fwd_mfma_kernel<64>, shm);
-        attn_fwd_mfma_kernel<64><<<B * H, 256, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (bf16_t *)o, ld_o, lse, S, H, scale);
+        attn_fwd_mfma_kernel<64><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (bf16_t *)o, ld_o, lse, S, H, scale);
     } else {
         allow_lds_attn(attn_fwd_mfma_kernel<32>, shm);
-        attn_fwd_mfma_kernel<32><<<B * H, 256, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (bf16_t *)o, ld_o, lse, S, H, scale);
+        attn_fwd_mfma_kernel<32><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (bf16_t *)o, ld_o, lse, S, H, scale);
     }
     return b4c_check_launch("attn_fwd_mfma");
 }
@@ -399,19 +418,17 @@ int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const
                       int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B, int S, int H, int dh,
                       hipStream_t st) {
     if (!mfma_shape_ok(S, dh)) return B4C_EUNSUPPORTED;
+    (void)delta;   // delta is computed while staging dO / O tiles
     const int S_pad = (S + 31) / 32 * 32;
-    const size_t kstr = dh * 2 + 16, tstr = S_pad * 2 + 16, qstr = 72;
-    const size_t shm = 2 * S_pad * kstr + dh * tstr + 2 * 32 * kstr + 2 * ((dh * qstr + 15) & ~(size_t)15) + 32 * tstr + 64 * 4;
+    const size_t kstr = dh * 2 + 16, tstr = S_pad * 2 + 16;
+    const size_t shm = 2 * S_pad * kstr + 2 * (2 * 32 * kstr + 256) + 32 * tstr;
     const float scale = 1.0f / sqrtf((float)dh);
-    const int64_t groups = (int64_t)B * S * H;
     if (dh == 64) {
-        attn_delta_kernel<64><<<(int)ceil_div64(groups * 8, 256), 256, 0, st>>>((const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, delta, B, S, H);
         allow_lds_attn(attn_bwd_mfma_kernel<64>, shm);
-        attn_bwd_mfma_kernel<64><<<B * H, 256, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)d_o, ld_do, lse, delta, (bf16_t *)dqkv, ld_dqkv, S, H, scale);
+        attn_bwd_mfma_kernel<64><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale);
     } else {
-        attn_delta_kernel<32><<<(int)ceil_div64(groups * 4, 256), 256, 0, st>>>((const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, delta, B, S, H);
         allow_lds_attn(attn_bwd_mfma_kernel<32>, shm);
-        attn_bwd_mfma_kernel<32><<<B * H, 256, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)d_o, ld_do, lse, delta, (bf16_t *)dqkv, ld_dqkv, S, H, scale);
+        attn_bwd_mfma_kernel<32><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale);
     }
     return b4c_check_launch("attn_bwd_mfma");
 }
