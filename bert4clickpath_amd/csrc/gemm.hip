@@ -14,6 +14,7 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (once per process).
 template <typename K> static void allow_lds(K kernel, size_t bytes) {
@@ -128,9 +129,16 @@ __device__ __forceinline__ void epilogue8(float (&v)[8], int64_t row, int col, O
     Vec8<OutT>::store(C + row * ldc + col, v);
 }
 
-// One LDS stage (36.9 KB -> 4 workgroups per CU) with register prefetch of the next K tile; 2-byte outputs
-// leave through an LDS transpose so that every global store / gate / residual access is a 16-B row chunk.
-template <typename T, typename OutT>
+// One LDS stage (36.9 KB -> 4 workgroups per CU) with register prefetch of the next K tile.  The kernel is
+// latency-bound at K = 128 (two K tiles), so dependent round trips to memory are issued early:
+//   * the bias chunk of each lane is loaded at entry,
+//   * gate / residual chunks are requested before the last tile's MFMAs and consumed after them.
+// MFMA roles are swapped (acc^T = Bt_tile . A_tile^T: rows = n in registers, col = m on the lane) so a lane
+// owns 4 consecutive n of one output row: 2-byte outputs go to the LDS transpose as 8-byte writes and leave
+// as 16-byte row chunks.
+#define OUT_STRIDE 136   // bytes per staged output row (128 + 8: 8-byte writes spread over the banks)
+
+template <typename T, typename OutT, bool EPI>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, int lda, const T *__restrict__ Bt, int ldb,
                                                       OutT *__restrict__ C, int ldc, int M, int N, int K,
                                                       const float *__restrict__ bias, int act, const T *__restrict__ gate,
@@ -138,8 +146,12 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
-    f32x16 acc[2][2];
+    // blockIdx.x walks the N tiles first: neighbours in dispatch order share the A tile (L2) and write
+    // adjacent 256-B segments of the same output rows (DRAM pages), which matters for the vocabulary GEMM
+    const int ntn = (N + TILE - 1) / TILE;
+    const int m0 = (blockIdx.x / ntn) * TILE, n0 = (blockIdx.x % ntn) * TILE;
+    const bool vec = (sizeof(OutT) == 2) && vec_ok;
+    f32x16 acc[2][2];   // acc[j][i]: rows = n (tile j of this wave's 64 columns), col = m (tile i of its 64 rows)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -148,65 +160,106 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, i
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
 
     const int nk = (K + MM<T>::BKE - 1) / MM<T>::BKE;
-    u32x4 ra[4], rb[4];
-    nt_load<T>(A, lda, m0, M, 0, K, tid, ra);
-    nt_load<T>(Bt, ldb, n0, N, 0, K, tid, rb);
-    nt_store(smem, tid, ra);
-    nt_store(smem + TILE_BYTES, tid, rb);
+    u32x4 xa[4], xb[4];
+    nt_load<T>(A, lda, m0, M, 0, K, tid, xa);
+    nt_load<T>(Bt, ldb, n0, N, 0, K, tid, xb);
+    // epilogue chunk q of this lane: row (lane + 64 q) >> 3 of the wave's 64 rows, columns 8 * (lane & 7) ...
+    const int part = lane & 7;
+    const int gcol = n0 + wn * 64 + part * 8;
+    float bv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bv[k] = 0.f;
+    if (vec && bias && gcol < N) Vec8<float>::load(bias + gcol, bv);
+    nt_store(smem, tid, xa);
+    nt_store(smem + TILE_BYTES, tid, xb);
     __syncthreads();
+    // one prefetched epilogue operand (gate if given, else residual): requested before the last tile's MFMAs,
+    // into the staging registers that are idle by then
+    const T *epi = EPI ? (gate ? gate : residual) : nullptr;
+    const int lde = gate ? ldg : ldr;
+    u32x4 pe[EPI ? 8 : 1];
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) {
-            nt_load<T>(A, lda, m0, M, (kt + 1) * MM<T>::BKE, K, tid, ra);
-            nt_load<T>(Bt, ldb, n0, N, (kt + 1) * MM<T>::BKE, K, tid, rb);
+            nt_load<T>(A, lda, m0, M, (kt + 1) * MM<T>::BKE, K, tid, xa);
+            nt_load<T>(Bt, ldb, n0, N, (kt + 1) * MM<T>::BKE, K, tid, xb);
+        } else if (EPI && vec && epi) {
+#pragma unroll
+            for (int q = 0; q < (EPI ? 8 : 1); ++q) {
+                const int64_t grow = m0 + wm * 64 + ((lane + q * 64) >> 3);
+                pe[q] = (grow < M && gcol < N) ? *reinterpret_cast<const u32x4 *>(epi + grow * lde + gcol) : (u32x4){0u, 0u, 0u, 0u};
+            }
         }
-        mma_stage<T>(smem, smem + TILE_BYTES, wm, wn, r, h, acc);
+        mma_stage<T>(smem + TILE_BYTES, smem, wn, wm, r, h, acc);
         __syncthreads();
         if (more) {
-            nt_store(smem, tid, ra);
-            nt_store(smem + TILE_BYTES, tid, rb);
+            nt_store(smem, tid, xa);
+            nt_store(smem + TILE_BYTES, tid, xb);
             __syncthreads();
         }
     }
-    // acc register t of tile (i,j): row = (t&3) + 8*(t>>2) + 4*h, col = lane&31.
-    if (sizeof(OutT) == 2 && vec_ok) {
-        // wave-private 64 x 64 tile -> LDS [64][144 B] -> 16-B row chunks
-        char *ws = smem + wave * (64 * LDS_STRIDE);
+    // acc[j][i] register t: n = j*32 + (t&3) + 8*(t>>2) + 4*h (4 consecutive n per t>>2), m = i*32 + r.
+    if (vec) {
+        char *ws = smem + wave * (64 * OUT_STRIDE);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int row = i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
-                    *reinterpret_cast<OutT *>(ws + row * LDS_STRIDE + (j * 32 + r) * 2) = (OutT)acc[i][j][t];
+                for (int tq = 0; tq < 4; ++tq) {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+                    bf16x4_t w;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w[k] = (bf16_t)acc[j][i][4 * tq + k];
+                    *reinterpret_cast<bf16x4_t *>(ws + (i * 32 + r) * OUT_STRIDE + (j * 32 + 8 * tq + 4 * h) * 2) = w;
                 }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int c = lane + q * 64;
-            const int row = c >> 3, part = c & 7;
+            const int row = (lane + q * 64) >> 3;
             const int64_t grow = m0 + wm * 64 + row;
-            const int gcol = n0 + wn * 64 + part * 8;
             if (grow < M && gcol < N) {
+                const u32x2 lo = *reinterpret_cast<const u32x2 *>(ws + row * OUT_STRIDE + part * 16);
+                const u32x2 hi = *reinterpret_cast<const u32x2 *>(ws + row * OUT_STRIDE + part * 16 + 8);
+                const u32x4 w4 = {lo[0], lo[1], hi[0], hi[1]};
+                const bf16x8 cv = __builtin_bit_cast(bf16x8, w4);
                 float v[8];
-                Vec8<OutT>::load(reinterpret_cast<const OutT *>(ws + row * LDS_STRIDE + part * 16), v);
-                epilogue8<T, OutT>(v, grow, gcol, C, ldc, bias, act, gate, ldg, residual, ldr);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (float)cv[k] + bv[k];
+                if (act == B4C_ACT_RELU) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                }
+                if (EPI && gate) {
+                    const bf16x8 gv = __builtin_bit_cast(bf16x8, pe[EPI ? q : 0]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = ((float)gv[k] > 0.f) ? v[k] : 0.f;
+                    if (residual) {   // both operands at once: not on the model's path, loaded late
+                        float rr[8];
+                        Vec8<T>::load(residual + grow * ldr + gcol, rr);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] += rr[k];
+                    }
+                } else if (EPI && residual) {
+                    const bf16x8 rv = __builtin_bit_cast(bf16x8, pe[EPI ? q : 0]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
+                }
+                Vec8<OutT>::store(C + grow * ldc + gcol, v);
             }
         }
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + r;
-            const float bv = (bias && col < N) ? bias[col] : 0.f;
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + wm * 64 + i * 32 + r;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const int row = m0 + wm * 64 + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+                const int col = n0 + wn * 64 + j * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
                 if (row < M && col < N) {
-                    float v = acc[i][j][t] + bv;
+                    float v = acc[j][i][t] + (bias ? bias[col] : 0.f);
                     if (act == B4C_ACT_RELU) v = fmaxf(v, 0.f);
                     if (gate) v = ((float)gate[(int64_t)row * ldg + col] > 0.f) ? v : 0.f;
                     if (residual) v += (float)residual[(int64_t)row * ldr + col];
@@ -229,8 +282,9 @@ extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void
     B4C_REQUIRE((((uintptr_t)A | (uintptr_t)Bt) & 15) == 0, "gemm_nt: operands must be 16-byte aligned");
     B4C_REQUIRE(out_dtype == dtype || out_dtype == B4C_F32, "gemm_nt: out_dtype %d", out_dtype);
     B4C_REQUIRE(act == B4C_ACT_NONE || act == B4C_ACT_RELU, "gemm_nt: act %d", act);
-    dim3 grid((M + TILE - 1) / TILE, (N + TILE - 1) / TILE);
-    B4C_REQUIRE(grid.y <= 65535, "gemm_nt: N too large");
+    const int64_t nblocks = ceil_div64(M, TILE) * ceil_div64(N, TILE);
+    B4C_REQUIRE(nblocks < (1ll << 31), "gemm_nt: too many tiles");
+    dim3 grid((unsigned)nblocks);
     hipStream_t st = (hipStream_t)stream;
     const size_t shm = STAGE_BYTES;
     // the 16-byte epilogue needs whole, aligned 8-column chunks in C / gate / residual / bias
@@ -238,12 +292,19 @@ extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void
                        (!gate || (ldg % 8 == 0 && ((uintptr_t)gate & 15) == 0)) &&
                        (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0)) &&
                        (!bias || ((uintptr_t)bias & 15) == 0);
-    if (dtype == B4C_F32)
-        gemm_nt_kernel<float, float><<<grid, 256, shm, st>>>((const float *)A, lda, (const float *)Bt, ldb, (float *)C, ldc, M, N, K, bias, act, (const float *)gate, ldg, (const float *)residual, ldr, vec_ok);
-    else if (out_dtype == B4C_F32)
-        gemm_nt_kernel<bf16_t, float><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (float *)C, ldc, M, N, K, bias, act, (const bf16_t *)gate, ldg, (const bf16_t *)residual, ldr, vec_ok);
-    else
-        gemm_nt_kernel<bf16_t, bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, act, (const bf16_t *)gate, ldg, (const bf16_t *)residual, ldr, vec_ok);
+#define NT_ARGS(TT, OT) (const TT *)A, lda, (const TT *)Bt, ldb, (OT *)C, ldc, M, N, K, bias, act, (const TT *)gate, ldg, (const TT *)residual, ldr, vec_ok
+    const bool epi = gate || residual;
+    if (dtype == B4C_F32) {
+        if (epi) gemm_nt_kernel<float, float, true><<<grid, 256, shm, st>>>(NT_ARGS(float, float));
+        else gemm_nt_kernel<float, float, false><<<grid, 256, shm, st>>>(NT_ARGS(float, float));
+    } else if (out_dtype == B4C_F32) {
+        if (epi) gemm_nt_kernel<bf16_t, float, true><<<grid, 256, shm, st>>>(NT_ARGS(bf16_t, float));
+        else gemm_nt_kernel<bf16_t, float, false><<<grid, 256, shm, st>>>(NT_ARGS(bf16_t, float));
+    } else {
+        if (epi) gemm_nt_kernel<bf16_t, bf16_t, true><<<grid, 256, shm, st>>>(NT_ARGS(bf16_t, bf16_t));
+        else gemm_nt_kernel<bf16_t, bf16_t, false><<<grid, 256, shm, st>>>(NT_ARGS(bf16_t, bf16_t));
+    }
+#undef NT_ARGS
     return b4c_check_launch("gemm_nt");
 }
 

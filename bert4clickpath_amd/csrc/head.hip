@@ -261,6 +261,155 @@ __global__ void __launch_bounds__(1024) softmax_ce_fused_kernel(T *__restrict__ 
     }
 }
 
+// bf16 throughput form: 512 threads per row, the row stays in registers as RAW bf16 pairs (NCH x 16 B
+// per thread, <= 128 VGPRs so 2 workgroups share a CU and their load / compute / store phases overlap), exponentials
+// are recomputed per pass with v_exp_f32.  When no probability leaves [1e-7, 1-1e-7] the clip is the
+// identity (S = Pu = 1, G = 0) and the TF form reduces to p - onehot: that row-uniform fast path skips
+// the S / Pu pass.
+template <int NCH>
+__global__ void __launch_bounds__(512, 4) softmax_ce_bf16_kernel(bf16_t *__restrict__ x, int ld, const int32_t *__restrict__ labels,
+                                                              float *__restrict__ item_loss, const float *__restrict__ grad_scale,
+                                                              int64_t R, int V, int variant) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    __shared__ float buf[8];
+    __shared__ float buf2[8];
+    __shared__ float s_ey;
+    const int tid = threadIdx.x;
+    const int nch_ld = ld >> 3;
+    const float gs = grad_scale[0];
+    const float LOG2E = 1.4426950408889634f;
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        bf16_t *xr = x + row * ld;
+        const int y = labels[row];
+        const bool valid = y >= 0 && y < V;
+        u32x4 raw[NCH];
+        if (!valid) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = i * 512 + tid;
+                if (c < nch_ld) *reinterpret_cast<u32x4 *>(xr + c * 8) = (u32x4){0u, 0u, 0u, 0u};
+            }
+            if (tid == 0) item_loss[row] = (y >= V) ? NAN : 0.f;
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 512 + tid;
+            raw[i] = (c < nch_ld) ? *reinterpret_cast<const u32x4 *>(xr + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+        // element k of chunk i: dword k>>1, low half for even k
+#define CE_ELEM(i, k) __uint_as_float((k & 1) ? (raw[i][k >> 1] & 0xFFFF0000u) : (raw[i][k >> 1] << 16))
+        float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int base = (i * 512 + tid) * 8;
+            if (base + 8 <= V) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float v = CE_ELEM(i, k); mx = fmaxf(mx, v); mn = fminf(mn, v); }
+            } else if (base < V) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (base + k < V) { const float v = CE_ELEM(i, k); mx = fmaxf(mx, v); mn = fminf(mn, v); }
+            }
+        }
+        mx = wave_max(mx);
+        mn = -wave_max(-mn);
+        __syncthreads();
+        if ((tid & 63) == 0) { buf[tid >> 6] = mx; buf2[tid >> 6] = mn; }
+        __syncthreads();
+        mx = buf[0]; mn = buf2[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { mx = fmaxf(mx, buf[w]); mn = fminf(mn, buf2[w]); }
+        const float mb = mx * LOG2E;
+        float z = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int base = (i * 512 + tid) * 8;
+            if (base < V) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float e = __builtin_amdgcn_exp2f(CE_ELEM(i, k) * LOG2E - mb);
+                    if (base + 8 <= V || base + k < V) {
+                        z += e;
+                        if (base + k == y) s_ey = e;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep one chunk's temporaries live at a time
+        }
+        z = wave_sum(z);
+        __syncthreads();
+        if ((tid & 63) == 0) buf[tid >> 6] = z;
+        __syncthreads();
+        z = buf[0] + buf[1] + buf[2] + buf[3] + buf[4] + buf[5] + buf[6] + buf[7];
+        const float invz = 1.0f / z;
+        const float py = s_ey * invz;
+        const float pmin = __builtin_amdgcn_exp2f(mn * LOG2E - mb) * invz, pmax = invz;   // exp2(0) / z
+        const bool clipped = (variant == B4C_CE_TF) && (pmin < KERAS_EPS || pmax > 1.0f - KERAS_EPS);
+        float invS = 1.f, G = 0.f, inv_pyc = 1.0f / py, loss = -logf(py);
+        if (clipped) {   // row-uniform
+            float S = 0.f, Pu = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int base = (i * 512 + tid) * 8;
+                if (base < V) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (base + 8 <= V || base + k < V) {
+                            const float p = __builtin_amdgcn_exp2f(CE_ELEM(i, k) * LOG2E - mb) * invz;
+                            const float pc = __builtin_amdgcn_fmed3f(p, KERAS_EPS, 1.0f - KERAS_EPS);
+                            S += pc;
+                            Pu += (pc == p) ? p : 0.f;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            S = wave_sum(S);
+            Pu = wave_sum(Pu);
+            __syncthreads();
+            if ((tid & 63) == 0) { buf[tid >> 6] = S; buf2[tid >> 6] = Pu; }
+            __syncthreads();
+            S = buf[0] + buf[1] + buf[2] + buf[3] + buf[4] + buf[5] + buf[6] + buf[7];
+            Pu = buf2[0] + buf2[1] + buf2[2] + buf2[3] + buf2[4] + buf2[5] + buf2[6] + buf2[7];
+            const float pyc = __builtin_amdgcn_fmed3f(py, KERAS_EPS, 1.0f - KERAS_EPS);
+            const float uy = (pyc == py) ? 1.f : 0.f;
+            invS = 1.0f / S;
+            G = Pu * invS - uy * py / pyc;
+            inv_pyc = uy / pyc;
+            loss = logf(S) - logf(pyc);
+        }
+        // d loss / d x_j = p_j (u_j / S - G) - [j == y] p_y u_y / clip(p_y)   (u = 1, S = 1, G = 0 when unclipped)
+        const float ydelta = py * inv_pyc;    // == 1 when unclipped
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 512 + tid;
+            const int base = c * 8;
+            if (c < nch_ld) {
+                float g[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float v = 0.f;
+                    if (base + 8 <= V || base + k < V) {
+                        const float p = __builtin_amdgcn_exp2f(CE_ELEM(i, k) * LOG2E - mb) * invz;
+                        float u = 1.f;
+                        if (clipped) u = (p >= KERAS_EPS && p <= 1.0f - KERAS_EPS) ? 1.f : 0.f;
+                        v = p * (u * invS - G);
+                        if (base + k == y) v -= ydelta;
+                        v *= gs;
+                    }
+                    g[k] = v;
+                }
+                Vec8<bf16_t>::store(xr + base, g);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef CE_ELEM
+        if (tid == 0) item_loss[row] = loss;
+        __syncthreads();   // buf / s_ey are reused by the next row
+    }
+}
+
 extern "C" int b4c_softmax_ce_fwd_bwd(void *logits, int ld, const int32_t *labels, float *item_loss,
                                       const float *grad_scale, int64_t R, int V, int variant, int dtype, void *stream) {
     B4C_REQUIRE(logits && labels && item_loss && grad_scale && R >= 0 && V > 0, "softmax_ce_fwd_bwd: bad argument");
@@ -278,7 +427,17 @@ extern "C" int b4c_softmax_ce_fwd_bwd(void *logits, int ld, const int32_t *label
     else if (nch <= 4) CE_LAUNCH(T, 4);       \
     else CE_LAUNCH(T, 8);
     if (dtype == B4C_F32) { CE_DISPATCH(float) }
-    else if (dtype == B4C_BF16) { CE_DISPATCH(bf16_t) }
+    else if (dtype == B4C_BF16) {
+        const int nch512 = (int)ceil_div64(ld / 8, 512);
+        const int grid512 = (int)(R < 3072 ? R : 3072);
+#define CE16_LAUNCH(N) softmax_ce_bf16_kernel<N><<<grid512, 512, 0, st>>>((bf16_t *)logits, ld, labels, item_loss, grad_scale, R, V, variant)
+        if (nch512 <= 2) CE16_LAUNCH(2);
+        else if (nch512 <= 4) CE16_LAUNCH(4);
+        else if (nch512 <= 8) CE16_LAUNCH(8);
+        else if (nch512 <= 13) CE16_LAUNCH(13);
+        else CE16_LAUNCH(16);
+#undef CE16_LAUNCH
+    }
     else B4C_REQUIRE(false, "softmax_ce_fwd_bwd: dtype %d", dtype);
     return b4c_check_launch("softmax_ce_fwd_bwd");
 }
