@@ -461,6 +461,128 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T *__restrict__ A, i
     }
 }
 
+// bf16 dW: token-major tiles are staged AS THEY ARE (16-B loads, 16-B LDS writes: 64 tokens x 128 features
+// per operand, 320-B rows so the transposed reads are conflict-free) and the MFMA fragments -- 8 consecutive
+// tokens of one feature -- come out of ds_read_b64_tr_b16.  No transposing stage, 4x fewer load instructions
+// than the dword path above (which remains the fp32 path).
+#define TN_STR 320                      // bytes per token row in LDS (256 + 64)
+#define TN_TILE_BYTES (64 * TN_STR)     // one operand, one stage
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ bf16x8 tn_frag(const char *p) {   // tokens +0..3 and +4..7 of the lane's feature
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3))) *)(p));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3))) *)(p + 4 * TN_STR));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t w = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ void tn_load16(const bf16_t *__restrict__ P, int ld, int f0, int64_t tok0, int64_t tok_end, int tid, u32x4 (&reg)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        const int64_t t = tok0 + (c >> 4);
+        const int f = f0 + (c & 15) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (t < tok_end && f < ld) v = *reinterpret_cast<const u32x4 *>(P + t * ld + f);
+        reg[i] = v;
+    }
+}
+__device__ __forceinline__ void tn_store16(char *s, int tid, const u32x4 (&reg)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        *reinterpret_cast<u32x4 *>(s + (c >> 4) * TN_STR + (c & 15) * 16) = reg[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ G, int ldg,
+                                                           float *__restrict__ dW, int ldw, float *__restrict__ db, int64_t M,
+                                                           int K, int N, int64_t chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5, li = lane & 15, g = lane >> 4;
+    const int k0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
+    const int64_t m_begin = blockIdx.z * chunk;
+    const int64_t m_end = (m_begin + chunk < M) ? m_begin + chunk : M;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+    float bs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bs[k] = 0.f;
+    const bool want_db = (db != nullptr) && blockIdx.x == 0;
+    const int nsteps = (int)((m_end - m_begin + 63) / 64);
+    char *sA = smem, *sG = smem + TN_TILE_BYTES;
+    u32x4 ra[4], rg[4];
+    auto colsum = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 v = __builtin_bit_cast(bf16x8, rg[i]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bs[k] += (float)v[k];
+        }
+    };
+    if (nsteps > 0) {
+        tn_load16(A, lda, k0, m_begin, m_end, tid, ra);
+        tn_load16(G, ldg, n0, m_begin, m_end, tid, rg);
+        tn_store16(sA, tid, ra);
+        tn_store16(sG, tid, rg);
+        if (want_db) colsum();
+    }
+    __syncthreads();
+    // the lane's transposed-read base: token row (li >> 2) (+ 8 h), feature column 16 (g & 1) + 4 (li & 3) of a 32-wide tile
+    const int lane_off = ((li >> 2) + 8 * h) * TN_STR + (16 * (g & 1) + 4 * (li & 3)) * 2;
+    for (int st = 0; st < nsteps; ++st) {
+        const bool more = st + 1 < nsteps;
+        if (more) {
+            tn_load16(A, lda, k0, m_begin + (int64_t)(st + 1) * 64, m_end, tid, ra);
+            tn_load16(G, ldg, n0, m_begin + (int64_t)(st + 1) * 64, m_end, tid, rg);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {   // 16 tokens per MFMA
+            const char *pa = sA + kk * 16 * TN_STR + lane_off + (wm * 64) * 2;
+            const char *pg = sG + kk * 16 * TN_STR + lane_off + (wn * 64) * 2;
+            const bf16x8 fa0 = tn_frag(pa), fa1 = tn_frag(pa + 64);
+            const bf16x8 fb0 = tn_frag(pg), fb1 = tn_frag(pg + 64);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            tn_store16(sA, tid, ra);
+            tn_store16(sG, tid, rg);
+            if (want_db) colsum();
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int row = k0 + wm * 64 + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+                if (row < K && col < N) atomicAdd(dW + (int64_t)row * ldw + col, acc[i][j][t]);
+            }
+        }
+    if (want_db) {
+        float *red = reinterpret_cast<float *>(smem);   // all fragment reads are behind the last barrier
+        if (tid < 128) red[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&red[(tid & 15) * 8 + k], bs[k]);
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N) atomicAdd(db + n0 + tid, red[tid]);
+    }
+}
+
 extern "C" int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float *dW, int ldw, float *db, int M, int K,
                            int N, int dtype, void *stream) {
     B4C_REQUIRE(A && G && dW && M > 0 && K > 0 && N > 0, "gemm_tn: null pointer / empty");
@@ -470,7 +592,10 @@ extern "C" int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float
     B4C_REQUIRE((((uintptr_t)A | (uintptr_t)G) & 3) == 0, "gemm_tn: operands must be 4-byte aligned");
     const int tk = (K + TILE - 1) / TILE, tn = (N + TILE - 1) / TILE;
     const int tok = dtype == B4C_BF16 ? 64 : 32;
-    int64_t nsplit = 2048 / ((int64_t)tk * tn);
+    // every split ends in a 128 x 128 fp32 atomic tile (64 KB at ~1.3 TB/s chip-wide): 3 workgroups per CU
+    // keep the loads busy without drowning the run in atomics
+    const int64_t tiles = (int64_t)tk * tn;
+    int64_t nsplit = (tiles <= 8 ? 768 : 1536) / tiles;
     const int64_t max_split = ceil_div64(M, (int64_t)tok * 4);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
@@ -481,8 +606,11 @@ extern "C" int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float
     B4C_REQUIRE(tn <= 65535, "gemm_tn: N too large");
     hipStream_t st = (hipStream_t)stream;
     const size_t shm = STAGE_BYTES;
+    const bool vec16 = (lda % 8 == 0) && (ldg % 8 == 0) && ((((uintptr_t)A | (uintptr_t)G) & 15) == 0);
     if (dtype == B4C_F32)
         gemm_tn_kernel<float><<<grid, 256, shm, st>>>((const float *)A, lda, (const float *)G, ldg, dW, ldw, db, M, K, N, chunk);
+    else if (vec16)
+        gemm_tn_bf16_kernel<<<grid, 256, 2 * TN_TILE_BYTES, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, dW, ldw, db, M, K, N, chunk);
     else
         gemm_tn_kernel<bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, dW, ldw, db, M, K, N, chunk);
     return b4c_check_launch("gemm_tn");
