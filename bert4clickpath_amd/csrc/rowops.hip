@@ -75,14 +75,22 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(EmbedArgs a, const float
     }
 }
 
-// scatter-add into the fp32 gradient tables; one lane = one column so that a wave-instruction
-// adds 256 contiguous bytes (MI355X float-atomic rate shape).  Exact zeros (pad rows) are skipped.
+// scatter-add into the fp32 gradient tables; one lane = one column so that a wave-instruction adds
+// contiguous bytes (MI355X float-atomic rate shape).  Exact zeros (pad rows) are skipped.  Rows with
+// id < EMB_HOT -- the reserved tokens ([MASK] alone receives one add per masked item, [CLS]/[SEP] one per
+// sequence) and the first vocabulary entries -- are accumulated in an LDS copy per workgroup and flushed
+// once: a single contended HBM row otherwise runs the whole kernel at the 14x-slower same-row atomic rate.
+#define EMB_HOT 64
 template <typename T>
 __global__ void __launch_bounds__(256) embed_bwd_kernel(EmbedArgs a, float scale, const T *__restrict__ dout, int ld,
-                                                        int64_t T_tok, int d, float rate, uint64_t seed) {
-    const int64_t total = T_tok * d;
+                                                        int64_t T_tok, int d, float rate, uint64_t seed, int64_t tok_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float hot[];   // [EMB_HOT][d]
+    for (int i = threadIdx.x; i < EMB_HOT * d; i += 256) hot[i] = 0.f;
+    __syncthreads();
     const float mul = scale * (rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f);
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t0 = blockIdx.x * tok_per_wg;
+    const int64_t t1 = (t0 + tok_per_wg < T_tok) ? t0 + tok_per_wg : T_tok;
+    for (int64_t i = t0 * d + threadIdx.x; i < t1 * d; i += 256) {
         const int64_t t = i / d;
         const int c = (int)(i - t * d);
         float g = (float)dout[t * ld + c];
@@ -94,8 +102,19 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(EmbedArgs a, float scale
             if (k < a.n && c >= a.col0[k]) f = k;
         int64_t id = a.ids[f][t];
         id = id < 0 ? 0 : (id >= a.rows[f] ? a.rows[f] - 1 : id);
-        const int fd = a.col0[f + 1] - a.col0[f];
-        atomicAdd(a.table[f] + id * fd + (c - a.col0[f]), g * mul);
+        if (id < EMB_HOT) atomicAdd(&hot[id * d + c], g * mul);
+        else atomicAdd(a.table[f] + id * (a.col0[f + 1] - a.col0[f]) + (c - a.col0[f]), g * mul);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < EMB_HOT * d; i += 256) {
+        const float v = hot[i];
+        if (v == 0.f) continue;
+        const int id = i / d, c = i - id * d;
+        int f = 0;
+#pragma unroll
+        for (int k = 1; k < B4C_MAX_FEATURES; ++k)
+            if (k < a.n && c >= a.col0[k]) f = k;
+        if (id < a.rows[f]) atomicAdd(a.table[f] + (int64_t)id * (a.col0[f + 1] - a.col0[f]) + (c - a.col0[f]), v);
     }
 }
 
@@ -155,12 +174,20 @@ extern "C" int b4c_embed_concat_pe_bwd(int n_feat, const int64_t *const *h_ids, 
     if (rc) return rc;
     B4C_REQUIRE(dout && B > 0 && S > 0 && ld_dout >= d_model, "embed_bwd: bad shape");
     const int64_t T_tok = (int64_t)B * S;
-    const int grid = grid_for(T_tok * d_model, 256);
+    B4C_REQUIRE(d_model <= 512, "embed_bwd: d_model %d > 512 (LDS hot-row cache)", d_model);
+    int grid = (int)(T_tok < 1024 ? T_tok : 1024);
+    const int64_t tok_per_wg = ceil_div64(T_tok, grid);
+    grid = (int)ceil_div64(T_tok, tok_per_wg);
+    const size_t shm = (size_t)EMB_HOT * d_model * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    if (shm > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)embed_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute((const void *)embed_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    }
     if (dtype == B4C_F32)
-        embed_bwd_kernel<float><<<grid, 256, 0, st>>>(a, scale, (const float *)dout, ld_dout, T_tok, d_model, dropout_rate, seed);
+        embed_bwd_kernel<float><<<grid, 256, shm, st>>>(a, scale, (const float *)dout, ld_dout, T_tok, d_model, dropout_rate, seed, tok_per_wg);
     else if (dtype == B4C_BF16)
-        embed_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(a, scale, (const bf16_t *)dout, ld_dout, T_tok, d_model, dropout_rate, seed);
+        embed_bwd_kernel<bf16_t><<<grid, 256, shm, st>>>(a, scale, (const bf16_t *)dout, ld_dout, T_tok, d_model, dropout_rate, seed, tok_per_wg);
     else
         B4C_REQUIRE(false, "embed_bwd: dtype %d", dtype);
     return b4c_check_launch("embed_bwd");
