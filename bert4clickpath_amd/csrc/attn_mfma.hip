@@ -117,15 +117,28 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16_t *__rest
         qf[ks] = __builtin_bit_cast(bf16x8, v);
     }
     if (tid < ATT_MAX_KT) sLive[tid] = 0;
-    for (int c = tid; c < S_pad * CH; c += 512) {
-        const int row = c / CH, part = c % CH;
-        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (row < S) {
-            kv = *reinterpret_cast<const u32x4 *>(kbase + (int64_t)row * ld + part * 8);
-            vv = *reinterpret_cast<const u32x4 *>(vbase + (int64_t)row * ld + part * 8);
+    {
+        constexpr int NIT = (256 * CH + 511) / 512;
+        u32x4 rk[NIT], rv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = tid + it * 512;
+            const int row = c / CH, part = c % CH;
+            rk[it] = rv[it] = (u32x4){0u, 0u, 0u, 0u};
+            if (c < S_pad * CH && row < S) {
+                rk[it] = *reinterpret_cast<const u32x4 *>(kbase + (int64_t)row * ld + part * 8);
+                rv[it] = *reinterpret_cast<const u32x4 *>(vbase + (int64_t)row * ld + part * 8);
+            }
         }
-        *reinterpret_cast<u32x4 *>(sK + row * KSTR + part * 16) = kv;
-        *reinterpret_cast<u32x4 *>(sV + row * KSTR + part * 16) = vv;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = tid + it * 512;
+            const int row = c / CH, part = c % CH;
+            if (c < S_pad * CH) {
+                *reinterpret_cast<u32x4 *>(sK + row * KSTR + part * 16) = rk[it];
+                *reinterpret_cast<u32x4 *>(sV + row * KSTR + part * 16) = rv[it];
+            }
+        }
     }
     __syncthreads();
     for (int k = tid; k < S_pad; k += 512) {
@@ -396,6 +409,170 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------
+// backward, fully resident (S_pad <= 224 at dh = 64): K, V, Q, dO of the (sequence, head) are all staged
+// once -- one burst of ~130 KB of loads per workgroup instead of a dependent load per query tile (the
+// streaming kernel above spends ~60 % of its wave-cycles parked on those, SQ_WAIT_ANY) -- then the 32-query
+// tiles run back to back out of LDS.
+// ------------------------------------------------------------------------------------------
+template <int DH>
+__global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
+                                                                const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o,
+                                                                int ld_do, const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
+                                                                int ld_dq, int S, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KSTR = DH * 2 + 16;
+    constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8;
+    const int nkt = (S + 31) >> 5, S_pad = nkt * 32;
+    const int TSTR = S_pad * 2 + 16;
+    char *sK = smem;
+    char *sV = sK + S_pad * KSTR;
+    char *sQa = sV + S_pad * KSTR;
+    char *sGa = sQa + S_pad * KSTR;
+    char *sDS = sGa + S_pad * KSTR;                       // [32][TSTR] bf16
+    float *sLseA = reinterpret_cast<float *>(sDS + 32 * TSTR);
+    float *sDeltaA = sLseA + S_pad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int li = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
+    const int64_t tok0 = (int64_t)b * S;
+    const bf16_t *qbase = qkv + tok0 * ld + hh * DH;
+    const bf16_t *kbase = qbase + dm;
+    const bf16_t *vbase = qbase + 2 * dm;
+    const bf16_t *gbase = d_o + tok0 * ld_do + hh * DH;
+    const bf16_t *obase = o + tok0 * ld_o + hh * DH;
+    const float *lbase = lse + ((int64_t)b * H + hh) * S;
+
+    {   // all global loads of the workgroup are issued before the first LDS write (one latency, not one per pass)
+        constexpr int NIT = (256 * CH + 511) / 512;
+        u32x4 rk[NIT], rv[NIT], rq[NIT], rg[NIT], ro[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = tid + it * 512;
+            const int row = c / CH, part = c % CH;
+            rk[it] = rv[it] = rq[it] = rg[it] = ro[it] = (u32x4){0u, 0u, 0u, 0u};
+            if (c < S_pad * CH && row < S) {
+                rk[it] = *reinterpret_cast<const u32x4 *>(kbase + (int64_t)row * ld + part * 8);
+                rv[it] = *reinterpret_cast<const u32x4 *>(vbase + (int64_t)row * ld + part * 8);
+                rq[it] = *reinterpret_cast<const u32x4 *>(qbase + (int64_t)row * ld + part * 8);
+                rg[it] = *reinterpret_cast<const u32x4 *>(gbase + (int64_t)row * ld_do + part * 8);
+                ro[it] = *reinterpret_cast<const u32x4 *>(obase + (int64_t)row * ld_o + part * 8);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = tid + it * 512;
+            const int row = c / CH, part = c % CH;
+            if (c < S_pad * CH) {          // wave-uniform: S_pad * CH is a multiple of 128
+                *reinterpret_cast<u32x4 *>(sK + row * KSTR + part * 16) = rk[it];
+                *reinterpret_cast<u32x4 *>(sV + row * KSTR + part * 16) = rv[it];
+                *reinterpret_cast<u32x4 *>(sQa + row * KSTR + part * 16) = rq[it];
+                *reinterpret_cast<u32x4 *>(sGa + row * KSTR + part * 16) = rg[it];
+                const bf16x8 g8 = __builtin_bit_cast(bf16x8, rg[it]), o8 = __builtin_bit_cast(bf16x8, ro[it]);
+                float pd = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pd += (float)g8[k] * (float)o8[k];
+                pd = group_sum<CH>(pd);     // CH consecutive lanes share a row
+                if (part == 0) sDeltaA[row] = pd;
+            }
+        }
+    }
+    for (int q = tid; q < S_pad; q += 512) sLseA[q] = (q < S) ? lbase[q] : INFINITY;
+
+    const int kt = wave;
+    const int key = kt * 32 + r;
+    const bool key_live = kt < nkt && key < S && !key_pad[tok0 + key];
+    const float madd = (kt >= nkt || key >= S) ? -INFINITY : (key_live ? 0.f : -1e9f);
+    const bool tile_live = __any(key_live);
+    f32x16 dk[NDT], dv[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { dk[dt][t] = 0.f; dv[dt][t] = 0.f; }
+    if (kt < nkt && !tile_live) {     // a fully padded key tile never changes: its dS columns are zero for every query tile
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            *reinterpret_cast<bf16_t *>(sDS + rowmap(t, hf) * TSTR + (kt * 32 + r) * 2) = (bf16_t)0.f;
+    }
+    __syncthreads();
+
+    for (int qt = 0; qt < nkt; ++qt) {
+        const int q0 = qt * 32;
+        const char *sQ = sQa + q0 * KSTR, *sdO = sGa + q0 * KSTR;
+        const float *sLse = sLseA + q0, *sDelta = sDeltaA + q0;
+        if (kt < nkt && tile_live) {
+            f32x16 sa, pa;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { sa[t] = 0.f; pa[t] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 fq = *reinterpret_cast<const bf16x8 *>(sQ + r * KSTR + ks * 32 + hf * 16);
+                const bf16x8 fk = *reinterpret_cast<const bf16x8 *>(sK + (kt * 32 + r) * KSTR + ks * 32 + hf * 16);
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq, fk, sa, 0, 0, 0);
+                const bf16x8 fg = *reinterpret_cast<const bf16x8 *>(sdO + r * KSTR + ks * 32 + hf * 16);
+                const bf16x8 fv = *reinterpret_cast<const bf16x8 *>(sV + (kt * 32 + r) * KSTR + ks * 32 + hf * 16);
+                pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg, fv, pa, 0, 0, 0);
+            }
+            float pv[16], dsv[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int q = rowmap(t, hf);
+                const float p = __expf(sa[t] * scale + madd - sLse[q]);
+                pv[t] = p;
+                dsv[t] = p * (pa[t] - sDelta[q]);
+                *reinterpret_cast<bf16_t *>(sDS + q * TSTR + (kt * 32 + r) * 2) = (bf16_t)dsv[t];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(pv + 8 * s2);
+                const bf16x8 df = pack8(dsv + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const int off = (16 * s2 + 4 * hf + (li >> 2)) * KSTR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
+                    const bf16x8 fgt = frag_tr(sdO + off, 8 * KSTR);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fgt, pf, dv[dt], 0, 0, 0);
+                    const bf16x8 fqt = frag_tr(sQ + off, 8 * KSTR);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fqt, df, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                  // dS tile complete
+        if (wave < 2 * (DH / 16)) {
+            const int qi = wave / (DH / 16), di = wave % (DH / 16);
+            f32x4 qa = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < nkt; ++ks) {
+                const bf16x8 fs = *reinterpret_cast<const bf16x8 *>(sDS + (qi * 16 + li) * TSTR + (ks * 32 + 8 * g) * 2);
+                const char *kb = sK + (ks * 32 + 8 * g + (li >> 2)) * KSTR + (di * 16 + 4 * (li & 3)) * 2;
+                const bf16x8 fk = frag_tr(kb, 4 * KSTR);
+                qa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fs, fk, qa, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int q = q0 + qi * 16 + 4 * g + t;
+                if (q < S) dqkv[(tok0 + q) * ld_dq + hh * DH + di * 16 + li] = (bf16_t)(qa[t] * scale);
+            }
+        }
+        __syncthreads();                                  // dS consumed
+    }
+    if (kt < nkt && key < S) {
+        bf16_t *krow = dqkv + (tok0 + key) * ld_dq + dm + hh * DH;
+        bf16_t *vrow = krow + dm;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                bf16x4 wk, wv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wk[j] = (bf16_t)(dk[dt][4 * tq + j] * scale);
+                    wv[j] = (bf16_t)dv[dt][4 * tq + j];
+                }
+                *reinterpret_cast<bf16x4 *>(krow + dt * 32 + 8 * tq + 4 * hf) = wk;
+                *reinterpret_cast<bf16x4 *>(vrow + dt * 32 + 8 * tq + 4 * hf) = wv;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 static bool mfma_shape_ok(int S, int dh) { return (dh == 32 || dh == 64) && S <= 32 * ATT_MAX_KT; }
 
 int b4c_attn_fwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, void *o, int ld_o, float *lse, int B, int S,
@@ -422,7 +599,18 @@ int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const
     const int S_pad = (S + 31) / 32 * 32;
     const size_t kstr = dh * 2 + 16, tstr = S_pad * 2 + 16;
     const size_t shm = 2 * S_pad * kstr + 2 * (2 * 32 * kstr + 256) + 32 * tstr;
+    const size_t shm_res = 4 * S_pad * kstr + 32 * tstr + 2 * (size_t)S_pad * 4;
     const float scale = 1.0f / sqrtf((float)dh);
+    if (shm_res <= 160 * 1024) {
+        if (dh == 64) {
+            allow_lds_attn(attn_bwd_resident_kernel<64>, shm_res);
+            attn_bwd_resident_kernel<64><<<B * H, 512, shm_res, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale);
+        } else {
+            allow_lds_attn(attn_bwd_resident_kernel<32>, shm_res);
+            attn_bwd_resident_kernel<32><<<B * H, 512, shm_res, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale);
+        }
+        return b4c_check_launch("attn_bwd_resident");
+    }
     if (dh == 64) {
         allow_lds_attn(attn_bwd_mfma_kernel<64>, shm);
         attn_bwd_mfma_kernel<64><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale);

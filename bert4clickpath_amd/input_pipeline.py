@@ -95,3 +95,65 @@ def synthetic_cloze_batch(B, S, V, seed, zipf_a=1.1, min_len=20, full_length=Fal
     return {'ids': ids, 'flat_idx': np.concatenate(flat).astype(np.int32) if flat else np.zeros(0, np.int32),
             'labels': np.concatenate(lab).astype(np.int32) if lab else np.zeros(0, np.int32),
             'labels_padded': labels_padded, 'extra': extra, 'lens': lens}
+
+
+class BeautyCloze:
+    """Amazon-Beauty Cloze batches from data/beauty_sequences.npz (built by data/make_beauty_sequences.py with
+    the reference's data-prep rules).  Works on integer item indices: input id = 10 + index, label = index.
+    TRAIN: drop the last item, mask n_masked random positions (sorted); EVAL: mask the last item of the full
+    sequence (input_pipeline.py:93-133).  One seeded permutation per epoch stands in for shuffle(20000)+repeat."""
+
+    def __init__(self, path):
+        z = np.load(path, allow_pickle=False)
+        self.items, self.offsets = z['items'].astype(np.int64), z['offsets']
+        self.n_seq = len(self.offsets) - 1
+        self.V = int(z['vocab'].shape[0])
+
+    def seq(self, i):
+        return self.items[self.offsets[i]:self.offsets[i + 1]]
+
+    def _batch(self, rows, labels):
+        B = len(rows)
+        L = max(len(r) for r in rows)
+        S = L + 3
+        ids = np.zeros((B, S), np.int64)
+        ids[:, 0], ids[:, 1], ids[:, S - 1] = CLS, SEP, SEP
+        M = max((len(l) for l in labels), default=0)
+        lp = np.full((B, M), LABEL_PAD, np.float32)
+        for b, (r, l) in enumerate(zip(rows, labels)):
+            ids[b, 2:2 + len(r)] = r
+            lp[b, :len(l)] = l
+        flat = np.flatnonzero(ids.reshape(-1) == MASK_ID).astype(np.int32)
+        lab = lp[lp != LABEL_PAD].astype(np.int32)
+        return {'ids': ids, 'flat_idx': flat, 'labels': lab, 'labels_padded': lp}
+
+    def train_batches(self, batch_size, seed, steps):
+        rng = np.random.default_rng(seed)
+        done = 0
+        while done < steps:
+            order = rng.permutation(self.n_seq)
+            for s in range(0, self.n_seq - batch_size + 1, batch_size):
+                rows, labels = [], []
+                for i in order[s:s + batch_size]:
+                    it = self.seq(i)[:-1]
+                    pos = random_choice(len(it), n_masked(len(it)), rng)
+                    labels.append(it[pos].astype(np.float32))
+                    row = it + 10
+                    row[pos] = MASK_ID
+                    rows.append(row)
+                yield self._batch(rows, labels)
+                done += 1
+                if done >= steps:
+                    return
+
+    def eval_batches(self, batch_size, limit=None):
+        n = self.n_seq if limit is None else min(limit, self.n_seq)
+        for s in range(0, n, batch_size):
+            rows, labels = [], []
+            for i in range(s, min(s + batch_size, n)):
+                it = self.seq(i)
+                labels.append(it[-1:].astype(np.float32))
+                row = it + 10
+                row[-1] = MASK_ID
+                rows.append(row)
+            yield self._batch(rows, labels)
