@@ -18,6 +18,13 @@ class B4CError(RuntimeError):
     pass
 
 
+class PackDesc(ctypes.Structure):
+    """b4c_pack_desc of include/b4c.h."""
+    _fields_ = [('src', ctypes.c_void_p), ('bias_src', ctypes.c_void_p), ('wt', ctypes.c_void_p), ('wc', ctypes.c_void_p),
+                ('bias_dst', ctypes.c_void_p), ('K', ctypes.c_int32), ('N', ctypes.c_int32), ('ld_t', ctypes.c_int32),
+                ('ld_c', ctypes.c_int32), ('col_off', ctypes.c_int32), ('_pad', ctypes.c_int32)]
+
+
 def declared_symbols(header_path=HEADER_PATH):
     """Names of every function include/b4c.h declares (used by the symbol-export test)."""
     with open(header_path) as f:
@@ -49,6 +56,8 @@ def lib():
             'b4c_pack_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, vp]),
             'b4c_gemm_nt': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
             'b4c_gemm_tn': (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+            'b4c_gemm_tn_seg': (i32, [vp, i32, vp, i32, i32, pp, pp, i32, i32, i32, i32, vp]),
+            'b4c_pack_weights_batched': (i32, [vp, i32, i32, i32, vp]),
             'b4c_attn_fwd': (i32, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
             'b4c_attn_bwd': (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
             'b4c_add_dropout_layernorm_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, u64, i32, vp]),

@@ -314,6 +314,23 @@ extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void
 // each lane keeps its feature(s) for 8 (bf16) / 4 (fp32) consecutive tokens and writes them as one
 // 16-B token-contiguous LDS chunk.
 // ------------------------------------------------------------------------------------------
+// dW / db destinations of gemm_tn: N may be cut into up to 4 equal column segments, each with its own
+// fp32 matrix [K][segw] (the fused Q|K|V projection writes straight into the three gradient tensors).
+struct TNOut {
+    float *dW[4];
+    float *db[4];
+    int segw;   // columns per segment (== N when there is one)
+    int ld;     // row pitch of every dW segment
+};
+__device__ __forceinline__ void tn_add_w(const TNOut &o, int row, int col, float v) {
+    const int seg = col / o.segw;
+    atomicAdd(o.dW[seg] + (int64_t)row * o.ld + (col - seg * o.segw), v);
+}
+__device__ __forceinline__ void tn_add_b(const TNOut &o, int col, float v) {
+    const int seg = col / o.segw;
+    atomicAdd(o.db[seg] + (col - seg * o.segw), v);
+}
+
 template <typename T> struct TNStage;
 
 template <> struct TNStage<bf16_t> {
@@ -395,7 +412,7 @@ template <> struct TNStage<float> {
 
 template <typename T>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(const T *__restrict__ A, int lda, const T *__restrict__ G, int ldg,
-                                                      float *__restrict__ dW, int ldw, float *__restrict__ db, int64_t M,
+                                                      TNOut out, int64_t M,
                                                       int K, int N, int64_t chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -411,7 +428,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T *__restrict__ A, i
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
     float bs0 = 0.f, bs1 = 0.f;
-    const bool want_db = (db != nullptr) && blockIdx.x == 0;
+    const bool want_db = (out.db[0] != nullptr) && blockIdx.x == 0;
 
     constexpr int TOK = TNStage<T>::TOK;
     const int nsteps = (int)((m_end - m_begin + TOK - 1) / TOK);
@@ -447,7 +464,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T *__restrict__ A, i
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int row = k0 + wm * 64 + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
-                if (row < K && col < N) atomicAdd(dW + (int64_t)row * ldw + col, acc[i][j][t]);
+                if (row < K && col < N) tn_add_w(out, row, col, acc[i][j][t]);
             }
         }
     if (want_db) {
@@ -457,7 +474,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T *__restrict__ A, i
         red[wave * 128 + TNStage<T>::feat1(lane)] = bs1;
         __syncthreads();
         if (tid < 128 && n0 + tid < N)
-            atomicAdd(db + n0 + tid, red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid]);
+            tn_add_b(out, n0 + tid, red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid]);
     }
 }
 
@@ -496,7 +513,7 @@ __device__ __forceinline__ void tn_store16(char *s, int tid, const u32x4 (&reg)[
 }
 
 __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ G, int ldg,
-                                                           float *__restrict__ dW, int ldw, float *__restrict__ db, int64_t M,
+                                                           TNOut out, int64_t M,
                                                            int K, int N, int64_t chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -514,7 +531,7 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restr
     float bs[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bs[k] = 0.f;
-    const bool want_db = (db != nullptr) && blockIdx.x == 0;
+    const bool want_db = (out.db[0] != nullptr) && blockIdx.x == 0;
     const int nsteps = (int)((m_end - m_begin + 63) / 64);
     char *sA = smem, *sG = smem + TN_TILE_BYTES;
     u32x4 ra[4], rg[4];
@@ -569,7 +586,7 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restr
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int row = k0 + wm * 64 + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
-                if (row < K && col < N) atomicAdd(dW + (int64_t)row * ldw + col, acc[i][j][t]);
+                if (row < K && col < N) tn_add_w(out, row, col, acc[i][j][t]);
             }
         }
     if (want_db) {
@@ -579,15 +596,15 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restr
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicAdd(&red[(tid & 15) * 8 + k], bs[k]);
         __syncthreads();
-        if (tid < 128 && n0 + tid < N) atomicAdd(db + n0 + tid, red[tid]);
+        if (tid < 128 && n0 + tid < N) tn_add_b(out, n0 + tid, red[tid]);
     }
 }
 
-extern "C" int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float *dW, int ldw, float *db, int M, int K,
-                           int N, int dtype, void *stream) {
-    B4C_REQUIRE(A && G && dW && M > 0 && K > 0 && N > 0, "gemm_tn: null pointer / empty");
+static int gemm_tn_launch(const void *A, int lda, const void *G, int ldg, const TNOut &out, int M, int K, int N, int dtype,
+                          void *stream) {
+    B4C_REQUIRE(A && G && out.dW[0] && M > 0 && K > 0 && N > 0, "gemm_tn: null pointer / empty");
     B4C_REQUIRE(dtype == B4C_F32 || dtype == B4C_BF16, "gemm_tn: dtype %d", dtype);
-    B4C_REQUIRE(lda >= K && ldg >= N && ldw >= N, "gemm_tn: pitches too small (lda=%d K=%d ldg=%d N=%d ldw=%d)", lda, K, ldg, N, ldw);
+    B4C_REQUIRE(lda >= K && ldg >= N, "gemm_tn: pitches too small (lda=%d K=%d ldg=%d N=%d)", lda, K, ldg, N);
     B4C_REQUIRE(lda % 2 == 0 && ldg % 2 == 0, "gemm_tn: operand pitches must be even");
     B4C_REQUIRE((((uintptr_t)A | (uintptr_t)G) & 3) == 0, "gemm_tn: operands must be 4-byte aligned");
     const int tk = (K + TILE - 1) / TILE, tn = (N + TILE - 1) / TILE;
@@ -608,10 +625,29 @@ extern "C" int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float
     const size_t shm = STAGE_BYTES;
     const bool vec16 = (lda % 8 == 0) && (ldg % 8 == 0) && ((((uintptr_t)A | (uintptr_t)G) & 15) == 0);
     if (dtype == B4C_F32)
-        gemm_tn_kernel<float><<<grid, 256, shm, st>>>((const float *)A, lda, (const float *)G, ldg, dW, ldw, db, M, K, N, chunk);
+        gemm_tn_kernel<float><<<grid, 256, shm, st>>>((const float *)A, lda, (const float *)G, ldg, out, M, K, N, chunk);
     else if (vec16)
-        gemm_tn_bf16_kernel<<<grid, 256, 2 * TN_TILE_BYTES, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, dW, ldw, db, M, K, N, chunk);
+        gemm_tn_bf16_kernel<<<grid, 256, 2 * TN_TILE_BYTES, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, out, M, K, N, chunk);
     else
-        gemm_tn_kernel<bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, dW, ldw, db, M, K, N, chunk);
+        gemm_tn_kernel<bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, out, M, K, N, chunk);
     return b4c_check_launch("gemm_tn");
+}
+
+extern "C" int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float *dW, int ldw, float *db, int M, int K,
+                           int N, int dtype, void *stream) {
+    B4C_REQUIRE(ldw >= N, "gemm_tn: ldw %d < N %d", ldw, N);
+    TNOut out = {{dW, nullptr, nullptr, nullptr}, {db, nullptr, nullptr, nullptr}, N, ldw};
+    return gemm_tn_launch(A, lda, G, ldg, out, M, K, N, dtype, stream);
+}
+
+extern "C" int b4c_gemm_tn_seg(const void *A, int lda, const void *G, int ldg, int n_seg, float *const *h_dW,
+                               float *const *h_db, int seg_width, int M, int K, int dtype, void *stream) {
+    B4C_REQUIRE(n_seg >= 1 && n_seg <= 4 && seg_width > 0 && h_dW, "gemm_tn_seg: n_seg %d / seg_width %d", n_seg, seg_width);
+    TNOut out = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}, seg_width, seg_width};
+    for (int i = 0; i < n_seg; ++i) {
+        B4C_REQUIRE(h_dW[i] && (!h_db || h_db[i] || !h_db[0]), "gemm_tn_seg: null segment pointer %d", i);
+        out.dW[i] = h_dW[i];
+        out.db[i] = h_db ? h_db[i] : nullptr;
+    }
+    return gemm_tn_launch(A, lda, G, ldg, out, M, K, n_seg * seg_width, dtype, stream);
 }

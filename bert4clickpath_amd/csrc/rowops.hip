@@ -589,6 +589,42 @@ extern "C" int b4c_pack_weight(const float *src, int K, int N, void *dst, int ld
     return b4c_check_launch("pack_weight");
 }
 
+// every dense layer's compute copies in ONE launch: grid = (max tiles, descriptors)
+template <typename T>
+__global__ void __launch_bounds__(256) pack_batched_kernel(const b4c_pack_desc *__restrict__ desc) {
+    __shared__ float tile[32][33];
+    const b4c_pack_desc d = desc[blockIdx.y];
+    const int tiles_n = (d.N + 31) / 32, tiles_k = (d.K + 31) / 32;
+    if ((int)blockIdx.x >= tiles_n * tiles_k) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int k0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+    T *wt = reinterpret_cast<T *>(d.wt), *wc = reinterpret_cast<T *>(d.wc);
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        const float v = (k < d.K && n < d.N) ? d.src[(int64_t)k * d.N + n] : 0.f;
+        tile[r][tx] = v;
+        if (wc && k < d.K && n < d.N) wc[(int64_t)k * d.ld_c + d.col_off + n] = (T)v;
+    }
+    __syncthreads();
+    if (wt)
+        for (int r = ty; r < 32; r += 8) {
+            const int n = n0 + r, k = k0 + tx;
+            if (n < d.N && k < d.K) wt[(int64_t)(d.col_off + n) * d.ld_t + k] = (T)tile[tx][r];
+        }
+    if (blockIdx.x == 0 && d.bias_src && d.bias_dst)
+        for (int n = threadIdx.x; n < d.N; n += 256) d.bias_dst[d.col_off + n] = d.bias_src[n];
+}
+
+extern "C" int b4c_pack_weights_batched(const b4c_pack_desc *d_desc, int n_desc, int max_tiles, int dtype, void *stream) {
+    B4C_REQUIRE(d_desc && n_desc > 0 && max_tiles > 0 && n_desc <= 65535, "pack_weights_batched: bad argument");
+    dim3 grid(max_tiles, n_desc);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32) pack_batched_kernel<float><<<grid, 256, 0, st>>>(d_desc);
+    else if (dtype == B4C_BF16) pack_batched_kernel<bf16_t><<<grid, 256, 0, st>>>(d_desc);
+    else B4C_REQUIRE(false, "pack_weights_batched: dtype %d", dtype);
+    return b4c_check_launch("pack_weights_batched");
+}
+
 // ------------------------------------------------------------------------------------------
 // Adam over a flat fp32 arena
 // ------------------------------------------------------------------------------------------

@@ -115,10 +115,10 @@ def embed_concat_pe_fwd(ids_list, tables, pe, scale, rate, seed, dtype):
     return out, key_pad
 
 
-def embed_concat_pe_bwd(ids_list, tables, dout, scale, rate, seed):
+def embed_concat_pe_bwd(ids_list, tables, dout, scale, rate, seed, into=None):
     B, S = ids_list[0].shape
     d = dout.shape[-1]
-    dtabs = [torch.zeros_like(t) for t in tables]
+    dtabs = into if into is not None else [torch.zeros_like(t) for t in tables]
     n, ids_arr, tab_arr, dims, rows = _feature_arrays(ids_list, dtabs)
     L.check(L.lib().b4c_embed_concat_pe_bwd(n, ids_arr, tab_arr, dims, rows, scale, _p(dout), d, B, S, d, rate, seed,
                                             dt_code(dout.dtype), _st()), 'embed_concat_pe_bwd')
@@ -139,9 +139,25 @@ def gemm_nt(a, bt, n, bias=None, act=L.ACT_NONE, gate=None, residual=None, out_d
     return out
 
 
-def gemm_tn(a, g, K, N, want_bias=True):
-    """dW[K,N] = a[:, :K]^T @ g[:, :N] (fp32), db[N] = colsum(g)"""
+def gemm_tn(a, g, K, N, want_bias=True, into=None):
+    """dW[K,N] (+)= a[:, :K]^T @ g[:, :N] (fp32), db[N] (+)= colsum(g).
+    into = (list of dW_i [K, N/len], list of db_i [N/len]): accumulate into existing fp32 tensors (column
+    segments of equal width) instead of allocating zeros; returns (None, None) then."""
     M = a.shape[0]
+    if into is not None:
+        dWs, dbs = into
+        if M == 0:
+            return None, None
+        n = len(dWs)
+        if n == 1:
+            L.check(L.lib().b4c_gemm_tn(_p(a), a.stride(0), _p(g), g.stride(0), _p(dWs[0]), N, _p(dbs[0]), M, K, N,
+                                        dt_code(a.dtype), _st()), 'gemm_tn')
+        else:
+            wa = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dWs])
+            ba = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dbs])
+            L.check(L.lib().b4c_gemm_tn_seg(_p(a), a.stride(0), _p(g), g.stride(0), n, wa, ba, N // n, M, K,
+                                            dt_code(a.dtype), _st()), 'gemm_tn_seg')
+        return None, None
     dW = torch.zeros(K, N, dtype=torch.float32, device=a.device)
     db = torch.zeros(N, dtype=torch.float32, device=a.device) if want_bias else None
     if M == 0:
@@ -149,6 +165,33 @@ def gemm_tn(a, g, K, N, want_bias=True):
     L.check(L.lib().b4c_gemm_tn(_p(a), a.stride(0), _p(g), g.stride(0), _p(dW), N, _p(db), M, K, N,
                                 dt_code(a.dtype), _st()), 'gemm_tn')
     return dW, db
+
+
+# ---- in-place gradient accumulation (arena mode, optim.FlatArena): weight-gradient kernels add with float
+# atomics anyway, so they add straight into param.grad and autograd receives None for those inputs.
+inplace_grads = False
+_grad_ready_cb = None       # parallel.GradReducer: called with each parameter whose gradient has just been produced
+
+
+def set_grad_ready_callback(cb):
+    global _grad_ready_cb
+    _grad_ready_cb = cb
+
+
+def _inplace_ok(*params):
+    if not inplace_grads:
+        return False
+    for p in params:
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or g.device != p.device:
+            return False
+    return True
+
+
+def _ready(*params):
+    if _grad_ready_cb is not None:
+        for p in params:
+            _grad_ready_cb(p)
 
 
 def attn_fwd(qkv, key_pad, B, S, H, dh):
@@ -179,12 +222,15 @@ def add_dropout_layernorm_fwd(x, y, gamma, beta, rate, seed, save=True):
     return z, out, stats
 
 
-def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed):
+def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed, into=None):
     rows, d = z.shape
     dz = torch.empty_like(z)
     dy = torch.empty_like(z) if rate > 0 else None
-    dgamma = torch.zeros(d, dtype=torch.float32, device=z.device)
-    dbeta = torch.zeros(d, dtype=torch.float32, device=z.device)
+    if into is not None:
+        dgamma, dbeta = into
+    else:
+        dgamma = torch.zeros(d, dtype=torch.float32, device=z.device)
+        dbeta = torch.zeros(d, dtype=torch.float32, device=z.device)
     L.check(L.lib().b4c_add_dropout_layernorm_bwd(_p(dout), _p(z), _p(stats), _p(gamma), _p(dz), _p(dy), _p(dgamma),
                                                   _p(dbeta), rows, d, rate, seed, dt_code(z.dtype), _st()),
             'add_dropout_layernorm_bwd')
@@ -298,55 +344,53 @@ def keep_mask(seed, n, rate):
 # --------------------------------------------------------------------------------------
 # packed compute copies of (fused) dense layers
 # --------------------------------------------------------------------------------------
+_pack_registry = []      # weak references to every PackedLinear: stale ones are refreshed together, in one launch
+
+
 class PackedLinear:
     """Compute-dtype copies of one dense layer whose Keras kernels [K, N_i] are fused along N:
     ``wt`` [Np][Kp] (forward operand, K-contiguous) and ``wc`` [Kp][Np] (backward-dX operand),
-    ``bias`` fp32 [Np].  Zero-padded to multiples of 8; refreshed when the masters change."""
+    ``bias`` fp32 [Np].  Zero-padded to multiples of 8.  When the masters change (optimizer step,
+    load_state_dict, .to()) ALL stale layers are re-packed by one b4c_pack_weights_batched launch."""
 
     def __init__(self, kernels, biases):
+        import weakref
         self.kernels, self.biases = list(kernels), list(biases)
         self.K = int(self.kernels[0].shape[0])
         self.Ns = [int(k.shape[1]) for k in self.kernels]
         self.N = sum(self.Ns)
         self.Np = rup8(self.N)
         self._cache = {}
+        _pack_registry.append(weakref.ref(self))
 
     def _key(self):
         return (_weights_epoch,) + tuple(t._version for t in self.kernels + self.biases) + \
             tuple(t.data_ptr() for t in self.kernels + self.biases)
 
+    def _descs(self, ent, Kp):
+        out, off = [], 0
+        for k, b, n in zip(self.kernels, self.biases, self.Ns):
+            kk = k.detach()
+            if kk.dtype != torch.float32 or not kk.is_contiguous():
+                raise B4CError('dense kernels must be contiguous float32 [in, out]')
+            out.append(L.PackDesc(kk.data_ptr(), b.detach().data_ptr(), ent['wt'].data_ptr(),
+                                  ent['wc'].data_ptr() if ent['wc'] is not None else None, ent['bias'].data_ptr(),
+                                  self.K, n, Kp, self.Np, off, 0))
+            off += n
+        return out
+
     def get(self, dtype, Kp, need_wc):
         dev = self.kernels[0].device
         ent = self._cache.get((dtype, Kp, dev))
-        key = self._key()
         if ent is None:
-            ent = {'key': None, 'wc_key': None,
-                   'wt': torch.zeros(self.Np, Kp, dtype=dtype, device=dev),
-                   'wc': None,
+            ent = {'key': None, 'wt': torch.zeros(self.Np, Kp, dtype=dtype, device=dev), 'wc': None,
                    'bias': torch.zeros(self.Np, dtype=torch.float32, device=dev)}
             self._cache[(dtype, Kp, dev)] = ent
-        lib, st, code = L.lib(), _st(), dt_code(dtype)
-        if ent['key'] != key:
-            off = 0
-            with torch.no_grad():
-                for k, b, n in zip(self.kernels, self.biases, self.Ns):
-                    kk = k.detach()
-                    if kk.dtype != torch.float32 or not kk.is_contiguous():
-                        raise B4CError('dense kernels must be contiguous float32 [in, out]')
-                    L.check(lib.b4c_pack_weight(_p(kk), self.K, n, ent['wt'].data_ptr() + off * Kp * ent['wt'].element_size(),
-                                                Kp, 1, code, st), 'pack_weight')
-                    ent['bias'][off:off + n].copy_(b.detach())
-                    off += n
-            ent['key'] = key
-        if need_wc and ent['wc_key'] != key:
-            if ent['wc'] is None:
-                ent['wc'] = torch.zeros(Kp, self.Np, dtype=dtype, device=dev)
-            off = 0
-            for k, n in zip(self.kernels, self.Ns):
-                L.check(lib.b4c_pack_weight(_p(k.detach()), self.K, n, ent['wc'].data_ptr() + off * ent['wc'].element_size(),
-                                            self.Np, 0, code, st), 'pack_weight')
-                off += n
-            ent['wc_key'] = key
+        if need_wc and ent['wc'] is None:
+            ent['wc'] = torch.zeros(Kp, self.Np, dtype=dtype, device=dev)
+            ent['key'] = None
+        if ent['key'] != self._key():
+            repack_stale(dtype, dev)
         return ent['wt'], ent['wc'], ent['bias']
 
     def split_grads(self, dW, db):
@@ -357,6 +401,45 @@ class PackedLinear:
             gb.append(db[off:off + n].contiguous() if len(self.Ns) > 1 else db)
             off += n
         return gk, gb
+
+
+_desc_cache = {}
+
+
+def repack_stale(dtype, dev):
+    """One launch refreshes every allocated compute copy (this dtype / device) whose masters changed."""
+    descs, ents, max_tiles = [], [], 1
+    alive = []
+    for ref in _pack_registry:
+        pk = ref()
+        if pk is None:
+            continue
+        alive.append(ref)
+        key = None
+        for (dt, Kp, dv), ent in pk._cache.items():
+            if dt != dtype or dv != dev:
+                continue
+            key = key or pk._key()
+            if ent['key'] == key:
+                continue
+            descs += pk._descs(ent, Kp)
+            ents.append((ent, key))
+            max_tiles = max(max_tiles, max(((pk.K + 31) // 32) * ((n + 31) // 32) for n in pk.Ns))
+    _pack_registry[:] = alive
+    if not descs:
+        return
+    sig = tuple((d.src, d.wt, d.wc, d.bias_src) for d in descs)
+    cached = _desc_cache.get((dtype, dev))
+    if cached is None or cached[0] != sig:
+        arr = (L.PackDesc * len(descs))(*descs)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        cached = (sig, host.to(dev))
+        _desc_cache[(dtype, dev)] = cached
+    with torch.no_grad():
+        L.check(L.lib().b4c_pack_weights_batched(cached[1].data_ptr(), len(descs), max_tiles, dt_code(dtype), _st()),
+                'pack_weights_batched')
+    for ent, key in ents:
+        ent['key'] = key
 
 
 def _as2d(x):
@@ -382,6 +465,10 @@ class EmbedFn(torch.autograd.Function):
     def backward(ctx, dout, _):
         saved = ctx.saved_tensors
         ids, tables = list(saved[:ctx.n]), list(saved[ctx.n:])
+        if _inplace_ok(*tables):
+            embed_concat_pe_bwd(ids, tables, dout.contiguous(), ctx.scale, ctx.rate, ctx.seed, into=[t.grad for t in tables])
+            _ready(*tables)
+            return (None,) * (6 + 2 * ctx.n)
         dtabs = embed_concat_pe_bwd(ids, tables, dout.contiguous(), ctx.scale, ctx.rate, ctx.seed)
         return (None,) * 6 + (None,) * ctx.n + tuple(dtabs)
 
@@ -406,6 +493,7 @@ class AttnBlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, key_pad, qkv, o, lse, z, stats, gamma)
             ctx.pk = (pk_qkv, pk_o)
             ctx.dims = (B, S, H, dh, rate, seed)
+            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta)
         return out
 
     @staticmethod
@@ -413,17 +501,24 @@ class AttnBlockFn(torch.autograd.Function):
         x, key_pad, qkv, o, lse, z, stats, gamma = ctx.saved_tensors
         pk_qkv, pk_o = ctx.pk
         B, S, H, dh, rate, seed = ctx.dims
+        wq, bq, wk, bk, wv, bv, wo, bo, gam, bet = ctx.params
         d = H * dh
-        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed)
+        inplace = _inplace_ok(*ctx.params)
+        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
+                                                          into=(gam.grad, bet.grad) if inplace else None)
         _, wc_o, _ = pk_o.get(x.dtype, d, True)
         _, wc_qkv, _ = pk_qkv.get(x.dtype, d, True)
-        dWo, dbo = gemm_tn(o, dy, d, d)
+        dWo, dbo = gemm_tn(o, dy, d, d, into=([wo.grad], [bo.grad]) if inplace else None)
         d_o = gemm_nt(dy, wc_o, d)
         with _timed('attn_bwd'):
             dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh)
         with _timed('qkv_dw'):
-            dWqkv, dbqkv = gemm_tn(x, dqkv, d, 3 * d)
+            dWqkv, dbqkv = gemm_tn(x, dqkv, d, 3 * d,
+                                   into=([wq.grad, wk.grad, wv.grad], [bq.grad, bk.grad, bv.grad]) if inplace else None)
         dx = gemm_nt(dqkv, wc_qkv, d, residual=dz)
+        if inplace:
+            _ready(*ctx.params)
+            return (dx,) + (None,) * 19
         (gq, gk, gv), (gbq, gbk, gbv) = pk_qkv.split_grads(dWqkv, dbqkv)
         return (dx, None, gq, gbq, gk, gbk, gv, gbv, dWo, dbo, dgamma, dbeta) + (None,) * 8
 
@@ -445,6 +540,7 @@ class FFNBlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, h, z, stats, gamma)
             ctx.pk = (pk1, pk2)
             ctx.dims = (rate, seed)
+            ctx.params = (w1, b1, w2, b2, gamma, beta)
         return out
 
     @staticmethod
@@ -452,14 +548,20 @@ class FFNBlockFn(torch.autograd.Function):
         x, h, z, stats, gamma = ctx.saved_tensors
         pk1, pk2 = ctx.pk
         rate, seed = ctx.dims
+        w1, b1, w2, b2, gam, bet = ctx.params
         d, Fp = x.shape[1], h.shape[1]
-        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed)
+        inplace = _inplace_ok(*ctx.params)
+        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
+                                                          into=(gam.grad, bet.grad) if inplace else None)
         _, wc1, _ = pk1.get(x.dtype, d, True)
         _, wc2, _ = pk2.get(x.dtype, Fp, True)
-        dW2, db2 = gemm_tn(h, dy, pk2.K, d)
+        dW2, db2 = gemm_tn(h, dy, pk2.K, d, into=([w2.grad], [b2.grad]) if inplace else None)
         dh = gemm_nt(dy, wc2, Fp, gate=h)
-        dW1, db1 = gemm_tn(x, dh, d, pk1.N)
+        dW1, db1 = gemm_tn(x, dh, d, pk1.N, into=([w1.grad], [b1.grad]) if inplace else None)
         dx = gemm_nt(dh, wc1, d, residual=dz)
+        if inplace:
+            _ready(*ctx.params)
+            return (dx,) + (None,) * 11
         return (dx, dW1, db1, dW2, db2, dgamma, dbeta) + (None,) * 5
 
 
@@ -481,6 +583,7 @@ class MLPFn(torch.autograd.Function):
         if training:
             ctx.save_for_backward(*acts[:-1])
             ctx.packs = packs
+            ctx.params = params
         return acts[-1]
 
     @staticmethod
@@ -493,13 +596,17 @@ class MLPFn(torch.autograd.Function):
         g = g.contiguous()
         grads = [None] * (2 * len(packs))
         dx = None
+        inplace = _inplace_ok(*ctx.params)
         for i in range(len(packs) - 1, -1, -1):
             a = acts[i]
             pk = packs[i]
             _, wc, _ = pk.get(a.dtype, a.shape[1], True)
             last = i == len(packs) - 1
+            kern, bias = ctx.params[2 * i], ctx.params[2 * i + 1]
             with _timed('vocab_proj_dw' if last else 'head_mlp_dw'):
-                dW, db = gemm_tn(a, g, pk.K, pk.N)
+                dW, db = gemm_tn(a, g, pk.K, pk.N, into=([kern.grad], [bias.grad]) if inplace else None)
+            if inplace:
+                _ready(kern, bias)
             grads[2 * i], grads[2 * i + 1] = dW, db
             with _timed('vocab_proj_dx' if last else 'head_mlp_dx'):
                 g = gemm_nt(g, wc, a.shape[1], gate=a if i > 0 else None)

@@ -36,6 +36,8 @@ class FlatArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        # weight-gradient kernels may now add straight into these views (ops.inplace_grads)
+        ops.inplace_grads = True
 
     def slice_of(self, p):
         i = next(k for k, q in enumerate(self.params) if q is p)

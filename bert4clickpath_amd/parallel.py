@@ -54,8 +54,14 @@ class GradReducer:
         self._sizes = [sum(1 for b in self._bucket_of if b == i) for i in range(len(self.buckets))]
         self.overlap = overlap and self.world > 1
         if self.overlap:
+            # gradients reach the arena either through autograd (hook) or straight from the HIP kernels
+            # (ops.inplace_grads -> ops callback); both count a parameter exactly once per backward
+            from . import ops
+            hooks = {}
             for p, b in zip(arena.params, self._bucket_of):
-                p.register_post_accumulate_grad_hook(self._make_hook(b))
+                hooks[id(p)] = self._make_hook(b)
+                p.register_post_accumulate_grad_hook(hooks[id(p)])
+            ops.set_grad_ready_callback(lambda p: hooks[id(p)](p) if id(p) in hooks else None)
 
     @property
     def grad_mul(self):

@@ -77,6 +77,22 @@ int b4c_embed_concat_pe_bwd(int n_feat, const int64_t *const *h_ids, float *cons
 int b4c_pack_weight(const float *src, int K, int N, void *dst, int ld_dst, int transpose, int dtype,
                     void *stream);
 
+/* All layers' compute copies in one launch.  One descriptor per Keras kernel; fused layers (Q|K|V) use
+ * several descriptors writing at different col_off of the same wt / wc / bias buffers.
+ *   wt[(col_off + n)][k]  (pitch ld_t)   = src[k][n]      forward operand, may be NULL
+ *   wc[k][col_off + n]    (pitch ld_c)   = src[k][n]      backward-dX operand, may be NULL
+ *   bias_dst[col_off + n]                = bias_src[n]    fp32, may be NULL
+ * d_desc is a DEVICE array; max_tiles = max over descriptors of ceil(K/32)*ceil(N/32). */
+typedef struct {
+    const float *src;
+    const float *bias_src;
+    void *wt;
+    void *wc;
+    float *bias_dst;
+    int32_t K, N, ld_t, ld_c, col_off, _pad;
+} b4c_pack_desc;
+int b4c_pack_weights_batched(const b4c_pack_desc *d_desc, int n_desc, int max_tiles, int dtype, void *stream);
+
 /* C[M][N] = epilogue( A[M][K] . Bt[N][K]^T )     (both operands K-contiguous)
  *   v = acc + bias[n]            (bias fp32 or NULL)
  *   v = relu(v)                  if act == B4C_ACT_RELU
@@ -92,6 +108,11 @@ int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void *C, int ld
  * the caller zeroes dW / db; db may be NULL).  Reduction runs over the M (token) axis. */
 int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float *dW, int ldw, float *db, int M, int K,
                 int N, int dtype, void *stream);
+/* same with N = n_seg * seg_width cut into n_seg (<= 4) column segments, each accumulated into its own
+ * dW_i [K][seg_width] / db_i [seg_width] (HOST arrays of device pointers): the fused Q|K|V projection
+ * adds straight into the three gradient tensors. */
+int b4c_gemm_tn_seg(const void *A, int lda, const void *G, int ldg, int n_seg, float *const *h_dW,
+                    float *const *h_db, int seg_width, int M, int K, int dtype, void *stream);
 
 /* ---- R8: attention -------------------------------------------------------------------
  * replaces MultiHeadAttention.split_heads + scaled_dot_product_attention + merge
