@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
                 }
             }
         }
-        __syncthreads();                                  // dS tile complete
+        B4C_LDS_BARRIER();                                // dS tile complete (LDS only: dQ stores of the previous tile keep draining)
         if (wave < 2 * (DH / 16)) {
             const int qi = wave / (DH / 16), di = wave % (DH / 16);
             f32x4 qa = {0.f, 0.f, 0.f, 0.f};
@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
                 if (q < S) dqkv[(tok0 + q) * ld_dq + hh * DH + di * 16 + li] = (bf16_t)(qa[t] * scale);
             }
         }
-        __syncthreads();                                  // dS consumed
+        B4C_LDS_BARRIER();                                // dS consumed
     }
     if (kt < nkt && key < S) {
         bf16_t *krow = dqkv + (tok0 + key) * ld_dq + dm + hh * DH;

@@ -13,6 +13,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define B4C_WAVE 64
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also makes every wave wait for ALL of its
+// outstanding global loads and stores (s_waitcnt vmcnt(0)): inside a loop that stores results or keeps a
+// prefetch in flight, that drains the memory pipeline once per iteration.  Use this where only LDS data is
+// exchanged between the waves.
+#define B4C_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 void b4c_set_error(const char *fmt, ...);
 int b4c_check_launch(const char *what);
 

@@ -11,6 +11,8 @@
 //   fp32 FMA chain, parity path), 32 K-elements per stage.
 // gemm_tn stages its operands TRANSPOSED (token-major global rows -> feature-major LDS rows) so the
 // reduction axis (tokens) is contiguous for the fragment reads.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -25,6 +27,19 @@ template <typename K> static void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (ndone < 16) done[ndone++] = (const void *)kernel;
 }
+
+// Branch-free guarded loads: a raw buffer descriptor over the tile's rows makes out-of-range rows read as 0,
+// and an out-of-range K chunk is steered out of range by its offset.  (A per-chunk `if` inside the unrolled
+// staging loops becomes control flow, and the compiler then waits vmcnt(0) at every join -- which also waits
+// for stores and for younger prefetches.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void *base, int64_t rows_left, int tile_rows, int64_t row_bytes) {
+    const int64_t rows = rows_left < tile_rows ? (rows_left < 0 ? 0 : rows_left) : tile_rows;
+    const int64_t bytes = rows * row_bytes;           // < 1 GiB for every tile this file uses
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (unsigned)(bytes > 0x3FFFFFF0ll ? 0x3FFFFFF0ll : bytes), 0x00020000);
+}
+// or-ing this bit into a byte offset pushes it past every tile descriptor (plain integer arithmetic: a select
+// between a real offset and a large constant gets if-converted into two differently-encoded loads)
+__device__ __forceinline__ int oob_if(bool invalid) { return invalid ? 0x40000000 : 0; }
 
 #define TILE 128
 #define LDS_STRIDE 144                     // bytes per tile row (128 + 16 pad)
@@ -81,14 +96,12 @@ __device__ __forceinline__ void mma_stage(const char *sA, const char *sB, int wm
 // K-contiguous staging: 128 rows x 128 B = 1024 16-B chunks, 4 per thread; 8 lanes cover one row.
 template <typename T>
 __device__ __forceinline__ void nt_load(const T *__restrict__ P, int ld, int row0, int nrows, int k0, int K, int tid, u32x4 (&reg)[4]) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(P + (int64_t)row0 * ld, (int64_t)nrows - row0, TILE, (int64_t)ld * sizeof(T));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = tid + i * 256;
-        const int row = c >> 3, cc = c & 7;
-        const int gr = row0 + row, gk = k0 + cc * MM<T>::VE;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (gr < nrows && gk < K) v = *reinterpret_cast<const u32x4 *>(P + (int64_t)gr * ld + gk);
-        reg[i] = v;
+        const int row = c >> 3, gk = k0 + (c & 7) * MM<T>::VE;
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((row * ld + gk) * (int)sizeof(T)) | oob_if(gk >= K), 0, 0);
     }
 }
 __device__ __forceinline__ void nt_store(char *s, int tid, const u32x4 (&reg)[4]) {
@@ -270,6 +283,196 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, i
     }
 }
 
+// Wide-N, small-K form (the vocabulary projection: [R][128] x [V][128]^T -> [R][V]).  The generic kernel
+// above spends most of its time outside stores and MFMAs there (with both removed it still runs at half its
+// full duration: 125 k workgroups each pay tile loads, staging and barriers for 32 KB of output).  Here a
+// workgroup keeps its 128-row A tile in LDS and walks a chunk of N tiles: per tile one W tile (L2), 32 MFMAs
+// per consumer wave over the whole K, and the output leaves through an LDS transpose as 16-B row chunks.
+#define WIDE_STR 272                         // bytes per LDS row: K = 128 bf16 + 16 pad
+#define WIDE_TILE_BYTES (TILE * WIDE_STR)    // 34816 == 4 waves * 64 rows * OUT_STRIDE
+
+__device__ __forceinline__ void wide_load(const bf16_t *__restrict__ P, int ld, int row0, int nrows, int K, int tid, u32x4 (&reg)[8]) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(P + (int64_t)row0 * ld, (int64_t)nrows - row0, TILE, (int64_t)ld * 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + i * 256;
+        const int row = c >> 4, cc = c & 15;
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((row * ld + cc * 8) * 2) | oob_if(cc * 8 >= K), 0, 0);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void wide_load_r(const bf16_t *__restrict__ P, int ld, int row0, int nrows, int K, int tid, u32x4 (&R)[16]) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(P + (int64_t)row0 * ld, (int64_t)nrows - row0, TILE, (int64_t)ld * 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + i * 256;
+        const int row = c >> 4, cc = c & 15;
+        R[OFF + i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((row * ld + cc * 8) * 2) | oob_if(cc * 8 >= K), 0, 0);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void wide_store_r(char *s, int tid, const u32x4 (&R)[16]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + i * 256;
+        *reinterpret_cast<u32x4 *>(s + (c >> 4) * WIDE_STR + (c & 15) * 16) = R[OFF + i];
+    }
+}
+__device__ __forceinline__ void wide_store(char *s, int tid, const u32x4 (&reg)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + i * 256;
+        *reinterpret_cast<u32x4 *>(s + (c >> 4) * WIDE_STR + (c & 15) * 16) = reg[i];
+    }
+}
+
+// Two wave roles in one 512-thread workgroup per CU.  Ablation of a version whose compute waves also stored
+// showed its phases ADDING instead of overlapping (loop skeleton 1.06 us/tile + W loads 0.68 + stores 1.43): a
+// wave that issues 8 x 1 KB stores stalls in store ISSUE at the CU's ~22 GB/s drain rate.  So:
+//   waves 0-3  compute: A fragments live in registers for the whole chunk; 32 MFMAs per tile over K <= 128,
+//              + bias, bf16, into a double-buffered LDS transpose; they never touch global memory in the loop
+//   waves 4-7  move: W tile (+ bias slice) L2 -> registers (two tiles in flight) -> LDS, double buffered, and the
+//              PREVIOUS output tile LDS -> 16-B row chunks (4 rows x 256 B per wave-instruction) -> HBM.  Their
+//              loads are always older than the stores they issue next, so the counted vmcnt wait for a W tile
+//              never waits for the latest stores.
+// One LDS-only barrier per tile.  (Measured at R = 40,960, V = 50,000: 1.32 ms = 3.1 TB/s; splitting the move
+// role further into 2 load + 2 store waves was slower, 1.53 ms.)
+#define WOUT_STR 264                          // bytes per staged output row: 128 bf16 + 8 pad (8-B writes 2-way at most)
+#define WOUT_BYTES (TILE * WOUT_STR)          // 33792
+
+__global__ void __launch_bounds__(512) gemm_nt_wide_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ Bt, int ldb,
+                                                           bf16_t *__restrict__ C, int ldc, int M, int N, int K,
+                                                           const float *__restrict__ bias, int mt, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sW = smem;                                     // 2 x WIDE_TILE_BYTES
+    char *sOut = smem + 2 * WIDE_TILE_BYTES;             // 2 x WOUT_BYTES
+    float *sBias = reinterpret_cast<float *>(smem + 2 * WIDE_TILE_BYTES + 2 * WOUT_BYTES);   // 2 x 128
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = wave >> 2;                          // 0 compute, 1 move
+    const int rtid = tid & 255;
+    const int m0 = (blockIdx.x % mt) * TILE;
+    const int ntn = (N + TILE - 1) / TILE;
+    const int nt0 = (blockIdx.x / mt) * tiles_per_chunk;
+    const int nt1 = min(ntn, nt0 + tiles_per_chunk);
+    if (nt0 >= nt1) return;
+    const int ntiles = nt1 - nt0;
+    const int wm = (wave & 3) >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+
+    // One 16 x 16-B register block serves whichever role the wave has (the roles are exclusive; separate arrays
+    // would be allocated side by side): compute waves keep their A fragments in it
+    // (AF(i,kk) = A[m0 + wm*64 + i*32 + r][kk*16 + 8h ..]), move waves two in-flight W tiles (R[0..7] / R[8..15]).
+    u32x4 R[16];
+#define AF(i, kk) __builtin_bit_cast(bf16x8, R[(i) * 8 + (kk)])
+    float xb = 0.f, yb = 0.f;
+    if (role == 0) {
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(A + (int64_t)m0 * lda, (int64_t)M - m0, TILE, (int64_t)lda * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int row = wm * 64 + i * 32 + r, col = kk * 16 + h * 8;
+                R[i * 8 + kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((row * lda + col) * 2) | oob_if(col >= K), 0, 0);
+            }
+    } else {
+        wide_load_r<0>(Bt, ldb, nt0 * TILE, N, K, rtid, R);
+        wide_store_r<0>(sW, rtid, R);
+        if (rtid < 128) sBias[rtid] = (bias && nt0 * TILE + rtid < N) ? bias[nt0 * TILE + rtid] : 0.f;
+        if (ntiles > 1) {
+            wide_load_r<0>(Bt, ldb, (nt0 + 1) * TILE, N, K, rtid, R);
+            if (rtid < 128 && bias && (nt0 + 1) * TILE + rtid < N) xb = bias[(nt0 + 1) * TILE + rtid];
+        }
+    }
+    __syncthreads();
+
+    for (int t = 0; t <= ntiles; ++t) {                  // one extra iteration: the stores trail by one tile
+        const int buf = t & 1;
+        const int n0 = (nt0 + t) * TILE;
+        if (role == 1) {
+            if (buf == 0) {          // x (R[0..7]) -> LDS buffer 1, refill y (R[8..15])
+                if (t + 2 < ntiles) {
+                    wide_load_r<8>(Bt, ldb, n0 + 2 * TILE, N, K, rtid, R);
+                    yb = (rtid < 128 && bias && n0 + 2 * TILE + rtid < N) ? bias[n0 + 2 * TILE + rtid] : 0.f;
+                }
+                if (t + 1 < ntiles) {
+                    wide_store_r<0>(sW + WIDE_TILE_BYTES, rtid, R);
+                    if (rtid < 128) sBias[128 + rtid] = xb;
+                }
+            } else {                 // y -> LDS buffer 0, refill x
+                if (t + 2 < ntiles) {
+                    wide_load_r<0>(Bt, ldb, n0 + 2 * TILE, N, K, rtid, R);
+                    xb = (rtid < 128 && bias && n0 + 2 * TILE + rtid < N) ? bias[n0 + 2 * TILE + rtid] : 0.f;
+                }
+                if (t + 1 < ntiles) {
+                    wide_store_r<8>(sW, rtid, R);
+                    if (rtid < 128) sBias[rtid] = yb;
+                }
+            }
+            if (t >= 1) {            // tile t-1: rows of 256 B, 16 lanes per row
+                const char *so = sOut + (buf ^ 1) * WOUT_BYTES;
+                const int ns = n0 - TILE;
+                const bool interior = (m0 + TILE <= M) && (ns + TILE <= N);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = rtid + q * 256;
+                    const int row = c >> 4, pc = c & 15;
+                    const int64_t grow = m0 + row;
+                    const int gcol = ns + pc * 8;
+                    const u32x2 lo = *reinterpret_cast<const u32x2 *>(so + row * WOUT_STR + pc * 16);
+                    const u32x2 hi = *reinterpret_cast<const u32x2 *>(so + row * WOUT_STR + pc * 16 + 8);
+                    if (interior || (grow < M && gcol < N)) {     // interior tiles: uniform, no per-store control flow
+                        const u32x4 w4 = {lo[0], lo[1], hi[0], hi[1]};
+                        *reinterpret_cast<u32x4 *>(C + grow * ldc + gcol) = w4;
+                    }
+                }
+            }
+        } else {
+            if (t < ntiles) {
+                const char *w0 = sW + buf * WIDE_TILE_BYTES + (wn * 64 + r) * WIDE_STR;
+                f32x16 acc[2][2];    // acc[j][i]: rows = n (tile j of the wave's 64 columns), col = m (tile i of its 64 rows)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const bf16x8 fw0 = *reinterpret_cast<const bf16x8 *>(w0 + kk * 32 + h * 16);
+                    const bf16x8 fw1 = *reinterpret_cast<const bf16x8 *>(w0 + 32 * WIDE_STR + kk * 32 + h * 16);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw0, AF(0, kk), acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw0, AF(1, kk), acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw1, AF(0, kk), acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw1, AF(1, kk), acc[1][1], 0, 0, 0);
+                }
+                // reg 4 tq + k of acc[j][i]: n = wn*64 + j*32 + 8 tq + 4 h + k, m = wm*64 + i*32 + r
+                char *so = sOut + buf * WOUT_BYTES;
+                const float *sb = sBias + buf * 128;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int tq = 0; tq < 4; ++tq) {
+                        const int nl = wn * 64 + j * 32 + 8 * tq + 4 * h;
+                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sb + nl);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+                            bf16x4_t w;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) w[k] = (bf16_t)(acc[j][i][4 * tq + k] + b4[k]);
+                            *reinterpret_cast<bf16x4_t *>(so + (wm * 64 + i * 32 + r) * WOUT_STR + nl * 2) = w;
+                        }
+                    }
+            }
+        }
+        B4C_LDS_BARRIER();
+    }
+#undef AF
+}
+
+static bool vec_ok_wide(const void *C, int ldc, int N, const float *bias) {
+    return (N % 8 == 0) && (ldc % 8 == 0) && (((uintptr_t)C & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
+}
+
 extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void *C, int ldc, int M, int N, int K,
                            const float *bias, int act, const void *gate, int ldg, const void *residual, int ldr,
                            int dtype, int out_dtype, void *stream) {
@@ -282,6 +485,20 @@ extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void
     B4C_REQUIRE((((uintptr_t)A | (uintptr_t)Bt) & 15) == 0, "gemm_nt: operands must be 16-byte aligned");
     B4C_REQUIRE(out_dtype == dtype || out_dtype == B4C_F32, "gemm_nt: out_dtype %d", out_dtype);
     B4C_REQUIRE(act == B4C_ACT_NONE || act == B4C_ACT_RELU, "gemm_nt: act %d", act);
+    hipStream_t st_w = (hipStream_t)stream;
+    if (dtype == B4C_BF16 && out_dtype == B4C_BF16 && K <= 128 && N >= 2048 && act == B4C_ACT_NONE && !gate && !residual &&
+        vec_ok_wide(C, ldc, N, bias)) {
+        const int mt = (int)ceil_div64(M, TILE), ntn = (int)ceil_div64(N, TILE);
+        int chunks = (int)ceil_div64(1280, mt);          // 1 workgroup per CU resident, ~5 per CU over the launch
+        if (chunks > ntn) chunks = ntn;
+        if (chunks < 1) chunks = 1;
+        const int tpc = (int)ceil_div64(ntn, chunks);
+        chunks = (int)ceil_div64(ntn, tpc);
+        const size_t shm_w = 2 * WIDE_TILE_BYTES + 2 * WOUT_BYTES + 2 * 128 * sizeof(float);
+        allow_lds(gemm_nt_wide_kernel, shm_w);
+        gemm_nt_wide_kernel<<<mt * chunks, 512, shm_w, st_w>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, mt, tpc);
+        return b4c_check_launch("gemm_nt_wide");
+    }
     const int64_t nblocks = ceil_div64(M, TILE) * ceil_div64(N, TILE);
     B4C_REQUIRE(nblocks < (1ll << 31), "gemm_nt: too many tiles");
     dim3 grid((unsigned)nblocks);
@@ -494,14 +711,12 @@ __device__ __forceinline__ bf16x8 tn_frag(const char *p) {   // tokens +0..3 and
     return __builtin_bit_cast(bf16x8, w);
 }
 __device__ __forceinline__ void tn_load16(const bf16_t *__restrict__ P, int ld, int f0, int64_t tok0, int64_t tok_end, int tid, u32x4 (&reg)[4]) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(P + tok0 * ld, tok_end - tok0, 64, (int64_t)ld * 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = tid + i * 256;
-        const int64_t t = tok0 + (c >> 4);
         const int f = f0 + (c & 15) * 8;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (t < tok_end && f < ld) v = *reinterpret_cast<const u32x4 *>(P + t * ld + f);
-        reg[i] = v;
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (((c >> 4) * ld + f) * 2) | oob_if(f >= ld), 0, 0);
     }
 }
 __device__ __forceinline__ void tn_store16(char *s, int tid, const u32x4 (&reg)[4]) {

@@ -48,6 +48,19 @@ def test_gemm_nt_exact_integers(ops, dtype, M, N, K):
     assert torch.equal(got.cpu().double(), want)
 
 
+@pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('M,N,K', [(300, 2560, 128), (129, 4104, 64), (128, 2048, 104), (1000, 50000, 128)])
+def test_gemm_nt_wide_vocab_kernel(ops, out_dtype, M, N, K):
+    # the persistent wide-N kernel (K <= 128, N >= 2048): exact on integers (|sums| <= 256 are exact in bf16), bias fused
+    g = torch.Generator().manual_seed(N + K)
+    a = torch.randint(-1, 2, (M, K), generator=g).float()
+    bt = torch.randint(-1, 2, (N, K), generator=g).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    want = a.double() @ bt.double().T + bias.double()
+    got = ops.gemm_nt(dev(a, torch.bfloat16), dev(bt, torch.bfloat16), N, dev(bias), out_dtype=out_dtype)
+    assert torch.equal(got.cpu().double(), want)
+
+
 @pytest.mark.parametrize('dtype', DT)
 def test_gemm_nt_epilogue(ops, dtype):
     g = torch.Generator().manual_seed(5)
