@@ -45,7 +45,6 @@ def parse():
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--n_batches', type=int, default=2, help='distinct resident batches cycled through')
-    ap.add_argument('--roofline_kernel', default='vocab_proj_fwd')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_rows', type=int, default=48, help='sequences in the bounded CPU-baseline sample')
     ap.add_argument('--traffic_json', default=None, help='optional JSON with PMC-derived HBM bytes per launch')
@@ -130,31 +129,29 @@ def cpu_baseline(a):
             'ms_per_step': dt * 1e3}
 
 
-def roofline_for(kernel, a, R, ms):
-    """Algorithmic bytes / flops of ONE launch of the named kernel (Measurement)."""
-    es = 2 if a.dtype == 'bf16' else 4
-    V, Vp, d, T = a.vocab, (a.vocab + 7) // 8 * 8, a.d_model, a.batch * a.seq
-    if kernel == 'vocab_proj_fwd':      # logits[R][Vp] = h[R][128] . W[V][128]^T : write-bound
-        by = R * Vp * es + R * 128 * es + V * 128 * es
-        return {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': 'gemm_nt (vocab projection fwd)'}
-    if kernel == 'vocab_proj_dx':
-        by = R * Vp * es + R * 128 * es + V * 128 * es
-        return {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': 'gemm_nt (vocab projection dX)'}
-    if kernel == 'vocab_proj_dw':
-        by = R * Vp * es + R * 128 * es + V * 128 * 4
-        return {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': 'gemm_tn (vocab projection dW)'}
-    if kernel == 'softmax_ce':
-        by = 2 * R * Vp * es
-        return {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': 'softmax_ce_fused'}
-    if kernel == 'qkv_fwd':
-        by = T * d * es + T * 3 * d * es + 3 * d * d * es
-        return {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'kernel': 'gemm_nt (QKV projection fwd)'}
-    if kernel in ('attn_fwd', 'attn_bwd'):
-        S, H = a.seq, a.heads
-        fl = (4 if kernel == 'attn_fwd' else 10) * a.batch * S * S * d
-        return {'bound': 'mfma', 'achieved': fl / (ms * 1e-3) / 1e12, 'peak': MFMA_BF16_PEAK_TF if a.dtype == 'bf16' else 157.3,
-                'unit': 'TFLOP/s', 'kernel': kernel}
-    raise SystemExit('unknown roofline kernel %s' % kernel)
+KERNEL_OF = {   # launch family (ops recorder) -> kernel symbol(s) in the rocprofv3 trace
+    'gemm_nt': 'gemm_nt_kernel / gemm_nt_wide_kernel (dense fwd + dX)', 'gemm_tn': 'gemm_tn_bf16_kernel (dW)',
+    'attn_fwd': 'attn_fwd_mfma_kernel', 'attn_bwd': 'attn_bwd_resident_kernel', 'softmax_ce': 'softmax_ce_bf16_kernel',
+    'add_ln_fwd': 'add_ln_fwd_kernel', 'add_ln_bwd': 'add_ln_bwd_kernel', 'embed_fwd': 'embed_fwd_kernel',
+    'embed_bwd': 'embed_bwd_kernel', 'adam': 'adam_kernel'}
+
+
+def roofline_from(fams, steps, peak_tf):
+    """Dominant launch family of the timed region (largest summed HIP-event time) against the HBM roofline:
+    achieved = sum of the launches' ALGORITHMIC bytes / summed duration."""
+    table = {}
+    for fam, v in fams.items():
+        ms = max(v['ms'], 1e-9)
+        table[fam] = {'ms_per_step': v['ms'] / steps, 'launches_per_step': v['launches'] / steps,
+                      'GB_per_s': v['bytes'] / ms / 1e6, 'TFLOP_per_s': v['flops'] / ms / 1e9}
+    dom = max(fams, key=lambda f: fams[f]['ms'])
+    v = fams[dom]
+    ach = v['bytes'] / v['ms'] / 1e6
+    return {'bound': 'hbm', 'kernel': KERNEL_OF.get(dom, dom), 'family': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': ach / HBM_PEAK_GBS, 'avg_launch_ms': v['ms'] / v['launches'], 'launches_timed': v['launches'],
+            'algorithmic_bytes_per_launch': v['bytes'] / v['launches'],
+            'mfma_frac_of_%g_TF' % peak_tf: v['flops'] / v['ms'] / 1e9 / peak_tf, 'traffic': None,
+            'families': table}
 
 
 def main():
@@ -188,7 +185,8 @@ def main():
 
     for i in range(a.warmup):
         loss = step(i)
-    ops.enable_timer(a.roofline_kernel)
+    if rank == 0:
+        ops.start_recording()      # HIP events around every hot-path launch of the timed steps (rank 0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -205,18 +203,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
     dt, items = float(tt[0]), float(rr[0])
-    k_ms, k_n = ops.timer_results_ms(a.roofline_kernel)
 
     if rank == 0:
-        R = batches[0]['R']
-        roof = roofline_for(a.roofline_kernel, a, R, k_ms)
-        roof['frac'] = roof['achieved'] / roof['peak']
-        roof['avg_launch_ms'] = k_ms
-        roof['launches_timed'] = k_n
-        roof['traffic'] = None
-        if a.traffic_json and os.path.exists(a.traffic_json):
-            with open(a.traffic_json) as f:
-                roof['traffic'] = json.load(f).get(a.roofline_kernel)
+        fams = ops.stop_recording()
+        roof = roofline_from(fams, a.steps, MFMA_BF16_PEAK_TF if a.dtype == 'bf16' else 157.3)
+        tj = a.traffic_json or os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tj):      # rocprofv3 PMC passes (separate runs), HBM bytes per launch of each family
+            with open(tj) as f:
+                roof['traffic'] = json.load(f).get(roof['family'])
         out = {
             'metric': 'masked-items/sec (whole node)', 'value': items / dt, 'unit': 'masked-items/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,

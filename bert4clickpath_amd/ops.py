@@ -23,8 +23,46 @@ def rup8(n):
     return (n + 7) // 8 * 8
 
 
-# ---- optional per-launch timers (bench.py: HIP events on the launch stream around ONE named
-# kernel, so its roofline fraction is measured live inside the timed region) ---------------------
+# ---- optional launch recorder (bench.py): HIP events on the launch stream around EVERY launch of the hot-path
+# kernels, with the algorithmic bytes / flops of that launch, so the dominant kernel family and its roofline
+# fraction are measured live inside the timed region -------------------------------------------------------
+_rec = None        # None = off; else dict family -> [ms_events..., bytes, flops, launches]
+
+
+def start_recording():
+    global _rec
+    _rec = {}
+
+
+def stop_recording():
+    """-> {family: {'ms': total, 'launches': n, 'bytes': algorithmic bytes, 'flops': algorithmic flops}} (synchronises)."""
+    global _rec
+    rec, _rec = _rec, None
+    torch.cuda.synchronize()
+    out = {}
+    for fam, items in (rec or {}).items():
+        out[fam] = {'ms': sum(a.elapsed_time(b) for a, b, _, _ in items), 'launches': len(items),
+                    'bytes': sum(x[2] for x in items), 'flops': sum(x[3] for x in items)}
+    return out
+
+
+class _record:
+    def __init__(self, family, nbytes, flops=0):
+        self.on = _rec is not None
+        self.family, self.nbytes, self.flops = family, nbytes, flops
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.on and _rec is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _rec.setdefault(self.family, []).append((self.a, b, self.nbytes, self.flops))
+
+
 _timers = {}
 
 
@@ -110,8 +148,9 @@ def embed_concat_pe_fwd(ids_list, tables, pe, scale, rate, seed, dtype):
     out = torch.empty(B, S, d, dtype=dtype, device=pe.device)
     key_pad = torch.empty(B, S, dtype=torch.uint8, device=pe.device)
     n, ids_arr, tab_arr, dims, rows = _feature_arrays(ids_list, tables)
-    L.check(L.lib().b4c_embed_concat_pe_fwd(n, ids_arr, tab_arr, dims, rows, _p(pe), scale, _p(out), d, _p(key_pad),
-                                            B, S, d, rate, seed, dt_code(dtype), _st()), 'embed_concat_pe_fwd')
+    with _record('embed_fwd', B * S * d * (4 + out.element_size())):
+        L.check(L.lib().b4c_embed_concat_pe_fwd(n, ids_arr, tab_arr, dims, rows, _p(pe), scale, _p(out), d, _p(key_pad),
+                                                B, S, d, rate, seed, dt_code(dtype), _st()), 'embed_concat_pe_fwd')
     return out, key_pad
 
 
@@ -120,8 +159,9 @@ def embed_concat_pe_bwd(ids_list, tables, dout, scale, rate, seed, into=None):
     d = dout.shape[-1]
     dtabs = into if into is not None else [torch.zeros_like(t) for t in tables]
     n, ids_arr, tab_arr, dims, rows = _feature_arrays(ids_list, dtabs)
-    L.check(L.lib().b4c_embed_concat_pe_bwd(n, ids_arr, tab_arr, dims, rows, scale, _p(dout), d, B, S, d, rate, seed,
-                                            dt_code(dout.dtype), _st()), 'embed_concat_pe_bwd')
+    with _record('embed_bwd', B * S * d * (4 + dout.element_size())):
+        L.check(L.lib().b4c_embed_concat_pe_bwd(n, ids_arr, tab_arr, dims, rows, scale, _p(dout), d, B, S, d, rate, seed,
+                                                dt_code(dout.dtype), _st()), 'embed_concat_pe_bwd')
     return dtabs
 
 
@@ -132,10 +172,14 @@ def gemm_nt(a, bt, n, bias=None, act=L.ACT_NONE, gate=None, residual=None, out_d
     out = torch.empty(M, n, dtype=out_dtype, device=a.device)
     if M == 0:
         return out
-    L.check(L.lib().b4c_gemm_nt(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), n, M, n, K, _p(bias), act,
-                                _p(gate), gate.stride(0) if gate is not None else 0,
-                                _p(residual), residual.stride(0) if residual is not None else 0,
-                                dt_code(a.dtype), dt_code(out_dtype), _st()), 'gemm_nt')
+    es = a.element_size()
+    nbytes = M * K * es + n * K * es + M * n * out.element_size() + (M * n * es if gate is not None else 0) + \
+        (M * n * es if residual is not None else 0)
+    with _record('gemm_nt', nbytes, 2 * M * n * K):
+        L.check(L.lib().b4c_gemm_nt(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), n, M, n, K, _p(bias), act,
+                                    _p(gate), gate.stride(0) if gate is not None else 0,
+                                    _p(residual), residual.stride(0) if residual is not None else 0,
+                                    dt_code(a.dtype), dt_code(out_dtype), _st()), 'gemm_nt')
     return out
 
 
@@ -143,6 +187,14 @@ def gemm_tn(a, g, K, N, want_bias=True, into=None):
     """dW[K,N] (+)= a[:, :K]^T @ g[:, :N] (fp32), db[N] (+)= colsum(g).
     into = (list of dW_i [K, N/len], list of db_i [N/len]): accumulate into existing fp32 tensors (column
     segments of equal width) instead of allocating zeros; returns (None, None) then."""
+    M = a.shape[0]
+    if M > 0 and _rec is not None:
+        with _record('gemm_tn', M * (K + N) * a.element_size() + K * N * 4, 2 * M * K * N):
+            return _gemm_tn_impl(a, g, K, N, want_bias, into)
+    return _gemm_tn_impl(a, g, K, N, want_bias, into)
+
+
+def _gemm_tn_impl(a, g, K, N, want_bias, into):
     M = a.shape[0]
     if into is not None:
         dWs, dbs = into
@@ -198,17 +250,19 @@ def attn_fwd(qkv, key_pad, B, S, H, dh):
     d = H * dh
     o = torch.empty(B * S, d, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
-    L.check(L.lib().b4c_attn_fwd(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), d, _p(lse), B, S, H, dh,
-                                 dt_code(qkv.dtype), _st()), 'attn_fwd')
+    with _record('attn_fwd', B * S * 4 * d * qkv.element_size(), 4 * B * S * S * d):
+        L.check(L.lib().b4c_attn_fwd(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), d, _p(lse), B, S, H, dh,
+                                     dt_code(qkv.dtype), _st()), 'attn_fwd')
     return o, lse
 
 
 def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    L.check(L.lib().b4c_attn_bwd(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), o.stride(0), _p(d_o), d_o.stride(0),
-                                 _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, dt_code(qkv.dtype), _st()),
-            'attn_bwd')
+    with _record('attn_bwd', B * S * 8 * H * dh * qkv.element_size(), 10 * B * S * S * H * dh):
+        L.check(L.lib().b4c_attn_bwd(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), o.stride(0), _p(d_o), d_o.stride(0),
+                                     _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, dt_code(qkv.dtype), _st()),
+                'attn_bwd')
     return dqkv
 
 
@@ -217,8 +271,9 @@ def add_dropout_layernorm_fwd(x, y, gamma, beta, rate, seed, save=True):
     z = torch.empty_like(x) if save else None
     out = torch.empty_like(x)
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if save else None
-    L.check(L.lib().b4c_add_dropout_layernorm_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(z), _p(out), _p(stats), rows, d,
-                                                  LN_EPS, rate, seed, dt_code(x.dtype), _st()), 'add_dropout_layernorm_fwd')
+    with _record('add_ln_fwd', rows * d * x.element_size() * (4 if save else 3)):
+        L.check(L.lib().b4c_add_dropout_layernorm_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(z), _p(out), _p(stats), rows, d,
+                                                      LN_EPS, rate, seed, dt_code(x.dtype), _st()), 'add_dropout_layernorm_fwd')
     return z, out, stats
 
 
@@ -231,9 +286,10 @@ def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed, into=None):
     else:
         dgamma = torch.zeros(d, dtype=torch.float32, device=z.device)
         dbeta = torch.zeros(d, dtype=torch.float32, device=z.device)
-    L.check(L.lib().b4c_add_dropout_layernorm_bwd(_p(dout), _p(z), _p(stats), _p(gamma), _p(dz), _p(dy), _p(dgamma),
-                                                  _p(dbeta), rows, d, rate, seed, dt_code(z.dtype), _st()),
-            'add_dropout_layernorm_bwd')
+    with _record('add_ln_bwd', rows * d * z.element_size() * (4 if rate > 0 else 3)):
+        L.check(L.lib().b4c_add_dropout_layernorm_bwd(_p(dout), _p(z), _p(stats), _p(gamma), _p(dz), _p(dy), _p(dgamma),
+                                                      _p(dbeta), rows, d, rate, seed, dt_code(z.dtype), _st()),
+                'add_dropout_layernorm_bwd')
     return dz, (dy if dy is not None else dz), dgamma, dbeta
 
 
@@ -304,8 +360,9 @@ def softmax_ce_fwd_bwd_(logits, labels_i32, grad_scale, V, variant=L.CE_TF):
     item = torch.empty(R, dtype=torch.float32, device=logits.device)
     if R == 0:
         return item
-    L.check(L.lib().b4c_softmax_ce_fwd_bwd(_p(logits), ld, _p(labels_i32), _p(item), _p(grad_scale), R, V, variant,
-                                           dt_code(logits.dtype), _st()), 'softmax_ce_fwd_bwd')
+    with _record('softmax_ce', 2 * R * ld * logits.element_size()):
+        L.check(L.lib().b4c_softmax_ce_fwd_bwd(_p(logits), ld, _p(labels_i32), _p(item), _p(grad_scale), R, V, variant,
+                                               dt_code(logits.dtype), _st()), 'softmax_ce_fwd_bwd')
     return item
 
 
@@ -323,8 +380,9 @@ def topk_rows(scores, V, k, labels_i32=None):
 
 
 def adam_step_(p, g, m, v, lr_t, beta1, beta2, eps, grad_mul=1.0):
-    L.check(L.lib().b4c_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr_t, beta1, beta2, eps, grad_mul, _st()),
-            'adam_step')
+    with _record('adam', p.numel() * 28):
+        L.check(L.lib().b4c_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr_t, beta1, beta2, eps, grad_mul, _st()),
+                'adam_step')
 
 
 def keep_mask(seed, n, rate):
