@@ -162,6 +162,7 @@ def main():
         if rank == 0:
             print('warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (a.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU fallback)'
+    local = local % torch.cuda.device_count()      # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
 

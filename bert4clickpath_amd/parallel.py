@@ -23,7 +23,8 @@ def init_distributed(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # "nccl" IS RCCL on ROCm
+            # "nccl" IS RCCL on ROCm.  B4C_DIST_BACKEND=gloo rehearses the N > 1 path on fewer GPUs than ranks.
+            backend = os.environ.get('B4C_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -47,6 +48,7 @@ class GradReducer:
         self.buckets = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1) if bounds[i + 1] > bounds[i]]
         self._handles = []
         self._pending = None
+        self._seen = set()
         self._bucket_of = []
         for p, o in zip(arena.params, arena.offsets):
             b = next(i for i, (lo, hi) in enumerate(self.buckets) if lo <= o < hi)
@@ -68,9 +70,12 @@ class GradReducer:
         return 1.0 / self.world if self.reduce == 'mean' else 1.0
 
     def _make_hook(self, b):
-        def hook(_param):
-            if self._pending is None:
+        def hook(param):
+            # a parameter may be announced twice in one backward (by the HIP kernels' in-place callback AND by
+            # autograd's post-accumulate hook): count it once, or a bucket would be reduced before it is complete
+            if self._pending is None or id(param) in self._seen:
                 return
+            self._seen.add(id(param))
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._launch(b)
@@ -83,6 +88,7 @@ class GradReducer:
     def begin_backward(self):
         """Call before loss.backward(): arms the per-bucket countdowns."""
         self._handles = []
+        self._seen = set()
         self._pending = list(self._sizes) if self.overlap else None
 
     def finish(self):

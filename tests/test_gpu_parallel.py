@@ -1,0 +1,97 @@
+"""Data-parallel training step on the GPU box: 2 ranks (gloo transport, both on cuda:0 -- the box has one GPU)
+run the real HIP step with the bucketed, hook-overlapped gradient all-reduce; afterwards the replicas must hold
+identical weights, equal to ONE process trained on both shards with the reference's semantics (sum over
+replicas of each replica's mean loss, losses.py:17,80-91)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+V, D, L, H, B, S, STEPS = 120, 32, 2, 2, 6, 19, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    torch.manual_seed(5)
+    m = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': D}, SoftMaxHead([24], V),
+                               value_to_head='[MASK]', num_encoder_layers=L, num_attention_heads=H, dropout_rate=0.0)
+    return m.cuda()
+
+
+def _batch(rank):
+    from bert4clickpath_amd import input_pipeline
+    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=100 + rank, min_len=4)
+    ids = torch.from_numpy(b['ids'])
+    return ids[:, 2:S - 1].contiguous().cuda(), torch.from_numpy(b['labels']).cuda(), torch.from_numpy(b['flat_idx']).cuda()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0', B4C_DIST_BACKEND='gloo')
+    from bert4clickpath_amd import optim, parallel
+    parallel.init_distributed()
+    torch.cuda.set_device(0)
+    model = _model()
+    opt = optim.Adam(model.parameters())
+    head_end = max(opt.arena.slice_of(p)[1] for n, p in model.named_parameters() if n.startswith('head.'))
+    red = parallel.GradReducer(opt.arena, bucket_bounds=[head_end], reduce='sum')
+    assert red.overlap and len(red.buckets) == 2
+    items, labels, flat = _batch(rank)
+    for _ in range(STEPS):
+        opt.zero_grad()
+        red.begin_backward()
+        loss = model.cloze_loss({'asin': items}, labels, training=True, flat_idx=flat)
+        loss.backward()
+        red.finish()
+        opt.step(red.grad_mul)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, 'rank%d.npy' % rank), opt.arena.flat.cpu().numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_matches_single_process(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip('needs the MI355X')
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    w0, w1 = np.load(tmp_path / 'rank0.npy'), np.load(tmp_path / 'rank1.npy')
+    d01 = np.abs(w0 - w1)
+    assert np.array_equal(w0, w1), 'replicas diverged: max %g at %d of %d (n differing %d)' % (d01.max(), d01.argmax(), d01.size, (d01 > 0).sum())
+    # one process, both shards: loss = mean(shard 0) + mean(shard 1)
+    from bert4clickpath_amd import optim
+    model = _model()
+    opt = optim.Adam(model.parameters())
+    shards = [_batch(r) for r in range(world)]
+    for _ in range(STEPS):
+        opt.zero_grad()
+        for items, labels, flat in shards:
+            model.cloze_loss({'asin': items}, labels, training=True, flat_idx=flat).backward()
+        opt.step()
+    ref = opt.arena.flat.cpu().numpy()
+    assert ref.shape == w0.shape
+    diff = np.abs(ref - w0)
+    for n, p in model.named_parameters():
+        if n.endswith('mha.wk.bias'):      # identically-zero gradient: Adam's 1e-9 epsilon turns rounding noise into steps
+            lo, hi = opt.arena.slice_of(p)
+            diff[lo:hi] = 0
+    assert float(diff.max()) < 2e-5
