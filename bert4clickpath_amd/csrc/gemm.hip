@@ -536,16 +536,121 @@ extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void
 struct TNOut {
     float *dW[4];
     float *db[4];
-    int segw;   // columns per segment (== N when there is one)
-    int ld;     // row pitch of every dW segment
+    int segw;      // columns per segment (== N when there is one)
+    int ld;        // row pitch of every dW segment
+    int mode;      // how a workgroup's partial tile leaves: TN_ATOMIC | TN_DIRECT | TN_WS
+    float *ws;     // TN_WS: partial tiles [split][tile][4096 float4 groups]
+    float *ws_db;  // TN_WS: partial column sums [split][tile column][128]
 };
-__device__ __forceinline__ void tn_add_w(const TNOut &o, int row, int col, float v) {
+enum { TN_ATOMIC = 0, TN_DIRECT = 1, TN_WS = 2 };
+__device__ __forceinline__ float *tn_w_ptr(const TNOut &o, int row, int col) {
     const int seg = col / o.segw;
-    atomicAdd(o.dW[seg] + (int64_t)row * o.ld + (col - seg * o.segw), v);
+    return o.dW[seg] + (int64_t)row * o.ld + (col - seg * o.segw);
 }
-__device__ __forceinline__ void tn_add_b(const TNOut &o, int col, float v) {
+__device__ __forceinline__ float *tn_b_ptr(const TNOut &o, int col) {
     const int seg = col / o.segw;
-    atomicAdd(o.db[seg] + (col - seg * o.segw), v);
+    return o.db[seg] + (col - seg * o.segw);
+}
+// The accumulator tile of one workgroup (4 waves x 2 x 2 MFMA 32x32 tiles, 128 x 128 outputs) leaves the kernel
+//   TN_WS:     as it sits in the registers -- float4 group ((wave*2+i)*2+j)*4+tq of lane -> 1 KB per wave
+//              store, no atomics; tn_reduce_kernel sums the splits in a fixed order (deterministic dW);
+//   TN_DIRECT: one split only -> plain read-modify-write;
+//   TN_ATOMIC: float atomics (no workspace given).  256 splits hitting the same 512 cache lines serialise
+//              at the memory-side atomic unit: 28 us for 16 MB at C2, which is why TN_WS exists.
+__device__ __forceinline__ void tn_emit_tile(const TNOut &out, const f32x16 (&acc)[2][2], int k0, int n0, int K, int N,
+                                             int wave, int lane) {
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    if (out.mode == TN_WS) {
+        const int64_t tile = ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y;
+        f32x4 *w = reinterpret_cast<f32x4 *>(out.ws) + tile * 4096;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    const f32x4 v = {acc[i][j][4 * tq], acc[i][j][4 * tq + 1], acc[i][j][4 * tq + 2], acc[i][j][4 * tq + 3]};
+                    w[((((wave * 2 + i) * 2 + j) * 4 + tq) << 6) + lane] = v;
+                }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int row = k0 + wm * 64 + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+                if (row < K && col < N) {
+                    float *p = tn_w_ptr(out, row, col);
+                    if (out.mode == TN_DIRECT) *p += acc[i][j][t];
+                    else atomicAdd(p, acc[i][j][t]);
+                }
+            }
+        }
+}
+// column sums of the workgroup's 128 columns (red[128] in LDS, complete)
+__device__ __forceinline__ void tn_emit_bias(const TNOut &out, const float *red, int n0, int N, int tid) {
+    if (tid >= 128) return;
+    if (out.mode == TN_WS) {
+        out.ws_db[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * 128 + tid] = red[tid];
+    } else if (n0 + tid < N) {
+        float *p = tn_b_ptr(out, n0 + tid);
+        if (out.mode == TN_DIRECT) *p += red[tid];
+        else atomicAdd(p, red[tid]);
+    }
+}
+
+// Second pass of TN_WS (latency-bound: every thread has at most ceil(nsplit/64) independent 16-B loads in
+// flight).  Blocks [0, tiles*256): 1024 threads = 16 float4 groups of one output tile x 64 split phases;
+// shuffles, then LDS across the 16 waves, then dW += sum.  Blocks [tiles*256, +tn): column sums.
+__global__ void __launch_bounds__(1024) tn_reduce_kernel(TNOut out, int K, int N, int tk, int tn, int nsplit) {
+    __shared__ f32x4 part[16][16];
+    const int tid = threadIdx.x;
+    const int tiles = tk * tn;
+    if ((int)blockIdx.x >= tiles * 256) {
+        if (!out.db[0]) return;
+        const int by = blockIdx.x - tiles * 256, c = tid & 127, zp = tid >> 7;
+        float s = 0.f;
+        for (int z = zp; z < nsplit; z += 8) s += out.ws_db[((int64_t)z * tn + by) * 128 + c];
+        float *red = reinterpret_cast<float *>(part);
+        red[zp * 128 + c] = s;
+        __syncthreads();
+        if (!zp && by * 128 + c < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[q * 128 + c];
+            *tn_b_ptr(out, by * 128 + c) += t;
+        }
+        return;
+    }
+    const int tile = blockIdx.x >> 8, grp = ((blockIdx.x & 255) << 4) + (tid & 15), zp = tid >> 4;
+    const f32x4 *w = reinterpret_cast<const f32x4 *>(out.ws) + (int64_t)tile * 4096 + grp;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int64_t zstride = (int64_t)tiles * 4096;
+#pragma unroll 4
+    for (int z = zp; z < nsplit; z += 64) s += w[z * zstride];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s[k] += __shfl_xor(s[k], 16);
+        s[k] += __shfl_xor(s[k], 32);
+    }
+    if ((tid & 63) < 16) part[tid >> 6][tid & 15] = s;
+    __syncthreads();
+    if (tid < 16) {
+        f32x4 v = part[0][tid];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) v += part[q][tid];
+        const int lane = grp & 63, tq = (grp >> 6) & 3, j = (grp >> 8) & 1, i = (grp >> 9) & 1, wave = grp >> 10;
+        const int k0 = (tile / tn) * TILE, n0 = (tile % tn) * TILE;
+        const int col = n0 + (wave & 1) * 64 + j * 32 + (lane & 31);
+        const int row = k0 + (wave >> 1) * 64 + i * 32 + 8 * tq + 4 * (lane >> 5);
+        if (col < N)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (row + k < K) *tn_w_ptr(out, row + k, col) += v[k];
+    }
 }
 
 template <typename T> struct TNStage;
@@ -673,25 +778,17 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T *__restrict__ A, i
             __syncthreads();
         }
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + r;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int row = k0 + wm * 64 + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
-                if (row < K && col < N) tn_add_w(out, row, col, acc[i][j][t]);
-            }
-        }
+    tn_emit_tile(out, acc, k0, n0, K, N, wave, lane);
     if (want_db) {
         // the 4 waves hold partial sums of the same features over different tokens
         float *red = reinterpret_cast<float *>(smem);  // all MFMA reads are behind the last barrier
-        red[wave * 128 + TNStage<T>::feat0(lane)] = bs0;
-        red[wave * 128 + TNStage<T>::feat1(lane)] = bs1;
+        float *tmp = red + 128;
+        tmp[wave * 128 + TNStage<T>::feat0(lane)] = bs0;
+        tmp[wave * 128 + TNStage<T>::feat1(lane)] = bs1;
         __syncthreads();
-        if (tid < 128 && n0 + tid < N)
-            tn_add_b(out, n0 + tid, red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid]);
+        if (tid < 128) red[tid] = tmp[tid] + tmp[128 + tid] + tmp[256 + tid] + tmp[384 + tid];
+        __syncthreads();
+        tn_emit_bias(out, red, n0, N, tid);
     }
 }
 
@@ -727,6 +824,7 @@ __device__ __forceinline__ void tn_store16(char *s, int tid, const u32x4 (&reg)[
     }
 }
 
+template <int D>
 __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ G, int ldg,
                                                            TNOut out, int64_t M,
                                                            int K, int N, int64_t chunk) {
@@ -749,120 +847,155 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restr
     const bool want_db = (out.db[0] != nullptr) && blockIdx.x == 0;
     const int nsteps = (int)((m_end - m_begin + 63) / 64);
     char *sA = smem, *sG = smem + TN_TILE_BYTES;
-    u32x4 ra[4], rg[4];
-    auto colsum = [&]() {
+    // D register sets: while the MFMAs run on the tile in LDS, tiles st+1 .. st+D are in flight (the barriers
+    // order LDS only, so loads stay outstanding across them and the waits are counted).
+    u32x4 ra[D][4], rg[D][4];
+    auto colsum = [&](const u32x4 (&q)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bf16x8 v = __builtin_bit_cast(bf16x8, rg[i]);
+            const bf16x8 v = __builtin_bit_cast(bf16x8, q[i]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) bs[k] += (float)v[k];
         }
     };
-    if (nsteps > 0) {
-        tn_load16(A, lda, k0, m_begin, m_end, tid, ra);
-        tn_load16(G, ldg, n0, m_begin, m_end, tid, rg);
-        tn_store16(sA, tid, ra);
-        tn_store16(sG, tid, rg);
-        if (want_db) colsum();
-    }
-    __syncthreads();
     // the lane's transposed-read base: token row (li >> 2) (+ 8 h), feature column 16 (g & 1) + 4 (li & 3) of a 32-wide tile
     const int lane_off = ((li >> 2) + 8 * h) * TN_STR + (16 * (g & 1) + 4 * (li & 3)) * 2;
-    for (int st = 0; st < nsteps; ++st) {
-        const bool more = st + 1 < nsteps;
-        if (more) {
-            tn_load16(A, lda, k0, m_begin + (int64_t)(st + 1) * 64, m_end, tid, ra);
-            tn_load16(G, ldg, n0, m_begin + (int64_t)(st + 1) * 64, m_end, tid, rg);
-        }
+    // tile t (t >= nsteps loads nothing: the descriptor has no rows, every lane reads zeros)
+    auto load = [&](int t, u32x4 (&qa)[4], u32x4 (&qg)[4]) {
+        const int64_t tok0 = m_begin + (int64_t)t * 64;
+        const int64_t e = tok0 < m_end ? m_end : tok0;
+        tn_load16(A, lda, k0, tok0, e, tid, qa);
+        tn_load16(G, ldg, n0, tok0, e, tid, qg);
+    };
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {   // 16 tokens per MFMA
-            const char *pa = sA + kk * 16 * TN_STR + lane_off + (wm * 64) * 2;
-            const char *pg = sG + kk * 16 * TN_STR + lane_off + (wn * 64) * 2;
-            const bf16x8 fa0 = tn_frag(pa), fa1 = tn_frag(pa + 64);
-            const bf16x8 fb0 = tn_frag(pg), fb1 = tn_frag(pg + 64);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
-        }
-        __syncthreads();
-        if (more) {
-            tn_store16(sA, tid, ra);
-            tn_store16(sG, tid, rg);
-            if (want_db) colsum();
-            __syncthreads();
-        }
-    }
+    for (int p = 0; p < D; ++p) load(p, ra[p], rg[p]);
+    tn_store16(sA, tid, ra[0]);
+    tn_store16(sG, tid, rg[0]);
+    if (want_db) colsum(rg[0]);
+    B4C_LDS_BARRIER();
+    for (int st = 0; st < nsteps; st += D) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int p = 0; p < D; ++p) {
+            const int t = st + p;                // the tile in LDS; set p is free again
+            if (t < nsteps) {
+                load(t + D, ra[p], rg[p]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + r;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int row = k0 + wm * 64 + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
-                if (row < K && col < N) tn_add_w(out, row, col, acc[i][j][t]);
+                for (int kk = 0; kk < 4; ++kk) {   // 16 tokens per MFMA
+                    const char *pa = sA + kk * 16 * TN_STR + lane_off + (wm * 64) * 2;
+                    const char *pg = sG + kk * 16 * TN_STR + lane_off + (wn * 64) * 2;
+                    const bf16x8 fa0 = tn_frag(pa), fa1 = tn_frag(pa + 64);
+                    const bf16x8 fb0 = tn_frag(pg), fb1 = tn_frag(pg + 64);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+                }
+                B4C_LDS_BARRIER();
+                if (t + 1 < nsteps) {
+                    constexpr int dummy = 0; (void)dummy;
+                    tn_store16(sA, tid, ra[(p + 1) % D]);
+                    tn_store16(sG, tid, rg[(p + 1) % D]);
+                    if (want_db) colsum(rg[(p + 1) % D]);
+                    B4C_LDS_BARRIER();
+                }
             }
         }
+    }
+    tn_emit_tile(out, acc, k0, n0, K, N, wave, lane);
     if (want_db) {
         float *red = reinterpret_cast<float *>(smem);   // all fragment reads are behind the last barrier
-        if (tid < 128) red[tid] = 0.f;
-        __syncthreads();
+        float *tmp = red + 128;                          // [16 token rows of the staging pattern][128 columns]
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&red[(tid & 15) * 8 + k], bs[k]);
+        for (int k = 0; k < 8; ++k) tmp[(tid >> 4) * 128 + (tid & 15) * 8 + k] = bs[k];
         __syncthreads();
-        if (tid < 128 && n0 + tid < N) tn_add_b(out, n0 + tid, red[tid]);
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += tmp[q * 128 + tid];
+            red[tid] = t;
+        }
+        __syncthreads();
+        tn_emit_bias(out, red, n0, N, tid);
     }
 }
 
-static int gemm_tn_launch(const void *A, int lda, const void *G, int ldg, const TNOut &out, int M, int K, int N, int dtype,
-                          void *stream) {
+// Split rule.  Few output tiles (encoder layers: 1-3): ~256 workgroups in all, each streaming its token chunk
+// with two tiles in flight -- one workgroup per CU runs at copy speed (5.2 TB/s measured) and every extra split
+// only adds partial tiles to reduce.  Many tiles (vocabulary projection: 391): one split, no reduction at all.
+static void tn_plan(int M, int K, int N, int dtype, int *tk, int *tn, int64_t *nsplit, int64_t *chunk) {
+    *tk = (K + TILE - 1) / TILE;
+    *tn = (N + TILE - 1) / TILE;
+    const int tok = dtype == B4C_BF16 ? 64 : 32;
+    const int64_t tiles = (int64_t)*tk * *tn;
+    int64_t ns = tiles >= 192 ? 1 : (256 + tiles / 2) / tiles;
+    const int64_t max_split = ceil_div64(M, (int64_t)tok * 4);
+    if (ns > max_split) ns = max_split;
+    if (ns < 1) ns = 1;
+    *chunk = ceil_div64(ceil_div64(M, ns), tok) * tok;
+    *nsplit = ceil_div64(M, *chunk);
+}
+
+extern "C" int64_t b4c_gemm_tn_workspace_bytes(int M, int K, int N, int dtype) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    int tk, tn;
+    int64_t nsplit, chunk;
+    tn_plan(M, K, N, dtype, &tk, &tn, &nsplit, &chunk);
+    if (nsplit == 1) return 0;
+    return nsplit * ((int64_t)tk * tn * 16384 + (int64_t)tn * 128) * 4;
+}
+
+static int gemm_tn_launch(const void *A, int lda, const void *G, int ldg, TNOut out, int M, int K, int N, int dtype,
+                          void *workspace, int64_t workspace_bytes, void *stream) {
     B4C_REQUIRE(A && G && out.dW[0] && M > 0 && K > 0 && N > 0, "gemm_tn: null pointer / empty");
     B4C_REQUIRE(dtype == B4C_F32 || dtype == B4C_BF16, "gemm_tn: dtype %d", dtype);
     B4C_REQUIRE(lda >= K && ldg >= N, "gemm_tn: pitches too small (lda=%d K=%d ldg=%d N=%d)", lda, K, ldg, N);
     B4C_REQUIRE(lda % 2 == 0 && ldg % 2 == 0, "gemm_tn: operand pitches must be even");
     B4C_REQUIRE((((uintptr_t)A | (uintptr_t)G) & 3) == 0, "gemm_tn: operands must be 4-byte aligned");
-    const int tk = (K + TILE - 1) / TILE, tn = (N + TILE - 1) / TILE;
-    const int tok = dtype == B4C_BF16 ? 64 : 32;
-    // every split ends in a 128 x 128 fp32 atomic tile (64 KB at ~1.3 TB/s chip-wide): 3 workgroups per CU
-    // keep the loads busy without drowning the run in atomics
-    const int64_t tiles = (int64_t)tk * tn;
-    int64_t nsplit = (tiles <= 8 ? 768 : 1536) / tiles;
-    const int64_t max_split = ceil_div64(M, (int64_t)tok * 4);
-    if (nsplit > max_split) nsplit = max_split;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > 65535) nsplit = 65535;
-    int64_t chunk = ceil_div64(ceil_div64(M, nsplit), tok) * tok;
-    nsplit = ceil_div64(M, chunk);
+    int tk, tn;
+    int64_t nsplit, chunk;
+    tn_plan(M, K, N, dtype, &tk, &tn, &nsplit, &chunk);
+    B4C_REQUIRE(tn <= 65535 && nsplit <= 65535, "gemm_tn: N too large");
+    const int64_t need = nsplit == 1 ? 0 : nsplit * ((int64_t)tk * tn * 16384 + (int64_t)tn * 128) * 4;
+    if (nsplit == 1) {
+        out.mode = TN_DIRECT;
+    } else if (workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) {
+        out.mode = TN_WS;
+        out.ws = (float *)workspace;
+        out.ws_db = out.ws + nsplit * tk * tn * 16384;
+    } else {
+        out.mode = TN_ATOMIC;
+    }
     dim3 grid(tk, tn, (unsigned)nsplit);
-    B4C_REQUIRE(tn <= 65535, "gemm_tn: N too large");
     hipStream_t st = (hipStream_t)stream;
     const size_t shm = STAGE_BYTES;
     const bool vec16 = (lda % 8 == 0) && (ldg % 8 == 0) && ((((uintptr_t)A | (uintptr_t)G) & 15) == 0);
     if (dtype == B4C_F32)
         gemm_tn_kernel<float><<<grid, 256, shm, st>>>((const float *)A, lda, (const float *)G, ldg, out, M, K, N, chunk);
     else if (vec16)
-        gemm_tn_bf16_kernel<<<grid, 256, 2 * TN_TILE_BYTES, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, out, M, K, N, chunk);
+        gemm_tn_bf16_kernel<2><<<grid, 256, 2 * TN_TILE_BYTES, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, out, M, K, N, chunk);
     else
         gemm_tn_kernel<bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, out, M, K, N, chunk);
+    if (out.mode == TN_WS)
+        tn_reduce_kernel<<<tk * tn * 256 + tn, 1024, 0, st>>>(out, K, N, tk, tn, (int)nsplit);
     return b4c_check_launch("gemm_tn");
 }
 
 extern "C" int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float *dW, int ldw, float *db, int M, int K,
-                           int N, int dtype, void *stream) {
+                           int N, int dtype, void *workspace, int64_t workspace_bytes, void *stream) {
     B4C_REQUIRE(ldw >= N, "gemm_tn: ldw %d < N %d", ldw, N);
-    TNOut out = {{dW, nullptr, nullptr, nullptr}, {db, nullptr, nullptr, nullptr}, N, ldw};
-    return gemm_tn_launch(A, lda, G, ldg, out, M, K, N, dtype, stream);
+    TNOut out = {{dW, nullptr, nullptr, nullptr}, {db, nullptr, nullptr, nullptr}, N, ldw, TN_ATOMIC, nullptr, nullptr};
+    return gemm_tn_launch(A, lda, G, ldg, out, M, K, N, dtype, workspace, workspace_bytes, stream);
 }
 
 extern "C" int b4c_gemm_tn_seg(const void *A, int lda, const void *G, int ldg, int n_seg, float *const *h_dW,
-                               float *const *h_db, int seg_width, int M, int K, int dtype, void *stream) {
+                               float *const *h_db, int seg_width, int M, int K, int dtype, void *workspace,
+                               int64_t workspace_bytes, void *stream) {
     B4C_REQUIRE(n_seg >= 1 && n_seg <= 4 && seg_width > 0 && h_dW, "gemm_tn_seg: n_seg %d / seg_width %d", n_seg, seg_width);
-    TNOut out = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}, seg_width, seg_width};
+    TNOut out = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}, seg_width, seg_width, TN_ATOMIC, nullptr, nullptr};
     for (int i = 0; i < n_seg; ++i) {
         B4C_REQUIRE(h_dW[i] && (!h_db || h_db[i] || !h_db[0]), "gemm_tn_seg: null segment pointer %d", i);
         out.dW[i] = h_dW[i];
         out.db[i] = h_db ? h_db[i] : nullptr;
     }
-    return gemm_tn_launch(A, lda, G, ldg, out, M, K, n_seg * seg_width, dtype, stream);
+    return gemm_tn_launch(A, lda, G, ldg, out, M, K, n_seg * seg_width, dtype, workspace, workspace_bytes, stream);
 }

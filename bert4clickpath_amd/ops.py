@@ -194,8 +194,26 @@ def gemm_tn(a, g, K, N, want_bias=True, into=None):
     return _gemm_tn_impl(a, g, K, N, want_bias, into)
 
 
+_tn_ws = {}      # device -> scratch for the split partial tiles of gemm_tn (shared by all calls of a stream)
+tn_deterministic = True     # False: no workspace, partial tiles are added with float atomics
+
+
+def _tn_workspace(a, M, K, N):
+    if not tn_deterministic or M == 0:
+        return None, 0
+    need = L.lib().b4c_gemm_tn_workspace_bytes(M, K, N, dt_code(a.dtype))
+    if need == 0:
+        return None, 0
+    ws = _tn_ws.get(a.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=a.device)
+        _tn_ws[a.device] = ws
+    return ws.data_ptr(), ws.numel()
+
+
 def _gemm_tn_impl(a, g, K, N, want_bias, into):
     M = a.shape[0]
+    wsp, wsb = _tn_workspace(a, M, K, N)
     if into is not None:
         dWs, dbs = into
         if M == 0:
@@ -203,19 +221,19 @@ def _gemm_tn_impl(a, g, K, N, want_bias, into):
         n = len(dWs)
         if n == 1:
             L.check(L.lib().b4c_gemm_tn(_p(a), a.stride(0), _p(g), g.stride(0), _p(dWs[0]), N, _p(dbs[0]), M, K, N,
-                                        dt_code(a.dtype), _st()), 'gemm_tn')
+                                        dt_code(a.dtype), wsp, wsb, _st()), 'gemm_tn')
         else:
             wa = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dWs])
             ba = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dbs])
             L.check(L.lib().b4c_gemm_tn_seg(_p(a), a.stride(0), _p(g), g.stride(0), n, wa, ba, N // n, M, K,
-                                            dt_code(a.dtype), _st()), 'gemm_tn_seg')
+                                            dt_code(a.dtype), wsp, wsb, _st()), 'gemm_tn_seg')
         return None, None
     dW = torch.zeros(K, N, dtype=torch.float32, device=a.device)
     db = torch.zeros(N, dtype=torch.float32, device=a.device) if want_bias else None
     if M == 0:
         return dW, db
     L.check(L.lib().b4c_gemm_tn(_p(a), a.stride(0), _p(g), g.stride(0), _p(dW), N, _p(db), M, K, N,
-                                dt_code(a.dtype), _st()), 'gemm_tn')
+                                dt_code(a.dtype), wsp, wsb, _st()), 'gemm_tn')
     return dW, db
 
 

@@ -104,15 +104,22 @@ int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void *C, int ld
                 const float *bias, int act, const void *gate, int ldg, const void *residual, int ldr,
                 int dtype, int out_dtype, void *stream);
 
-/* dW[K][N] (+)= A[M][K]^T . G[M][N]   and  db[N] (+)= colsum(G)   (fp32 outputs, float atomics:
- * the caller zeroes dW / db; db may be NULL).  Reduction runs over the M (token) axis. */
+/* dW[K][N] += A[M][K]^T . G[M][N]   and  db[N] += colsum(G)   (fp32 outputs ADDED to what is there: the
+ * caller zeroes or accumulates; db may be NULL).  The reduction over the M (token) axis is split over
+ * workgroups when the output has few 128x128 tiles; the partial tiles are then summed
+ *   - through `workspace` (device memory, 16-B aligned, >= b4c_gemm_tn_workspace_bytes(M,K,N,dtype)) in a
+ *     fixed order: deterministic, no atomics.  The workspace is scratch: it may be shared by every call on
+ *     the same stream;
+ *   - with float atomics if workspace is NULL or too small (order-dependent rounding). */
+int64_t b4c_gemm_tn_workspace_bytes(int M, int K, int N, int dtype);
 int b4c_gemm_tn(const void *A, int lda, const void *G, int ldg, float *dW, int ldw, float *db, int M, int K,
-                int N, int dtype, void *stream);
+                int N, int dtype, void *workspace, int64_t workspace_bytes, void *stream);
 /* same with N = n_seg * seg_width cut into n_seg (<= 4) column segments, each accumulated into its own
  * dW_i [K][seg_width] / db_i [seg_width] (HOST arrays of device pointers): the fused Q|K|V projection
  * adds straight into the three gradient tensors. */
 int b4c_gemm_tn_seg(const void *A, int lda, const void *G, int ldg, int n_seg, float *const *h_dW,
-                    float *const *h_db, int seg_width, int M, int K, int dtype, void *stream);
+                    float *const *h_db, int seg_width, int M, int K, int dtype, void *workspace,
+                    int64_t workspace_bytes, void *stream);
 
 /* ---- R8: attention -------------------------------------------------------------------
  * replaces MultiHeadAttention.split_heads + scaled_dot_product_attention + merge
