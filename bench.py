@@ -47,6 +47,8 @@ def parse():
     ap.add_argument('--n_batches', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_rows', type=int, default=48, help='sequences in the bounded CPU-baseline sample')
+    ap.add_argument('--materialised_logits', action='store_true',
+                    help='A/B: vocabulary projection writes the (R x V) logits and the CE reads them (ops.flash_ce = False)')
     ap.add_argument('--traffic_json', default=None, help='optional JSON with PMC-derived HBM bytes per launch')
     return ap.parse_args()
 
@@ -133,7 +135,9 @@ KERNEL_OF = {   # launch family (ops recorder) -> kernel symbol(s) in the rocpro
     'gemm_nt': 'gemm_nt_kernel / gemm_nt_wide_kernel (dense fwd + dX)', 'gemm_tn': 'gemm_tn_bf16_kernel (dW)',
     'attn_fwd': 'attn_fwd_mfma_kernel', 'attn_bwd': 'attn_bwd_resident_kernel', 'softmax_ce': 'softmax_ce_bf16_kernel',
     'add_ln_fwd': 'add_ln_fwd_kernel', 'add_ln_bwd': 'add_ln_bwd_kernel', 'embed_fwd': 'embed_fwd_kernel',
-    'embed_bwd': 'embed_bwd_kernel', 'adam': 'adam_kernel'}
+    'embed_bwd': 'embed_bwd_kernel', 'adam': 'adam_kernel',
+    'vocab_ce_fwd': 'vce_token_kernel<128,0|1|2> + vce_combine_kernel (projection + softmax CE + dX, logits in registers)',
+    'vocab_ce_dw': 'vce_dw_kernel + vce_label_kernel (projection dW / db, logits recomputed)'}
 
 
 def roofline_from(fams, steps, peak_tf):
@@ -166,6 +170,8 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
 
+    if a.materialised_logits:
+        ops.flash_ce = False
     model = build_model(a, device)
     opt = optim.Adam(model.parameters(), order=backward_order(model))
     arena = opt.arena

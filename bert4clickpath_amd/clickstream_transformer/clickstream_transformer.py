@@ -217,9 +217,10 @@ class ClickstreamTransformer(nn.Module):
         lab = lab.to(torch.int32).contiguous()
         if lab.shape[0] != rows.shape[0]:
             raise ValueError('%d labels for %d masked positions' % (lab.shape[0], rows.shape[0]))
-        logits = self.head.logits(rows)
-        V = self.head.output_vocab_size
-        return ops.FusedSoftmaxCEFn.apply(logits, lab, V, CE_TF if variant == 'tf' else CE_PLAIN, unit_grad)
+        code = CE_TF if variant == 'tf' else CE_PLAIN
+        if hasattr(self.head, 'cloze_ce'):
+            return self.head.cloze_ce(rows, lab, code, unit_grad)
+        return ops.FusedSoftmaxCEFn.apply(self.head.logits(rows), lab, self.head.output_vocab_size, code, unit_grad)
 
     @torch.no_grad()
     def predict_topk(self, inputs, k, labels=None, flat_idx=None):

@@ -58,6 +58,27 @@ class SoftMaxHead(nn.Module):
         need_tape = torch.is_grad_enabled()
         return ops.MLPFn.apply(x2d, self._packs, need_tape, out_fp32, *self._params())
 
+    def trunk(self, x2d):
+        """relu(Dense) x n of head.py:35 alone: the input of the vocabulary projection."""
+        if self.output_layer is None:
+            self.build(x2d.shape[-1])
+            self.to(x2d.device)
+        if not self.intermediate_layers:
+            return x2d
+        return ops.MLPFn.apply(x2d, self._packs[:-1], torch.is_grad_enabled(), 'relu_last', *self._params()[:-2])
+
+    def cloze_ce(self, x2d, labels_i32, variant, unit_grad=True):
+        """Mean over valid rows of the sparse CE of softmax(Dense(V)(trunk(x))) -- loss only, for training.
+        bf16 with a 64 / 128-wide projection input: the logits are never materialised (ops.VocabCEFn);
+        otherwise logits + fused softmax / CE (ops.FusedSoftmaxCEFn)."""
+        V = self.output_vocab_size
+        h = self.trunk(x2d)
+        K = self.output_layer.kernel.shape[0]
+        if ops.flash_ce and ops.vocab_ce_supported(h, K):
+            return ops.VocabCEFn.apply(h, self._packs[-1], labels_i32, V, variant, unit_grad,
+                                       self.output_layer.kernel, self.output_layer.bias)
+        return ops.FusedSoftmaxCEFn.apply(self.logits(x2d), labels_i32, V, variant, unit_grad)
+
     def forward(self, inputs, **kwargs):
         """inputs (B, M, d) -> probabilities (B, M, V), materialised as the reference does."""
         shp = inputs.shape

@@ -1,0 +1,664 @@
+// Vocabulary projection + softmax + masked sparse cross-entropy WITHOUT the (rows x V) logits in HBM
+// (bf16 throughput path of R12-R14: head.py:36 Dense(V, softmax), utils.py:56-134, losses.py:31-98).
+//
+// At C2 the materialised form moves the 4.1 GB logits tensor through HBM five times per step (projection
+// write, CE read + write, dX read, dW read).  The MI355X has ~300 FLOP per HBM byte to spare, so the logits
+// are recomputed instead: 128 x 128 tiles of  x = h W^T + b  live only in MFMA accumulators, three times:
+//
+//   K1  stats   (token-owned)  running max / sum-exp / min of every row             -> lse, "clipped" flag
+//   K2  U       (token-owned)  p = exp(x - lse) feeds  U = P W  from the accumulator registers (the P^T tile
+//                              is the B operand of the next MFMA, as in the attention kernels);
+//                              MODE 1 repeats the sweep for rows whose probabilities leave [1e-7, 1-1e-7]
+//                              (TF's clip, backend.py sparse_categorical_crossentropy): Ud = P(1-u) W, S, Pu
+//   K3  combine (row)          loss, dh = gs (Uc / S - G U - yd W_y), row scalars for K4
+//   K4  dW      (vocab-owned)  dlogit = p (u a - b) feeds  dW^T = h^T dlogit  from registers; db = colsum
+//   K5  label term             dW[:, y] -= yd h_row,  db[y] -= yd
+//
+// HBM traffic: h, W (L2 / MALL resident, 12.8 MB), per-row partial sums.  Work: 5 GEMM units + 3 R V exps.
+//
+// MFMA 32x32x16 bf16 maps (lane l: r = l & 31, hf = l >> 5): A[row r][k = 8 hf + j], B[k = 8 hf + j][col r],
+// D reg t: row (t&3) + 8 (t>>2) + 4 hf, col r.  An accumulator tile used as B operand of the next MFMA sums
+// over its rows in the order 16 s + 8 (j>>2) + 4 hf + (j&3); the A operand reads the same order through
+// ds_read_b64_tr_b16.
+#include <math.h>
+
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned vu32x4;
+typedef __attribute__((ext_vector_type(4))) short vs16x4;
+typedef __attribute__((ext_vector_type(8))) short vs16x8;
+
+#define VCE_EPS 1e-7f
+#define VCE_LOG2E 1.4426950408889634f
+#define VCE_LN2 0.6931471805599453f
+
+__device__ __forceinline__ int vce_rowmap(int t, int hf) { return (t & 3) + 8 * (t >> 2) + 4 * hf; }
+__device__ __forceinline__ bf16x8 vce_pack8(const float *p) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)p[j];
+    return v;
+}
+__device__ __forceinline__ bf16x8 vce_frag_tr(const char *p, int second_off) {
+    const vs16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((vs16x4 __attribute__((address_space(3))) *)(p));
+    const vs16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((vs16x4 __attribute__((address_space(3))) *)(p + second_off));
+    const vs16x8 w = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vce_rsrc(const void *base, int64_t rows, int64_t row_bytes) {
+    int64_t bytes = (rows < 0 ? 0 : rows) * row_bytes;
+    if (bytes > 0x3FFFFFF0ll) bytes = 0x3FFFFFF0ll;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (unsigned)bytes, 0x00020000);
+}
+
+// A [128 rows][KD] bf16 tile in flight: 16-B chunks, CH = KD / 8 per row, 512 threads.
+template <int KD> struct VTile {
+    static constexpr int CH = KD / 8;
+    static constexpr int NIT = 128 * CH / 512;   // 4 (KD = 128) or 2 (KD = 64)
+    static constexpr int STR = KD * 2 + 16;      // LDS row stride, bytes
+    vu32x4 reg[NIT];
+    // rows [row0, row0 + 128) of P (row pitch ld elements); rows >= nrows read as zeros
+    __device__ __forceinline__ void load(const bf16_t *__restrict__ P, int ld, int64_t row0, int64_t nrows, int tid) {
+        const int64_t left = nrows - row0;
+        const __amdgpu_buffer_rsrc_t rs = vce_rsrc(P + row0 * ld, left < 128 ? left : 128, (int64_t)ld * 2);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int c = tid + i * 512;
+            reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((c / CH) * ld + (c % CH) * 8) * 2, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void store(char *s, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int c = tid + i * 512;
+            *reinterpret_cast<vu32x4 *>(s + (c / CH) * STR + (c % CH) * 16) = reg[i];
+        }
+    }
+};
+
+// The lane's token row of h as MFMA B fragments (KD / 16 k-steps)
+template <int KD>
+__device__ __forceinline__ void vce_load_hfrag(const bf16_t *__restrict__ h, int ld_h, int64_t tok, int64_t R, int hf, bf16x8 (&f)[KD / 16]) {
+#pragma unroll
+    for (int ks = 0; ks < KD / 16; ++ks) {
+        vu32x4 v = {0u, 0u, 0u, 0u};
+        if (tok < R) v = *reinterpret_cast<const vu32x4 *>(h + tok * ld_h + ks * 16 + hf * 8);
+        f[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+struct VceArgs {
+    const bf16_t *h;      // [R][ld_h]
+    const bf16_t *wt;     // [V][ld_w]  (vocab-major rows of KD)
+    const float *bias;    // [V] or NULL
+    const int32_t *labels;
+    const float *grad_scale;   // device scalar: d(total loss) / d(row loss)
+    float *st1;           // [parts][R][4]: m, l, min, -
+    float *u;             // [parts][R][KD]
+    float *ud;            // [parts][R][KD]
+    float *sp;            // [parts][R][2]: S, Pu
+    float *rowscal;       // [R][8]: lse2, a, b, clipped, yd, -, -, -
+    float *item_loss;     // [R]
+    bf16_t *dh;           // [R][ld_dh]
+    int ld_h, ld_w, ld_dh;
+    int64_t R;
+    int V, parts, variant;
+};
+
+// merge the K1 partial statistics of one row: lse (natural log), clipped flag
+__device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, float &lse, bool &clipped) {
+    float m = -INFINITY, l = 0.f, mn = INFINITY;
+    for (int p = 0; p < a.parts; ++p) {
+        const f32x4 s = *reinterpret_cast<const f32x4 *>(a.st1 + ((int64_t)p * a.R + row) * 4);
+        const float M = fmaxf(m, s[0]);
+        l = l * __builtin_amdgcn_exp2f((m - M) * VCE_LOG2E) + s[1] * __builtin_amdgcn_exp2f((s[0] - M) * VCE_LOG2E);
+        m = M;
+        mn = fminf(mn, s[2]);
+    }
+    lse = m + __logf(l);
+    const float pmin = __expf(mn - lse), pmax = __expf(m - lse);
+    clipped = (a.variant == B4C_CE_TF) && (pmin < VCE_EPS || pmax > 1.0f - VCE_EPS);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 / K2: one workgroup = 128 tokens x one part of the vocabulary; 8 waves = 4 token groups (32 tokens on
+// the lanes) x 2 vocabulary halves of each 128-row W tile.  MODE: 0 = stats, 1 = U, 2 = Ud / S / Pu.
+// ------------------------------------------------------------------------------------------
+template <int KD, int MODE>
+__global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NKS = KD / 16, NDT = KD / 32, STR = VTile<KD>::STR;
+    constexpr int TILE_B = 128 * STR;
+    float *sBias = reinterpret_cast<float *>(smem + 2 * TILE_B);     // [2][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int li = lane & 15, g = lane >> 4;
+    const int tg = wave & 3, vh = wave >> 2;
+    const int64_t tok0 = (int64_t)blockIdx.x * 128;
+    const int64_t tok = tok0 + tg * 32 + r;
+    const int part = blockIdx.y;
+    const int nvt = (a.V + 127) >> 7;
+    const int vt0 = (int)((int64_t)nvt * part / a.parts), vt1 = (int)((int64_t)nvt * (part + 1) / a.parts);
+
+    float lse2 = INFINITY;   // log2-domain lse of the lane's token (MODE >= 1)
+    if (MODE >= 1) {
+        bool clipped = false;
+        if (tok < a.R) {
+            float lse;
+            vce_row_stats(a, tok, lse, clipped);
+            lse2 = lse * VCE_LOG2E;
+        }
+        if (MODE == 2 && !__syncthreads_or(clipped)) return;   // no clipped row in these 128 tokens
+    }
+    bf16x8 hfr[NKS];
+    vce_load_hfrag<KD>(a.h, a.ld_h, tok, a.R, hf, hfr);
+
+    VTile<KD> wt;
+    float breg = 0.f;
+    auto fetch = [&](int vt) {
+        wt.load(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, tid);
+        if (tid < 128) {
+            const int v = vt * 128 + tid;
+            breg = (vt < vt1 && v < a.V) ? (a.bias ? a.bias[v] : 0.f) : -INFINITY;   // rows past V: logit = -inf
+        }
+    };
+    auto commit = [&](int buf) {
+        wt.store(smem + buf * TILE_B, tid);
+        if (tid < 128) sBias[buf * 128 + tid] = breg;
+    };
+    fetch(vt0);
+    commit(0);
+    fetch(vt0 + 1);
+    __syncthreads();
+
+    // running state of the lane's token over its (hf, vh) share of the vocabulary
+    float m = -INFINITY, l = 0.f, mn = INFINITY;   // MODE 0
+    float S = 0.f, Pu = 0.f;                       // MODE 2
+    f32x16 U[NDT];
+    if (MODE >= 1) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) U[dt][t] = 0.f;
+    }
+
+    for (int vt = vt0; vt < vt1; ++vt) {
+        const int buf = (vt - vt0) & 1;
+        const char *w = smem + buf * TILE_B;
+        const float *bs = sBias + buf * 128;
+        f32x16 acc[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vh * 64 + rt * 32 + 8 * tq + 4 * hf);
+                acc[rt][4 * tq] = b4[0]; acc[rt][4 * tq + 1] = b4[1]; acc[rt][4 * tq + 2] = b4[2]; acc[rt][4 * tq + 3] = b4[3];
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(w + (vh * 64 + rt * 32 + r) * STR + ks * 32 + hf * 16);
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hfr[ks], acc[rt], 0, 0, 0);
+            }
+        }
+        const bool tail = (vt + 1) * 128 > a.V;      // some rows of this tile are past V (their logit is -inf)
+        if (MODE == 0) {
+            float tm = -INFINITY;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) tm = fmaxf(tm, acc[rt][t]);
+            if (!tail) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) mn = fminf(mn, acc[rt][t]);
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        if (vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V) mn = fminf(mn, acc[rt][t]);
+            }
+            const float M = fmaxf(m, tm);
+            if (M > -INFINITY) {
+                const float Mb = M * VCE_LOG2E;
+                float s = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) s += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -Mb));
+                l = l * __builtin_amdgcn_exp2f(m * VCE_LOG2E - Mb) + s;
+                m = M;
+            }
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float p[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -lse2));
+                    if (MODE == 2) {
+                        const bool valid = !tail || (vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V);
+                        const float pc = __builtin_amdgcn_fmed3f(pv, VCE_EPS, 1.0f - VCE_EPS);
+                        const bool un = pc == pv;              // inside the clip range
+                        if (valid) { S += pc; Pu += un ? pv : 0.f; }
+                        pv = (un || !valid) ? 0.f : pv;        // the clipped part feeds Ud
+                    }
+                    p[t] = pv;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pf = vce_pack8(p + 8 * s2);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        // W^T[d = dt*32 + r][vocab rows 16 s2 + 4 hf + {0..3, 8..11} of this 32-row tile]
+                        const char *wb = w + (vh * 64 + rt * 32 + 16 * s2 + 4 * hf + (li >> 2)) * STR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
+                        const bf16x8 wtf = vce_frag_tr(wb, 8 * STR);
+                        U[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wtf, pf, U[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // the other buffer was last read one tile ago (behind the previous barrier)
+        commit(buf ^ 1);
+        fetch(vt + 2);
+        B4C_LDS_BARRIER();
+    }
+    __syncthreads();   // all tiles consumed: LDS is reused below
+
+    if (MODE == 0) {
+        f32x4 *sS = reinterpret_cast<f32x4 *>(smem);     // [wave][lane]
+        sS[wave * 64 + lane] = (f32x4){m, l, mn, 0.f};
+        __syncthreads();
+        if (tid < 128 && tok0 + tid < a.R) {
+            const int tgi = tid >> 5, ri = tid & 31;
+            float M = -INFINITY, L = 0.f, MN = INFINITY;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 s = sS[(tgi + 4 * (q >> 1)) * 64 + ri + 32 * (q & 1)];
+                const float M2 = fmaxf(M, s[0]);
+                if (M2 > -INFINITY)
+                    L = L * __builtin_amdgcn_exp2f((M - M2) * VCE_LOG2E) + s[1] * __builtin_amdgcn_exp2f((s[0] - M2) * VCE_LOG2E);
+                M = M2;
+                MN = fminf(MN, s[2]);
+            }
+            *reinterpret_cast<f32x4 *>(a.st1 + ((int64_t)part * a.R + tok0 + tid) * 4) = (f32x4){M, L, MN, 0.f};
+        }
+        return;
+    }
+    // U^T tiles -> LDS [token][d] per wave, then the two vocabulary halves are summed and stored row-major
+    constexpr int USTR = KD + 4;                         // floats per token row
+    float *sU = reinterpret_cast<float *>(smem) + wave * 32 * USTR;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            const f32x4 v = {U[dt][4 * tq], U[dt][4 * tq + 1], U[dt][4 * tq + 2], U[dt][4 * tq + 3]};
+            *reinterpret_cast<f32x4 *>(sU + r * USTR + dt * 32 + 8 * tq + 4 * hf) = v;
+        }
+    float *sSP = reinterpret_cast<float *>(smem) + 8 * 32 * USTR;   // [wave][lane][2]
+    if (MODE == 2) {
+        sSP[(wave * 64 + lane) * 2] = S;
+        sSP[(wave * 64 + lane) * 2 + 1] = Pu;
+    }
+    __syncthreads();
+    float *dst = (MODE == 1 ? a.u : a.ud) + (int64_t)part * a.R * KD;
+    for (int c = tid; c < 128 * (KD / 4); c += 512) {
+        const int t = c / (KD / 4), q = c % (KD / 4);
+        if (tok0 + t < a.R) {
+            const float *p0 = reinterpret_cast<const float *>(smem) + ((t >> 5) * 32 + (t & 31)) * USTR + q * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(p0) + *reinterpret_cast<const f32x4 *>(p0 + 4 * 32 * USTR);
+            *reinterpret_cast<f32x4 *>(dst + (tok0 + t) * KD + q * 4) = v;
+        }
+    }
+    if (MODE == 2 && tid < 128 && tok0 + tid < a.R) {
+        const int tgi = tid >> 5, ri = tid & 31;
+        float s = 0.f, pu = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = ((tgi + 4 * (q >> 1)) * 64 + ri + 32 * (q & 1)) * 2;
+            s += sSP[idx];
+            pu += sSP[idx + 1];
+        }
+        float *o = a.sp + ((int64_t)part * a.R + tok0 + tid) * 2;
+        o[0] = s;
+        o[1] = pu;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: one wave per row.  loss, dh, row scalars for the dW sweep.
+//   dL/dx_j = p_j (u_j / S - G) - [j = y] u_y p_y / clip(p_y),  G = Pu / S - u_y p_y / clip(p_y)
+//   (u = 1, S = 1, G = 0 on rows that never leave the clip range; plain variant: p_j - [j = y])
+// ------------------------------------------------------------------------------------------
+template <int KD>
+__global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.R) return;
+    constexpr int E = KD / 64;      // elements per lane (1 or 2), consecutive
+    const int y = a.labels[row];
+    const bool valid = y >= 0 && y < a.V;
+    float *rs = a.rowscal + row * 8;
+    bf16_t *dh = a.dh + row * a.ld_dh;
+    if (!valid) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) dh[lane * E + e] = (bf16_t)0.f;
+        if (lane == 0) {
+            a.item_loss[row] = (y >= a.V) ? NAN : 0.f;
+            *reinterpret_cast<f32x4 *>(rs) = (f32x4){INFINITY, 0.f, 0.f, 0.f};     // lse2 = +inf: p = 0
+            *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    float lse;
+    bool clipped;
+    vce_row_stats(a, row, lse, clipped);
+    float U[E], Ud[E], hv[E], wy[E];
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int d = lane * E + e;
+        U[e] = 0.f;
+        Ud[e] = 0.f;
+        for (int p = 0; p < a.parts; ++p) {
+            U[e] += a.u[((int64_t)p * a.R + row) * KD + d];
+            if (clipped) Ud[e] += a.ud[((int64_t)p * a.R + row) * KD + d];
+        }
+        hv[e] = (float)a.h[row * a.ld_h + d];
+        wy[e] = (float)a.wt[(int64_t)y * a.ld_w + d];
+        dot += hv[e] * wy[e];
+    }
+    dot = wave_sum(dot);
+    const float xy = dot + (a.bias ? a.bias[y] : 0.f);
+    const float py = __expf(xy - lse);
+    const float gs = a.grad_scale[0];
+    float loss, invS = 1.f, G = 0.f, yd = 1.f;
+    if (clipped) {
+        float S = 0.f, Pu = 0.f;
+        for (int p = 0; p < a.parts; ++p) {
+            S += a.sp[((int64_t)p * a.R + row) * 2];
+            Pu += a.sp[((int64_t)p * a.R + row) * 2 + 1];
+        }
+        const float pyc = __builtin_amdgcn_fmed3f(py, VCE_EPS, 1.0f - VCE_EPS);
+        const float uy = (pyc == py) ? 1.f : 0.f;
+        invS = 1.0f / S;
+        yd = uy * py / pyc;
+        G = Pu * invS - yd;
+        loss = logf(S) - logf(pyc);
+    } else {
+        loss = lse - xy;          // -log p_y
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const float v = (U[e] - Ud[e]) * invS - G * U[e] - yd * wy[e];
+        dh[lane * E + e] = (bf16_t)(v * gs);
+    }
+    if (lane == 0) {
+        a.item_loss[row] = loss;
+        *reinterpret_cast<f32x4 *>(rs) = (f32x4){lse * VCE_LOG2E, gs * invS, gs * G, clipped ? 1.f : 0.f};
+        *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){gs * yd, 0.f, 0.f, 0.f};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: one workgroup = 128 vocabulary rows x one split of the token tiles; 8 waves = 4 vocabulary groups
+// (32 ids on the lanes) x 2 token halves of each 128-token h tile.
+//   x[tok][v] = h W^T + b;  dlogit = p (u a - b');  dW^T[d][v] += h^T dlogit;  db[v] += colsum
+// ------------------------------------------------------------------------------------------
+struct VceDwArgs {
+    const bf16_t *h;
+    const bf16_t *wt;
+    const float *bias;
+    const float *rowscal;
+    float *dW;           // [KD][ldw] fp32 (Keras kernel layout [in][out])
+    float *db;           // [V] or NULL
+    int ld_h, ld_w, ldw;
+    int64_t R;
+    int V, tsplit;
+};
+
+template <int KD>
+__global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NKS = KD / 16, NDT = KD / 32, STR = VTile<KD>::STR;
+    constexpr int TILE_B = 128 * STR;
+    f32x4 *sRow = reinterpret_cast<f32x4 *>(smem + 2 * TILE_B);      // [2][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int li = lane & 15, g = lane >> 4;
+    const int vg = wave & 3, th = wave >> 2;
+    const int v = blockIdx.x * 128 + vg * 32 + r;          // the lane's vocabulary id
+    const int64_t ntt = (a.R + 127) >> 7;
+    const int64_t tt0 = ntt * blockIdx.y / a.tsplit, tt1 = ntt * (blockIdx.y + 1) / a.tsplit;
+
+    bf16x8 wfr[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        vu32x4 q = {0u, 0u, 0u, 0u};
+        if (v < a.V) q = *reinterpret_cast<const vu32x4 *>(a.wt + (int64_t)v * a.ld_w + ks * 16 + hf * 8);
+        wfr[ks] = __builtin_bit_cast(bf16x8, q);
+    }
+    const float bv = (v < a.V) ? (a.bias ? a.bias[v] : 0.f) : -INFINITY;
+
+    VTile<KD> ht;
+    f32x4 rreg = {INFINITY, 0.f, 0.f, 0.f};
+    auto fetch = [&](int64_t tt) {
+        ht.load(a.h, a.ld_h, tt * 128, tt < tt1 ? a.R : 0, tid);
+        if (tid < 128) {
+            const int64_t row = tt * 128 + tid;
+            rreg = (tt < tt1 && row < a.R) ? *reinterpret_cast<const f32x4 *>(a.rowscal + row * 8) : (f32x4){INFINITY, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&](int buf) {
+        ht.store(smem + buf * TILE_B, tid);
+        if (tid < 128) sRow[buf * 128 + tid] = rreg;
+    };
+    fetch(tt0);
+    commit(0);
+    fetch(tt0 + 1);
+    __syncthreads();
+
+    f32x16 dW[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dW[dt][t] = 0.f;
+    float dbv = 0.f;
+
+    for (int64_t tt = tt0; tt < tt1; ++tt) {
+        const int buf = (int)(tt - tt0) & 1;
+        const char *hh = smem + buf * TILE_B;
+        const f32x4 *rs = sRow + buf * 128;
+        const bool any_clip = __any(rs[th * 64 + lane][3] != 0.f);     // the wave's 64 token rows
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x16 acc;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = bv;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 hfg = *reinterpret_cast<const bf16x8 *>(hh + (th * 64 + rt * 32 + r) * STR + ks * 32 + hf * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hfg, wfr[ks], acc, 0, 0, 0);
+            }
+            float gv[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 s = rs[th * 64 + rt * 32 + vce_rowmap(t, hf)];     // broadcast read
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t], VCE_LOG2E, -s[0]));
+                float c = s[1] - s[2];
+                if (any_clip && s[3] != 0.f) {
+                    const bool un = p >= VCE_EPS && p <= 1.0f - VCE_EPS;
+                    c = (un ? s[1] : 0.f) - s[2];
+                }
+                gv[t] = p * c;
+                dbv += gv[t];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 gf = vce_pack8(gv + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    // h^T[d = dt*32 + r][tokens 16 s2 + 4 hf + {0..3, 8..11} of this 32-token tile]
+                    const char *hb = hh + (th * 64 + rt * 32 + 16 * s2 + 4 * hf + (li >> 2)) * STR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
+                    const bf16x8 htf = vce_frag_tr(hb, 8 * STR);
+                    dW[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(htf, gf, dW[dt], 0, 0, 0);
+                }
+            }
+        }
+        commit(buf ^ 1);
+        fetch(tt + 2);
+        B4C_LDS_BARRIER();
+    }
+    __syncthreads();
+    // the two token halves are summed through LDS; [d][32 vocab] per vocabulary group
+    float *sD = reinterpret_cast<float *>(smem) + vg * (KD * 32 + 32);
+    dbv += __shfl_xor(dbv, 32);
+    if (th == 1) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) sD[(dt * 32 + vce_rowmap(t, hf)) * 32 + r] = dW[dt][t];
+        if (hf == 0) sD[KD * 32 + r] = dbv;
+    }
+    __syncthreads();
+    if (th == 0 && v < a.V) {
+        const bool direct = a.tsplit == 1;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int d = dt * 32 + vce_rowmap(t, hf);
+                const float val = dW[dt][t] + sD[d * 32 + r];
+                float *p = a.dW + (int64_t)d * a.ldw + v;
+                if (direct) *p += val;
+                else atomicAdd(p, val);
+            }
+        if (hf == 0 && a.db) {
+            const float val = dbv + sD[KD * 32 + r];
+            if (direct) a.db[v] += val;
+            else atomicAdd(a.db + v, val);
+        }
+    }
+}
+
+// K5: the [j = y] term of dlogit: dW[:, y] -= yd h_row, db[y] -= yd   (one wave per row)
+template <int KD>
+__global__ void __launch_bounds__(256) vce_label_kernel(VceDwArgs a, const int32_t *__restrict__ labels) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.R) return;
+    const int y = labels[row];
+    if (y < 0 || y >= a.V) return;
+    const float yd = a.rowscal[row * 8 + 4];
+    if (yd == 0.f) return;
+#pragma unroll
+    for (int e = 0; e < KD / 64; ++e) {
+        const int d = lane + 64 * e;
+        atomicAdd(a.dW + (int64_t)d * a.ldw + y, -yd * (float)a.h[row * a.ld_h + d]);
+    }
+    if (lane == 0 && a.db) atomicAdd(a.db + y, -yd);
+}
+
+// ------------------------------------------------------------------------------------------
+static int vce_pick_split(int64_t units, int64_t max_split) {
+    // smallest power of two <= 8 that fills the 256 CUs to >= 90 % in the last round
+    int best = 1;
+    double best_eff = 0.0;
+    for (int p = 1; p <= 8; p *= 2) {
+        if (p > max_split) break;
+        const int64_t wg = units * p;
+        const double eff = (double)wg / (double)(ceil_div64(wg, 256) * 256);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = p; }
+        if (best_eff >= 0.9) break;
+    }
+    return best;
+}
+static bool vce_shape_ok(int K) { return K == 64 || K == 128; }
+
+template <typename Kern> static void vce_allow_lds(Kern k, size_t bytes) {
+    (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+template <int KD> static size_t vce_token_lds() {
+    const size_t tiles = 2 * 128 * (size_t)VTile<KD>::STR + 2 * 128 * 4;
+    const size_t outs = (size_t)8 * 32 * (KD + 4) * 4 + 8 * 64 * 2 * 4;
+    return tiles > outs ? tiles : outs;
+}
+template <int KD> static size_t vce_dw_lds() {
+    const size_t tiles = 2 * 128 * (size_t)VTile<KD>::STR + 2 * 128 * 16;
+    const size_t outs = (size_t)4 * (KD * 32 + 32) * 4;
+    return tiles > outs ? tiles : outs;
+}
+
+extern "C" int64_t b4c_vocab_ce_workspace_bytes(int64_t R, int V, int K) {
+    if (R <= 0 || V <= 0 || !vce_shape_ok(K)) return 0;
+    return (int64_t)8 * R * (4 + 2 * (int64_t)K + 2) * 4;   // 8 = the largest vocabulary split
+}
+
+template <int KD>
+static int vce_fwd_launch(VceArgs a, hipStream_t st) {
+    const int64_t ntt = ceil_div64(a.R, 128);
+    const int nvt = (a.V + 127) / 128;
+    a.parts = vce_pick_split(ntt, nvt);
+    float *ws = a.st1;
+    a.u = ws + (int64_t)a.parts * a.R * 4;
+    a.ud = a.u + (int64_t)a.parts * a.R * KD;
+    a.sp = a.ud + (int64_t)a.parts * a.R * KD;
+    const size_t lds = vce_token_lds<KD>();
+    static thread_local bool done = false;
+    if (!done) {
+        vce_allow_lds(vce_token_kernel<KD, 0>, lds);
+        vce_allow_lds(vce_token_kernel<KD, 1>, lds);
+        vce_allow_lds(vce_token_kernel<KD, 2>, lds);
+        done = true;
+    }
+    dim3 grid((unsigned)ntt, (unsigned)a.parts);
+    vce_token_kernel<KD, 0><<<grid, 512, lds, st>>>(a);
+    vce_token_kernel<KD, 1><<<grid, 512, lds, st>>>(a);
+    if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2><<<grid, 512, lds, st>>>(a);
+    vce_combine_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a);
+    return b4c_check_launch("vocab_ce_fwd");
+}
+
+extern "C" int b4c_vocab_ce_fwd(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
+                                const float *grad_scale, float *item_loss, void *dh, int ld_dh, float *rowscal,
+                                void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, int variant, void *stream) {
+    B4C_REQUIRE(h && wt && labels && grad_scale && item_loss && dh && rowscal && workspace, "vocab_ce_fwd: null pointer");
+    B4C_REQUIRE(vce_shape_ok(K), "vocab_ce_fwd: K=%d unsupported (64 or 128)", K);
+    B4C_REQUIRE(variant == B4C_CE_TF || variant == B4C_CE_PLAIN, "vocab_ce_fwd: variant %d", variant);
+    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K && ld_dh >= K, "vocab_ce_fwd: shape");
+    B4C_REQUIRE(ld_h % 8 == 0 && ld_w % 8 == 0 && ((((uintptr_t)h | (uintptr_t)wt | (uintptr_t)workspace | (uintptr_t)rowscal) & 15) == 0),
+                "vocab_ce_fwd: operands must be 16-byte aligned with pitches % 8 == 0");
+    B4C_REQUIRE(workspace_bytes >= b4c_vocab_ce_workspace_bytes(R, V, K), "vocab_ce_fwd: workspace too small");
+    if (R == 0) return B4C_OK;
+    VceArgs a = {};
+    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.labels = labels; a.grad_scale = grad_scale;
+    a.st1 = (float *)workspace; a.rowscal = rowscal; a.item_loss = item_loss; a.dh = (bf16_t *)dh;
+    a.ld_h = ld_h; a.ld_w = ld_w; a.ld_dh = ld_dh; a.R = R; a.V = V; a.variant = variant;
+    return K == 128 ? vce_fwd_launch<128>(a, (hipStream_t)stream) : vce_fwd_launch<64>(a, (hipStream_t)stream);
+}
+
+template <int KD>
+static int vce_dw_launch(VceDwArgs a, const int32_t *labels, hipStream_t st) {
+    const int nvt = (a.V + 127) / 128;
+    const int64_t ntt = ceil_div64(a.R, 128);
+    a.tsplit = vce_pick_split(nvt, ntt);
+    const size_t lds = vce_dw_lds<KD>();
+    static thread_local bool done = false;
+    if (!done) { vce_allow_lds(vce_dw_kernel<KD>, lds); done = true; }
+    vce_dw_kernel<KD><<<dim3((unsigned)nvt, (unsigned)a.tsplit), 512, lds, st>>>(a);
+    vce_label_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a, labels);
+    return b4c_check_launch("vocab_ce_dw");
+}
+
+extern "C" int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
+                               const float *rowscal, float *dW, int ldw, float *db, int64_t R, int V, int K, void *stream) {
+    B4C_REQUIRE(h && wt && labels && rowscal && dW, "vocab_ce_dw: null pointer");
+    B4C_REQUIRE(vce_shape_ok(K), "vocab_ce_dw: K=%d unsupported (64 or 128)", K);
+    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K && ldw >= V, "vocab_ce_dw: shape");
+    B4C_REQUIRE(ld_h % 8 == 0 && ld_w % 8 == 0 && ((((uintptr_t)h | (uintptr_t)wt | (uintptr_t)rowscal) & 15) == 0),
+                "vocab_ce_dw: operands must be 16-byte aligned with pitches % 8 == 0");
+    if (R == 0) return B4C_OK;
+    VceDwArgs a = {};
+    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.rowscal = rowscal; a.dW = dW; a.db = db;
+    a.ld_h = ld_h; a.ld_w = ld_w; a.ldw = ldw; a.R = R; a.V = V;
+    return K == 128 ? vce_dw_launch<128>(a, labels, (hipStream_t)stream) : vce_dw_launch<64>(a, labels, (hipStream_t)stream);
+}

@@ -240,6 +240,7 @@ def _gemm_tn_impl(a, g, K, N, want_bias, into):
 # ---- in-place gradient accumulation (arena mode, optim.FlatArena): weight-gradient kernels add with float
 # atomics anyway, so they add straight into param.grad and autograd receives None for those inputs.
 inplace_grads = False
+flash_ce = True          # bf16 training: vocabulary projection + CE without the (R x V) logits (csrc/vocab_ce.hip)
 _grad_ready_cb = None       # parallel.GradReducer: called with each parameter whose gradient has just been produced
 
 
@@ -382,6 +383,47 @@ def softmax_ce_fwd_bwd_(logits, labels_i32, grad_scale, V, variant=L.CE_TF):
         L.check(L.lib().b4c_softmax_ce_fwd_bwd(_p(logits), ld, _p(labels_i32), _p(item), _p(grad_scale), R, V, variant,
                                                dt_code(logits.dtype), _st()), 'softmax_ce_fwd_bwd')
     return item
+
+
+_vce_ws = {}
+
+
+def vocab_ce_supported(h, K):
+    """The logits-free path: bf16 head input of width 64 / 128 (include/b4c.h b4c_vocab_ce_fwd)."""
+    return h.dtype == torch.bfloat16 and K in (64, 128) and h.shape[1] == K
+
+
+def vocab_ce_fwd(h, wt, bias, labels_i32, grad_scale, V, variant=L.CE_TF):
+    """h [R, K] bf16, wt [>=V, K] bf16, bias fp32 [>=V] -> (item_loss [R], dh [R, K] bf16 already scaled by
+    grad_scale, rowscal [R, 8] for vocab_ce_dw).  The (R x V) logits never exist in memory."""
+    _cuda(h)
+    R, K = h.shape
+    item = torch.empty(R, dtype=torch.float32, device=h.device)
+    dh = torch.empty(R, K, dtype=h.dtype, device=h.device)
+    rowscal = torch.empty(R, 8, dtype=torch.float32, device=h.device)
+    if R == 0:
+        return item, dh, rowscal
+    need = L.lib().b4c_vocab_ce_workspace_bytes(R, V, K)
+    ws = _vce_ws.get(h.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=h.device)
+        _vce_ws[h.device] = ws
+    nsweep = 3 if variant == L.CE_TF else 2
+    with _record('vocab_ce_fwd', R * K * 2 * 2 + V * K * 2, 2 * R * V * K * (2 * nsweep - 1)):
+        L.check(L.lib().b4c_vocab_ce_fwd(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(grad_scale),
+                                         _p(item), _p(dh), dh.stride(0), _p(rowscal), ws.data_ptr(), ws.numel(), R, V, K,
+                                         variant, _st()), 'vocab_ce_fwd')
+    return item, dh, rowscal
+
+
+def vocab_ce_dw(h, wt, bias, labels_i32, rowscal, V, dW, db):
+    """dW [K, V] fp32 += d loss / d kernel, db [V] += d loss / d bias (second half of vocab_ce_fwd)."""
+    R, K = h.shape
+    if R == 0:
+        return
+    with _record('vocab_ce_dw', R * K * 2 + V * K * 2 + V * K * 4, 4 * R * V * K):
+        L.check(L.lib().b4c_vocab_ce_dw(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(rowscal),
+                                        _p(dW), dW.stride(0), _p(db), R, V, K, _st()), 'vocab_ce_dw')
 
 
 def topk_rows(scores, V, k, labels_i32=None):
@@ -647,6 +689,8 @@ class MLPFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, packs, training, out_fp32, *params):
+        # out_fp32 == 'relu_last': every layer (also the last) is followed by relu -- the head's trunk alone
+        relu_last = out_fp32 == 'relu_last'
         acts = [x]
         n = len(packs)
         for i, pk in enumerate(packs):
@@ -654,12 +698,13 @@ class MLPFn(torch.autograd.Function):
             wt, _, bias = pk.get(x.dtype, a.shape[1], training)
             last = i == n - 1
             with _timed('vocab_proj_fwd' if last else 'head_mlp_fwd'):
-                acts.append(gemm_nt(a, wt, pk.Np, bias, act=L.ACT_NONE if last else L.ACT_RELU,
-                                    out_dtype=torch.float32 if (last and out_fp32) else None))
+                acts.append(gemm_nt(a, wt, pk.Np, bias, act=L.ACT_RELU if (relu_last or not last) else L.ACT_NONE,
+                                    out_dtype=torch.float32 if (last and out_fp32 is True) else None))
         if training:
-            ctx.save_for_backward(*acts[:-1])
+            ctx.save_for_backward(*(acts if relu_last else acts[:-1]))
             ctx.packs = packs
             ctx.params = params
+            ctx.relu_last = relu_last
         return acts[-1]
 
     @staticmethod
@@ -669,6 +714,8 @@ class MLPFn(torch.autograd.Function):
         g = dlogits
         if g.dtype != acts[0].dtype:
             g = g.to(acts[0].dtype)
+        if ctx.relu_last:
+            g = g * (acts[-1] > 0).to(g.dtype)
         g = g.contiguous()
         grads = [None] * (2 * len(packs))
         dx = None
@@ -688,6 +735,43 @@ class MLPFn(torch.autograd.Function):
                 g = gemm_nt(g, wc, a.shape[1], gate=a if i > 0 else None)
             dx = g
         return (dx, None, None, None) + tuple(grads)
+
+
+class VocabCEFn(torch.autograd.Function):
+    """R12 + R13 + R14 for training without the (R x V) logits: vocabulary projection, softmax, masked sparse
+    CE (mean over valid rows) and their backward, logits recomputed in MFMA accumulators (csrc/vocab_ce.hip).
+    apply(h, pack, labels_i32, V, variant, unit_grad, kernel, bias)"""
+
+    @staticmethod
+    def forward(ctx, h, pack, labels_i32, V, variant, unit_grad, kernel, bias):
+        h = h.contiguous()
+        wt, _, b = pack.get(h.dtype, h.shape[1], False)
+        valid = ((labels_i32 >= 0) & (labels_i32 < V)).sum().to(torch.float32)
+        scale = torch.where(valid > 0, 1.0 / valid.clamp(min=1.0), torch.zeros_like(valid)).reshape(1)
+        item, dh, rowscal = vocab_ce_fwd(h, wt, b, labels_i32, scale, V, variant)
+        ctx.save_for_backward(h, dh, rowscal, labels_i32)
+        ctx.pack, ctx.V, ctx.unit_grad = pack, V, unit_grad
+        ctx.params = (kernel, bias)
+        return item.sum() * scale[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        h, dh, rowscal, labels_i32 = ctx.saved_tensors
+        kernel, bias = ctx.params
+        if not ctx.unit_grad:
+            dh = dh * g.to(dh.dtype)
+            rowscal = rowscal.clone()
+            rowscal[:, [1, 2, 4]] *= g.to(torch.float32)
+        wt, _, b = ctx.pack.get(h.dtype, h.shape[1], False)
+        if _inplace_ok(kernel, bias):
+            vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel.grad, bias.grad)
+            _ready(kernel, bias)
+            dW = db = None
+        else:
+            dW = torch.zeros(kernel.shape, dtype=torch.float32, device=h.device)
+            db = torch.zeros(bias.shape, dtype=torch.float32, device=h.device)
+            vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, dW, db)
+        return dh, None, None, None, None, None, dW, db
 
 
 class GatherRowsFn(torch.autograd.Function):

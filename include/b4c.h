@@ -181,6 +181,23 @@ int b4c_sparse_ce_from_probs(const void *probs, int ld, const float *labels, flo
 int b4c_softmax_ce_fwd_bwd(void *logits, int ld, const int32_t *labels, float *item_loss,
                            const float *grad_scale, int64_t R, int V, int variant, int dtype, void *stream);
 
+/* ---- R12-R14 without the logits in HBM (bf16 training path) -------------------------------
+ * replaces, for training, Dense(V, softmax) (head.py:36) + cloze_output_adaptor + MaskedLoss +
+ * sparse_categorical_crossentropy (utils.py:56-134, losses.py:31-98, main.py:89) AND their backward:
+ * the (R x V) logits are recomputed tile by tile in MFMA accumulators instead of being stored.
+ *   h [R][ld_h] bf16 (head input), wt [V][ld_w] bf16 (vocabulary-major projection weights, K columns),
+ *   bias [V] fp32 or NULL, labels [R] int32 (< 0: ignored row), grad_scale: device scalar d total / d row loss.
+ * b4c_vocab_ce_fwd:  item_loss[R], dh [R][ld_dh] bf16 = grad_scale * d row_loss / d h, rowscal [R][8] fp32
+ *   (scratch handed to b4c_vocab_ce_dw); workspace >= b4c_vocab_ce_workspace_bytes(R, V, K), 16-B aligned.
+ * b4c_vocab_ce_dw:   dW [K][ldw] fp32 += d loss / d kernel (Keras layout [in][out]), db [V] += (or NULL).
+ * K in {64, 128}; variant B4C_CE_TF (clip-renormalised, as the TF backend) or B4C_CE_PLAIN. */
+int64_t b4c_vocab_ce_workspace_bytes(int64_t R, int V, int K);
+int b4c_vocab_ce_fwd(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
+                     const float *grad_scale, float *item_loss, void *dh, int ld_dh, float *rowscal,
+                     void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, int variant, void *stream);
+int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
+                    const float *rowscal, float *dW, int ldw, float *db, int64_t R, int V, int K, void *stream);
+
 /* ---- R15: top-k ids, HitRate@k / NDCG@k -------------------------------------------------
  * replaces tf.math.top_k + the Recall / NDCG update_state arithmetic (utils.py:161-190, 225-255).
  * topk_idx[R][k] int32, largest first, ties -> lower index.  labels (int32, may be NULL):

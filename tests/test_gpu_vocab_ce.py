@@ -1,0 +1,133 @@
+"""Logits-free vocabulary projection + softmax CE (csrc/vocab_ce.hip) against the CPU oracle.
+
+The reference materialises softmax(Dense(V)(h)) (head.py:36) and applies MaskedLoss + TF's sparse CE on
+probabilities (losses.py:31-98; clip [1e-7, 1-1e-7] -> log -> log-softmax).  The HIP path recomputes logits
+tiles in MFMA accumulators and must give the same loss and the same gradients (bf16 operands, fp32 sums)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from bert4clickpath_amd import ops as o
+    return o
+
+
+def _case(R, V, K, scale, seed, n_ignored=0):
+    rng = np.random.default_rng(seed)
+    h = (rng.standard_normal((R, K)) * scale).astype(np.float32)
+    W = (rng.standard_normal((V, K)) * scale).astype(np.float32)
+    b = (rng.standard_normal(V) * 0.5).astype(np.float32)
+    y = rng.integers(0, V, size=R).astype(np.int32)
+    if n_ignored:
+        y[rng.choice(R, n_ignored, replace=False)] = -1
+    # bf16-representable operands so that the fp64 oracle sees exactly what the kernels see
+    h = torch.from_numpy(h).bfloat16().float().numpy()
+    W = torch.from_numpy(W).bfloat16().float().numpy()
+    return h, W, b, y
+
+
+def _oracle(h, W, b, y, variant):
+    from oracle import torch_ref as tr
+    ht = torch.tensor(h, dtype=torch.float64, requires_grad=True)
+    Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    valid = y >= 0
+    yl = torch.tensor(np.where(valid, y, 0).astype(np.int64))
+    logits = ht @ Wt.T + bt
+    if variant == 'tf':
+        # TF computes the softmax in fp32 before clipping: the clip decisions are taken on fp32 probabilities
+        probs = torch.softmax(logits, dim=-1)
+        item = tr.sparse_ce_tf(probs, yl)
+    else:
+        item = -torch.log_softmax(logits, dim=-1).gather(1, yl[:, None])[:, 0]
+    item = item * torch.tensor(valid.astype(np.float64))
+    n = max(int(valid.sum()), 1)
+    loss = item.sum() / n
+    loss.backward()
+    return item.detach().numpy(), loss.item(), ht.grad.numpy(), Wt.grad.numpy(), bt.grad.numpy()
+
+
+CASES = [
+    # R, V, K, operand scale, ignored rows, variant
+    (300, 1000, 128, 0.3, 0, 'tf'),          # nothing clipped
+    (300, 1000, 128, 1.6, 5, 'tf'),          # many probabilities < 1e-7, some rows > 1 - 1e-7
+    (77, 50, 64, 0.5, 3, 'tf'),              # one partial vocabulary tile, partial token tile
+    (130, 129, 64, 2.0, 0, 'tf'),            # vocabulary tail of one row
+    (257, 700, 128, 1.2, 7, 'plain'),
+    (1, 300, 128, 1.0, 0, 'tf'),
+]
+
+
+@pytest.mark.parametrize('R,V,K,scale,n_ign,variant', CASES)
+def test_vocab_ce_matches_oracle(ops, R, V, K, scale, n_ign, variant):
+    from bert4clickpath_amd import _lib as L
+    h, W, b, y = _case(R, V, K, scale, seed=R * 7 + V, n_ignored=n_ign)
+    item_o, loss_o, dh_o, dW_o, db_o = _oracle(h, W, b, y, variant)
+    dev = 'cuda'
+    hd = torch.tensor(h, device=dev).bfloat16()
+    Vp = (V + 7) // 8 * 8
+    wt = torch.zeros(Vp, K, device=dev, dtype=torch.bfloat16)
+    wt[:V] = torch.tensor(W, device=dev).bfloat16()
+    bd = torch.zeros(Vp, device=dev)
+    bd[:V] = torch.tensor(b, device=dev)
+    yd = torch.tensor(y, device=dev)
+    n = max(int((y >= 0).sum()), 1)
+    gs = torch.tensor([1.0 / n], device=dev)
+    code = L.CE_TF if variant == 'tf' else L.CE_PLAIN
+    item, dh, rowscal = ops.vocab_ce_fwd(hd, wt, bd, yd, gs, V, code)
+    dW = torch.zeros(K, V, device=dev)
+    db = torch.zeros(V, device=dev)
+    ops.vocab_ce_dw(hd, wt, bd, yd, rowscal, V, dW, db)
+    item = item.cpu().numpy()
+    # loss: fp32 accumulation of bf16 products over K <= 128 terms, logsumexp over V
+    np.testing.assert_allclose(item, item_o, rtol=2e-4, atol=2e-4)
+    assert abs(float(item.sum()) / n - loss_o) < 2e-4 * max(1.0, abs(loss_o))
+    # gradients: P and dlogit pass through bf16 (8 significant bits) before their MFMA: 1 % L2 documented bound
+    # (rows whose probabilities are ALL outside the clip range have an exactly-zero gradient: the floor is 1e-3 of
+    # the unclipped gradient scale gs * |operand|, so that such cases compare absolutely)
+    def rel(a, ref, floor):
+        return np.linalg.norm(a - ref) / max(np.linalg.norm(ref), floor)
+    g = 1.0 / n
+    assert rel(dh.float().cpu().numpy(), dh_o, 1e-3 * g * np.sqrt(R) * np.linalg.norm(W, axis=1).mean()) < 1e-2
+    assert rel(dW.cpu().numpy(), dW_o.T, 1e-3 * g * np.linalg.norm(h)) < 1e-2
+    assert rel(db.cpu().numpy(), db_o, 1e-3 * g * np.sqrt(R)) < 1e-2
+    # ignored rows contribute nothing
+    ign = y < 0
+    if ign.any():
+        assert np.all(item[ign] == 0) and np.all(dh.float().cpu().numpy()[ign] == 0)
+
+
+def test_vocab_ce_accumulates_and_is_repeatable(ops):
+    from bert4clickpath_amd import _lib as L
+    R, V, K = 200, 640, 128
+    h, W, b, y = _case(R, V, K, 0.8, seed=5)
+    dev = 'cuda'
+    hd = torch.tensor(h, device=dev).bfloat16()
+    wt = torch.tensor(W, device=dev).bfloat16()
+    bd = torch.tensor(b, device=dev)
+    yd = torch.tensor(y, device=dev)
+    gs = torch.tensor([1.0 / R], device=dev)
+    i1, d1, r1 = ops.vocab_ce_fwd(hd, wt, bd, yd, gs, V, L.CE_TF)
+    i2, d2, r2 = ops.vocab_ce_fwd(hd, wt, bd, yd, gs, V, L.CE_TF)
+    assert torch.equal(i1, i2) and torch.equal(d1, d2) and torch.equal(r1, r2)
+    dW = torch.ones(K, V, device=dev)
+    db = torch.ones(V, device=dev)
+    ops.vocab_ce_dw(hd, wt, bd, yd, r1, V, dW, db)
+    dW0 = torch.zeros(K, V, device=dev)
+    db0 = torch.zeros(V, device=dev)
+    ops.vocab_ce_dw(hd, wt, bd, yd, r1, V, dW0, db0)
+    assert torch.allclose(dW, dW0 + 1.0, atol=1e-6) and torch.allclose(db, db0 + 1.0, atol=1e-6)
+
+
+def test_vocab_ce_rejects_bad_shapes(ops):
+    from bert4clickpath_amd import _lib as L
+    dev = 'cuda'
+    h = torch.zeros(8, 96, device=dev, dtype=torch.bfloat16)
+    wt = torch.zeros(16, 96, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(L.B4CError):
+        ops.vocab_ce_fwd(h, wt, torch.zeros(16, device=dev), torch.zeros(8, dtype=torch.int32, device=dev),
+                         torch.ones(1, device=dev), 16, L.CE_TF)
