@@ -22,11 +22,14 @@
 // ds_read_b64_tr_b16.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned vu32x4;
 typedef __attribute__((ext_vector_type(4))) short vs16x4;
 typedef __attribute__((ext_vector_type(8))) short vs16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define VCE_EPS 1e-7f
 #define VCE_LOG2E 1.4426950408889634f
@@ -51,12 +54,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t vce_rsrc(const void *base, int
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (unsigned)bytes, 0x00020000);
 }
 
-// A [128 rows][KD] bf16 tile in flight: 16-B chunks, CH = KD / 8 per row, 512 threads.
+// A [128 rows][KD] bf16 tile: in flight (registers) and in LDS.
+// KD = 128: rows are exactly one 256-B bank row; the 16-B chunk c of row j sits at chunk c ^ f(j),
+//   f(j) = ((j & 3) << 2) | ((j >> 2) & 3):  a transposed read (32-lane group: 4 consecutive rows x the same 64 B) and
+//   a direct fragment read (ds_read_b128 16-lane groups: rows {0-3,12-15,20-27} / {4-11,16-19,28-31}, same chunk)
+//   both land on 16 distinct 16-B slots -- no padding, no conflicts (MI355X_MICROARCH.md, LDS).
+// KD = 64: 128-B rows padded to 144 B.
 template <int KD> struct VTile {
     static constexpr int CH = KD / 8;
     static constexpr int NIT = 128 * CH / 512;   // 4 (KD = 128) or 2 (KD = 64)
-    static constexpr int STR = KD * 2 + 16;      // LDS row stride, bytes
+    static constexpr bool SWZ = KD == 128;
+    static constexpr int STR = SWZ ? 256 : KD * 2 + 16;
+    static constexpr int BYTES = 128 * STR;
     vu32x4 reg[NIT];
+    static __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+    static __device__ __forceinline__ int chunk_off(int row, int chunk) {
+        return row * STR + ((SWZ ? (chunk ^ swz(row)) : chunk) << 4);
+    }
     // rows [row0, row0 + 128) of P (row pitch ld elements); rows >= nrows read as zeros
     __device__ __forceinline__ void load(const bf16_t *__restrict__ P, int ld, int64_t row0, int64_t nrows, int tid) {
         const int64_t left = nrows - row0;
@@ -71,10 +85,25 @@ template <int KD> struct VTile {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int c = tid + i * 512;
-            *reinterpret_cast<vu32x4 *>(s + (c / CH) * STR + (c % CH) * 16) = reg[i];
+            *reinterpret_cast<vu32x4 *>(s + chunk_off(c / CH, c % CH)) = reg[i];
         }
     }
+    // per-lane offsets, relative to a row base that is a multiple of 16 rows:
+    //   direct fragment (row r, k-step ks, half hf): 16 B
+    static __device__ __forceinline__ int frag_off(int r, int ks, int hf) { return chunk_off(r, 2 * ks + hf); }
+    //   transposed fragment piece: rows 4 hf + (li >> 2) (+ 8 for the second piece), columns dt*32 + 16 (g&1) + 4 (li&3)
+    static __device__ __forceinline__ int tr_off(int hf, int li, int g, int dt, int second) {
+        const int row = 4 * hf + (li >> 2) + 8 * second;
+        const int e = dt * 32 + 16 * (g & 1) + 4 * (li & 3);
+        return chunk_off(row, e >> 3) + (e & 7) * 2;
+    }
 };
+__device__ __forceinline__ bf16x8 vce_frag_tr2(const char *p0, const char *p1) {
+    const vs16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((vs16x4 __attribute__((address_space(3))) *)(p0));
+    const vs16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((vs16x4 __attribute__((address_space(3))) *)(p1));
+    const vs16x8 w = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, w);
+}
 
 // The lane's token row of h as MFMA B fragments (KD / 16 k-steps)
 template <int KD>
@@ -93,11 +122,11 @@ struct VceArgs {
     const float *bias;    // [V] or NULL
     const int32_t *labels;
     const float *grad_scale;   // device scalar: d(total loss) / d(row loss)
-    float *st1;           // [parts][R][4]: m, l, min, -
-    float *u;             // [parts][R][KD]
-    float *ud;            // [parts][R][KD]
+    float *st1;           // [parts][R][4]: m2 (log2-domain reference), l = sum 2^(x log2e - m2), min x, max x
+    float *u;             // [parts][R][KD]: sum 2^(x log2e - m2) W   (un-normalised P W)
+    float *ud;            // [parts][R][KD]: sum over clipped p of p W (normalised)
     float *sp;            // [parts][R][2]: S, Pu
-    float *rowscal;       // [R][8]: lse2, a, b, clipped, yd, -, -, -
+    float *rowscal;       // [R][8]: lse2, c = a - b, a (negated on clipped rows), b, yd, -, -, -
     float *item_loss;     // [R]
     bf16_t *dh;           // [R][ld_dh]
     int ld_h, ld_w, ld_dh;
@@ -105,30 +134,38 @@ struct VceArgs {
     int V, parts, variant;
 };
 
-// merge the K1 partial statistics of one row: lse (natural log), clipped flag
-__device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, float &lse, bool &clipped) {
-    float m = -INFINITY, l = 0.f, mn = INFINITY;
+// merge the per-part statistics of one row: lse2 = log2 sum_j 2^(x_j log2e), clipped flag, and (optionally) the
+// factor f_p = 2^(m2_p - M2) / l that turns part p's un-normalised sums into probabilities
+__device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, float &lse2, bool &clipped) {
+    float M = -INFINITY, l = 0.f, mn = INFINITY, mx = -INFINITY;
     for (int p = 0; p < a.parts; ++p) {
         const f32x4 s = *reinterpret_cast<const f32x4 *>(a.st1 + ((int64_t)p * a.R + row) * 4);
-        const float M = fmaxf(m, s[0]);
-        l = l * __builtin_amdgcn_exp2f((m - M) * VCE_LOG2E) + s[1] * __builtin_amdgcn_exp2f((s[0] - M) * VCE_LOG2E);
-        m = M;
+        const float M2 = fmaxf(M, s[0]);
+        l = l * __builtin_amdgcn_exp2f(M - M2) + s[1] * __builtin_amdgcn_exp2f(s[0] - M2);
+        M = M2;
         mn = fminf(mn, s[2]);
+        mx = fmaxf(mx, s[3]);
     }
-    lse = m + __logf(l);
-    const float pmin = __expf(mn - lse), pmax = __expf(m - lse);
+    lse2 = M + __log2f(l);
+    const float pmin = __builtin_amdgcn_exp2f(mn * VCE_LOG2E - lse2), pmax = __builtin_amdgcn_exp2f(mx * VCE_LOG2E - lse2);
     clipped = (a.variant == B4C_CE_TF) && (pmin < VCE_EPS || pmax > 1.0f - VCE_EPS);
 }
 
 // ------------------------------------------------------------------------------------------
-// K1 / K2: one workgroup = 128 tokens x one part of the vocabulary; 8 waves = 4 token groups (32 tokens on
-// the lanes) x 2 vocabulary halves of each 128-row W tile.  MODE: 0 = stats, 1 = U, 2 = Ud / S / Pu.
+// K2: one workgroup = 128 tokens x one part of the vocabulary; 8 waves = 4 token groups (32 tokens on the
+// lanes) x 2 vocabulary halves of each 128-row W tile.
+//   MODE 1: online softmax (as flash attention with V = W): p' = 2^(x log2e - m2) against a lazily updated
+//           per-token reference m2 (raised, with U and l rescaled, only when a logit exceeds it by 2^12), P'^T
+//           feeds U += W^T P'^T from the accumulator registers.  One sweep gives lse and P W.
+//   MODE 2: second sweep for the tokens whose probabilities leave [1e-7, 1 - 1e-7]: Ud = P (1 - u) W, S, Pu.
 // ------------------------------------------------------------------------------------------
+#define VCE_LAZY 12.0f
+
 template <int KD, int MODE>
 __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NKS = KD / 16, NDT = KD / 32, STR = VTile<KD>::STR;
-    constexpr int TILE_B = 128 * STR;
+    constexpr int TILE_B = VTile<KD>::BYTES;
     float *sBias = reinterpret_cast<float *>(smem + 2 * TILE_B);     // [2][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int li = lane & 15, g = lane >> 4;
@@ -139,18 +176,22 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
     const int nvt = (a.V + 127) >> 7;
     const int vt0 = (int)((int64_t)nvt * part / a.parts), vt1 = (int)((int64_t)nvt * (part + 1) / a.parts);
 
-    float lse2 = INFINITY;   // log2-domain lse of the lane's token (MODE >= 1)
-    if (MODE >= 1) {
+    float lse2 = INFINITY;   // MODE 2: log2-domain lse of the lane's token
+    if (MODE == 2) {
         bool clipped = false;
-        if (tok < a.R) {
-            float lse;
-            vce_row_stats(a, tok, lse, clipped);
-            lse2 = lse * VCE_LOG2E;
-        }
-        if (MODE == 2 && !__syncthreads_or(clipped)) return;   // no clipped row in these 128 tokens
+        if (tok < a.R) vce_row_stats(a, tok, lse2, clipped);
+        if (!__syncthreads_or(clipped)) return;   // no clipped row in these 128 tokens
     }
     bf16x8 hfr[NKS];
     vce_load_hfrag<KD>(a.h, a.ld_h, tok, a.R, hf, hfr);
+    int foff[NKS], toff[NDT][2];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) foff[ks] = VTile<KD>::frag_off(r, ks, hf) + vh * 64 * STR;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+        toff[dt][0] = VTile<KD>::tr_off(hf, li, g, dt, 0) + vh * 64 * STR;
+        toff[dt][1] = VTile<KD>::tr_off(hf, li, g, dt, 1) + vh * 64 * STR;
+    }
 
     VTile<KD> wt;
     float breg = 0.f;
@@ -171,18 +212,18 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
     __syncthreads();
 
     // running state of the lane's token over its (hf, vh) share of the vocabulary
-    float m = -INFINITY, l = 0.f, mn = INFINITY;   // MODE 0
-    float S = 0.f, Pu = 0.f;                       // MODE 2
+    float m2 = -INFINITY, l = 0.f, mn = INFINITY, mx = -INFINITY;   // MODE 1
+    float S = 0.f, Pu = 0.f;                                        // MODE 2
     f32x16 U[NDT];
-    if (MODE >= 1) {
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) U[dt][t] = 0.f;
-    }
+        for (int t = 0; t < 16; ++t) U[dt][t] = 0.f;
 
-    for (int vt = vt0; vt < vt1; ++vt) {
-        const int buf = (vt - vt0) & 1;
+    // one vocabulary tile; the LDS buffer index is a compile-time constant (the loop is unrolled by two) so that every
+    // LDS address is a per-lane VGPR + an immediate
+    auto tile = [&](auto BUF, int vt) {
+        constexpr int buf = decltype(BUF)::value;
         const char *w = smem + buf * TILE_B;
         const float *bs = sBias + buf * 128;
         f32x16 acc[2];
@@ -195,12 +236,13 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
             }
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(w + (vh * 64 + rt * 32 + r) * STR + ks * 32 + hf * 16);
+                const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(w + rt * 32 * STR + foff[ks]);
                 acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hfr[ks], acc[rt], 0, 0, 0);
             }
         }
         const bool tail = (vt + 1) * 128 > a.V;      // some rows of this tile are past V (their logit is -inf)
-        if (MODE == 0) {
+        float e2 = lse2;                             // the exponent reference of this tile
+        if (MODE == 1) {
             float tm = -INFINITY;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -218,43 +260,48 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
                     for (int t = 0; t < 16; ++t)
                         if (vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V) mn = fminf(mn, acc[rt][t]);
             }
-            const float M = fmaxf(m, tm);
-            if (M > -INFINITY) {
-                const float Mb = M * VCE_LOG2E;
-                float s = 0.f;
+            tm = fmaxf(tm, __shfl_xor(tm, 32));      // the two lanes of a token share the reference (their P mix in U)
+            mx = fmaxf(mx, tm);
+            const float tm2 = tm * VCE_LOG2E;
+            const bool raise = tm2 > m2 + VCE_LAZY;
+            if (__any(raise)) {                       // rare after the first tile
+                if (raise) {
+                    const float al = __builtin_amdgcn_exp2f(m2 - tm2);     // 0 on the first tile (m2 = -inf)
+                    m2 = tm2;
+                    l *= al;
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) s += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -Mb));
-                l = l * __builtin_amdgcn_exp2f(m * VCE_LOG2E - Mb) + s;
-                m = M;
-            }
-        } else {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                float p[16];
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -lse2));
-                    if (MODE == 2) {
-                        const bool valid = !tail || (vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V);
-                        const float pc = __builtin_amdgcn_fmed3f(pv, VCE_EPS, 1.0f - VCE_EPS);
-                        const bool un = pc == pv;              // inside the clip range
-                        if (valid) { S += pc; Pu += un ? pv : 0.f; }
-                        pv = (un || !valid) ? 0.f : pv;        // the clipped part feeds Ud
-                    }
-                    p[t] = pv;
+                        for (int t = 0; t < 16; ++t) U[dt][t] *= al;
                 }
+            }
+            e2 = (m2 == -INFINITY) ? 0.f : m2;      // no finite logit seen yet (a tail half-tile past V): p = 2^(-inf) = 0
+        }
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 pf = vce_pack8(p + 8 * s2);
+        for (int rt = 0; rt < 2; ++rt) {
+            float p[16];
 #pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt) {
-                        // W^T[d = dt*32 + r][vocab rows 16 s2 + 4 hf + {0..3, 8..11} of this 32-row tile]
-                        const char *wb = w + (vh * 64 + rt * 32 + 16 * s2 + 4 * hf + (li >> 2)) * STR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
-                        const bf16x8 wtf = vce_frag_tr(wb, 8 * STR);
-                        U[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wtf, pf, U[dt], 0, 0, 0);
-                    }
+            for (int t = 0; t < 16; ++t) {
+                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -e2));
+                if (MODE == 1) l += pv;
+                if (MODE == 2) {
+                    const bool valid = !tail || (vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V);
+                    const float pc = __builtin_amdgcn_fmed3f(pv, VCE_EPS, 1.0f - VCE_EPS);
+                    const bool un = pc == pv;              // inside the clip range
+                    if (valid) { S += pc; Pu += un ? pv : 0.f; }
+                    pv = (un || !valid) ? 0.f : pv;        // the clipped part feeds Ud
+                }
+                p[t] = pv;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = vce_pack8(p + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    // W^T[d = dt*32 + r][vocab rows 16 s2 + 4 hf + {0..3, 8..11} of this 32-row tile]
+                    const char *wb = w + (rt * 32 + 16 * s2) * STR;
+                    const bf16x8 wtf = vce_frag_tr2(wb + toff[dt][0], wb + toff[dt][1]);
+                    U[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wtf, pf, U[dt], 0, 0, 0);
                 }
             }
         }
@@ -262,30 +309,15 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
         commit(buf ^ 1);
         fetch(vt + 2);
         B4C_LDS_BARRIER();
+    };
+    for (int vt = vt0; vt < vt1; vt += 2) {
+        tile(std::integral_constant<int, 0>{}, vt);
+        if (vt + 1 < vt1) tile(std::integral_constant<int, 1>{}, vt + 1);
     }
     __syncthreads();   // all tiles consumed: LDS is reused below
 
-    if (MODE == 0) {
-        f32x4 *sS = reinterpret_cast<f32x4 *>(smem);     // [wave][lane]
-        sS[wave * 64 + lane] = (f32x4){m, l, mn, 0.f};
-        __syncthreads();
-        if (tid < 128 && tok0 + tid < a.R) {
-            const int tgi = tid >> 5, ri = tid & 31;
-            float M = -INFINITY, L = 0.f, MN = INFINITY;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 s = sS[(tgi + 4 * (q >> 1)) * 64 + ri + 32 * (q & 1)];
-                const float M2 = fmaxf(M, s[0]);
-                if (M2 > -INFINITY)
-                    L = L * __builtin_amdgcn_exp2f((M - M2) * VCE_LOG2E) + s[1] * __builtin_amdgcn_exp2f((s[0] - M2) * VCE_LOG2E);
-                M = M2;
-                MN = fminf(MN, s[2]);
-            }
-            *reinterpret_cast<f32x4 *>(a.st1 + ((int64_t)part * a.R + tok0 + tid) * 4) = (f32x4){M, L, MN, 0.f};
-        }
-        return;
-    }
-    // U^T tiles -> LDS [token][d] per wave, then the two vocabulary halves are summed and stored row-major
+    // U^T tiles -> LDS [token][d] per wave; per-lane scalars -> LDS; then the two vocabulary halves (and the two
+    // lanes of each token) are merged and stored row-major
     constexpr int USTR = KD + 4;                         // floats per token row
     float *sU = reinterpret_cast<float *>(smem) + wave * 32 * USTR;
 #pragma unroll
@@ -295,33 +327,40 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
             const f32x4 v = {U[dt][4 * tq], U[dt][4 * tq + 1], U[dt][4 * tq + 2], U[dt][4 * tq + 3]};
             *reinterpret_cast<f32x4 *>(sU + r * USTR + dt * 32 + 8 * tq + 4 * hf) = v;
         }
-    float *sSP = reinterpret_cast<float *>(smem) + 8 * 32 * USTR;   // [wave][lane][2]
-    if (MODE == 2) {
-        sSP[(wave * 64 + lane) * 2] = S;
-        sSP[(wave * 64 + lane) * 2 + 1] = Pu;
-    }
+    f32x4 *sS = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(smem) + 8 * 32 * USTR);   // [wave][lane]
+    sS[wave * 64 + lane] = (MODE == 1) ? (f32x4){m2, l, mn, mx} : (f32x4){S, Pu, 0.f, 0.f};
     __syncthreads();
+    // token t of the tile: waves (t >> 5) and (t >> 5) + 4, lanes (t & 31) and (t & 31) + 32
     float *dst = (MODE == 1 ? a.u : a.ud) + (int64_t)part * a.R * KD;
     for (int c = tid; c < 128 * (KD / 4); c += 512) {
         const int t = c / (KD / 4), q = c % (KD / 4);
         if (tok0 + t < a.R) {
-            const float *p0 = reinterpret_cast<const float *>(smem) + ((t >> 5) * 32 + (t & 31)) * USTR + q * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(p0) + *reinterpret_cast<const f32x4 *>(p0 + 4 * 32 * USTR);
-            *reinterpret_cast<f32x4 *>(dst + (tok0 + t) * KD + q * 4) = v;
+            const float *p0 = reinterpret_cast<const float *>(smem) + t * USTR + q * 4;
+            f32x4 v0 = *reinterpret_cast<const f32x4 *>(p0), v1 = *reinterpret_cast<const f32x4 *>(p0 + 4 * 32 * USTR);
+            if (MODE == 1) {
+                const float ma = sS[(t >> 5) * 64 + (t & 31)][0], mb = sS[((t >> 5) + 4) * 64 + (t & 31)][0];
+                const float M = fmaxf(ma, mb);
+                v0 = v0 * __builtin_amdgcn_exp2f(ma - M) + v1 * __builtin_amdgcn_exp2f(mb - M);
+            } else {
+                v0 = v0 + v1;
+            }
+            *reinterpret_cast<f32x4 *>(dst + (tok0 + t) * KD + q * 4) = v0;
         }
     }
-    if (MODE == 2 && tid < 128 && tok0 + tid < a.R) {
+    if (tid < 128 && tok0 + tid < a.R) {
         const int tgi = tid >> 5, ri = tid & 31;
-        float s = 0.f, pu = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = ((tgi + 4 * (q >> 1)) * 64 + ri + 32 * (q & 1)) * 2;
-            s += sSP[idx];
-            pu += sSP[idx + 1];
+        const f32x4 a0 = sS[tgi * 64 + ri], a1 = sS[tgi * 64 + ri + 32], b0 = sS[(tgi + 4) * 64 + ri], b1 = sS[(tgi + 4) * 64 + ri + 32];
+        if (MODE == 1) {
+            const float M = fmaxf(a0[0], b0[0]);     // the two lanes of a token share m2
+            const float fa = __builtin_amdgcn_exp2f(a0[0] - M), fb = __builtin_amdgcn_exp2f(b0[0] - M);
+            *reinterpret_cast<f32x4 *>(a.st1 + ((int64_t)part * a.R + tok0 + tid) * 4) =
+                (f32x4){M, (a0[1] + a1[1]) * fa + (b0[1] + b1[1]) * fb, fminf(fminf(a0[2], a1[2]), fminf(b0[2], b1[2])),
+                        fmaxf(a0[3], b0[3])};
+        } else {
+            float *o = a.sp + ((int64_t)part * a.R + tok0 + tid) * 2;
+            o[0] = a0[0] + a1[0] + b0[0] + b1[0];
+            o[1] = a0[1] + a1[1] + b0[1] + b1[1];
         }
-        float *o = a.sp + ((int64_t)part * a.R + tok0 + tid) * 2;
-        o[0] = s;
-        o[1] = pu;
     }
 }
 
@@ -350,9 +389,10 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
         }
         return;
     }
-    float lse;
+    float lse2;
     bool clipped;
-    vce_row_stats(a, row, lse, clipped);
+    vce_row_stats(a, row, lse2, clipped);
+    const float lse = lse2 * VCE_LN2;
     float U[E], Ud[E], hv[E], wy[E];
     float dot = 0.f;
 #pragma unroll
@@ -361,7 +401,9 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
         U[e] = 0.f;
         Ud[e] = 0.f;
         for (int p = 0; p < a.parts; ++p) {
-            U[e] += a.u[((int64_t)p * a.R + row) * KD + d];
+            // part p's sums are relative to its own reference m2_p: 2^(m2_p - lse2) makes them probabilities
+            const float f = __builtin_amdgcn_exp2f(a.st1[((int64_t)p * a.R + row) * 4] - lse2);
+            U[e] += f * a.u[((int64_t)p * a.R + row) * KD + d];
             if (clipped) Ud[e] += a.ud[((int64_t)p * a.R + row) * KD + d];
         }
         hv[e] = (float)a.h[row * a.ld_h + d];
@@ -395,7 +437,8 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
     }
     if (lane == 0) {
         a.item_loss[row] = loss;
-        *reinterpret_cast<f32x4 *>(rs) = (f32x4){lse * VCE_LOG2E, gs * invS, gs * G, clipped ? 1.f : 0.f};
+        const float ra = gs * invS, rb = gs * G;
+        *reinterpret_cast<f32x4 *>(rs) = (f32x4){lse2, ra - rb, clipped ? -ra : ra, rb};
         *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){gs * yd, 0.f, 0.f, 0.f};
     }
 }
@@ -421,7 +464,7 @@ template <int KD>
 __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NKS = KD / 16, NDT = KD / 32, STR = VTile<KD>::STR;
-    constexpr int TILE_B = 128 * STR;
+    constexpr int TILE_B = VTile<KD>::BYTES;
     f32x4 *sRow = reinterpret_cast<f32x4 *>(smem + 2 * TILE_B);      // [2][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int li = lane & 15, g = lane >> 4;
@@ -438,6 +481,15 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
         wfr[ks] = __builtin_bit_cast(bf16x8, q);
     }
     const float bv = (v < a.V) ? (a.bias ? a.bias[v] : 0.f) : -INFINITY;
+    int foff[NKS], toff[NDT][2];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) foff[ks] = VTile<KD>::frag_off(r, ks, hf) + th * 64 * STR;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+        toff[dt][0] = VTile<KD>::tr_off(hf, li, g, dt, 0) + th * 64 * STR;
+        toff[dt][1] = VTile<KD>::tr_off(hf, li, g, dt, 1) + th * 64 * STR;
+    }
+    const int roff = (th * 64 + 4 * hf) * 16;       // the lane's first row-scalar entry (bytes)
 
     VTile<KD> ht;
     f32x4 rreg = {INFINITY, 0.f, 0.f, 0.f};
@@ -464,11 +516,13 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
         for (int t = 0; t < 16; ++t) dW[dt][t] = 0.f;
     float dbv = 0.f;
 
-    for (int64_t tt = tt0; tt < tt1; ++tt) {
-        const int buf = (int)(tt - tt0) & 1;
+    auto tile = [&](auto BUF, int64_t tt) {
+        constexpr int buf = decltype(BUF)::value;
         const char *hh = smem + buf * TILE_B;
         const f32x4 *rs = sRow + buf * 128;
-        const bool any_clip = __any(rs[th * 64 + lane][3] != 0.f);     // the wave's 64 token rows
+        const char *rsl = reinterpret_cast<const char *>(rs) + roff;
+        // row scalars {lse2, c = a - b, +-a, b}: a < 0 marks a row whose probabilities leave the clip range
+        const bool any_clip = __any(rs[th * 64 + lane][2] < 0.f);     // the wave's 64 token rows
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             f32x16 acc;
@@ -476,21 +530,26 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
             for (int t = 0; t < 16; ++t) acc[t] = bv;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8 hfg = *reinterpret_cast<const bf16x8 *>(hh + (th * 64 + rt * 32 + r) * STR + ks * 32 + hf * 16);
+                const bf16x8 hfg = *reinterpret_cast<const bf16x8 *>(hh + rt * 32 * STR + foff[ks]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hfg, wfr[ks], acc, 0, 0, 0);
             }
             float gv[16];
+            if (!any_clip) {      // wave-uniform
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const f32x4 s = rs[th * 64 + rt * 32 + vce_rowmap(t, hf)];     // broadcast read
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t], VCE_LOG2E, -s[0]));
-                float c = s[1] - s[2];
-                if (any_clip && s[3] != 0.f) {
-                    const bool un = p >= VCE_EPS && p <= 1.0f - VCE_EPS;
-                    c = (un ? s[1] : 0.f) - s[2];
+                for (int t = 0; t < 16; ++t) {
+                    const f32x2 s = *reinterpret_cast<const f32x2 *>(rsl + (rt * 32 + (t & 3) + 8 * (t >> 2)) * 16);   // broadcast
+                    gv[t] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t], VCE_LOG2E, -s[0])) * s[1];
+                    dbv += gv[t];
                 }
-                gv[t] = p * c;
-                dbv += gv[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const f32x4 s = *reinterpret_cast<const f32x4 *>(rsl + (rt * 32 + (t & 3) + 8 * (t >> 2)) * 16);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t], VCE_LOG2E, -s[0]));
+                    const bool un = (s[2] >= 0.f) || (p >= VCE_EPS && p <= 1.0f - VCE_EPS);
+                    gv[t] = p * ((un ? fabsf(s[2]) : 0.f) - s[3]);
+                    dbv += gv[t];
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -498,8 +557,8 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
                     // h^T[d = dt*32 + r][tokens 16 s2 + 4 hf + {0..3, 8..11} of this 32-token tile]
-                    const char *hb = hh + (th * 64 + rt * 32 + 16 * s2 + 4 * hf + (li >> 2)) * STR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
-                    const bf16x8 htf = vce_frag_tr(hb, 8 * STR);
+                    const char *hb = hh + (rt * 32 + 16 * s2) * STR;
+                    const bf16x8 htf = vce_frag_tr2(hb + toff[dt][0], hb + toff[dt][1]);
                     dW[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(htf, gf, dW[dt], 0, 0, 0);
                 }
             }
@@ -507,6 +566,10 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
         commit(buf ^ 1);
         fetch(tt + 2);
         B4C_LDS_BARRIER();
+    };
+    for (int64_t tt = tt0; tt < tt1; tt += 2) {
+        tile(std::integral_constant<int, 0>{}, tt);
+        if (tt + 1 < tt1) tile(std::integral_constant<int, 1>{}, tt + 1);
     }
     __syncthreads();
     // the two token halves are summed through LDS; [d][32 vocab] per vocabulary group
@@ -540,9 +603,11 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
     }
 }
 
-// K5: the [j = y] term of dlogit: dW[:, y] -= yd h_row, db[y] -= yd   (one wave per row)
+// K5: the [j = y] term of dlogit: dW[:, y] -= yd h_row, db[y] -= yd.  dW is [K][V] (a label touches a column),
+// so the rows are first added into a vocabulary-major scratch [V][KD] (coalesced atomics, one wave per row), which
+// is then added transposed.
 template <int KD>
-__global__ void __launch_bounds__(256) vce_label_kernel(VceDwArgs a, const int32_t *__restrict__ labels) {
+__global__ void __launch_bounds__(256) vce_label_kernel(VceDwArgs a, const int32_t *__restrict__ labels, float *__restrict__ tmp) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.R) return;
@@ -553,9 +618,26 @@ __global__ void __launch_bounds__(256) vce_label_kernel(VceDwArgs a, const int32
 #pragma unroll
     for (int e = 0; e < KD / 64; ++e) {
         const int d = lane + 64 * e;
-        atomicAdd(a.dW + (int64_t)d * a.ldw + y, -yd * (float)a.h[row * a.ld_h + d]);
+        atomicAdd(tmp + (int64_t)y * KD + d, -yd * (float)a.h[row * a.ld_h + d]);
     }
     if (lane == 0 && a.db) atomicAdd(a.db + y, -yd);
+}
+template <int KD>
+__global__ void __launch_bounds__(256) vce_label_add_kernel(float *__restrict__ dW, int ldw, const float *__restrict__ tmp, int V) {
+    __shared__ float t[32][33];
+    const int v0 = blockIdx.x * 32, d0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = v0 + ty + 8 * i;
+        t[ty + 8 * i][tx] = (v < V) ? tmp[(int64_t)v * KD + d0 + tx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = d0 + ty + 8 * i, v = v0 + tx;
+        const float x = t[tx][ty + 8 * i];
+        if (v < V && x != 0.f) dW[(int64_t)d * ldw + v] += x;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -578,19 +660,21 @@ template <typename Kern> static void vce_allow_lds(Kern k, size_t bytes) {
     (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 template <int KD> static size_t vce_token_lds() {
-    const size_t tiles = 2 * 128 * (size_t)VTile<KD>::STR + 2 * 128 * 4;
-    const size_t outs = (size_t)8 * 32 * (KD + 4) * 4 + 8 * 64 * 2 * 4;
+    const size_t tiles = 2 * (size_t)VTile<KD>::BYTES + 2 * 128 * 4;
+    const size_t outs = (size_t)8 * 32 * (KD + 4) * 4 + 8 * 64 * 16;
     return tiles > outs ? tiles : outs;
 }
 template <int KD> static size_t vce_dw_lds() {
-    const size_t tiles = 2 * 128 * (size_t)VTile<KD>::STR + 2 * 128 * 16;
+    const size_t tiles = 2 * (size_t)VTile<KD>::BYTES + 2 * 128 * 32;
     const size_t outs = (size_t)4 * (KD * 32 + 32) * 4;
     return tiles > outs ? tiles : outs;
 }
 
 extern "C" int64_t b4c_vocab_ce_workspace_bytes(int64_t R, int V, int K) {
     if (R <= 0 || V <= 0 || !vce_shape_ok(K)) return 0;
-    return (int64_t)8 * R * (4 + 2 * (int64_t)K + 2) * 4;   // 8 = the largest vocabulary split
+    const int64_t fwd = (int64_t)8 * R * (4 + 2 * (int64_t)K + 2) * 4;   // 8 = the largest vocabulary split
+    const int64_t dw = (int64_t)V * K * 4;                              // vocabulary-major scratch of the label term
+    return fwd > dw ? fwd : dw;
 }
 
 template <int KD>
@@ -605,13 +689,11 @@ static int vce_fwd_launch(VceArgs a, hipStream_t st) {
     const size_t lds = vce_token_lds<KD>();
     static thread_local bool done = false;
     if (!done) {
-        vce_allow_lds(vce_token_kernel<KD, 0>, lds);
         vce_allow_lds(vce_token_kernel<KD, 1>, lds);
         vce_allow_lds(vce_token_kernel<KD, 2>, lds);
         done = true;
     }
     dim3 grid((unsigned)ntt, (unsigned)a.parts);
-    vce_token_kernel<KD, 0><<<grid, 512, lds, st>>>(a);
     vce_token_kernel<KD, 1><<<grid, 512, lds, st>>>(a);
     if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2><<<grid, 512, lds, st>>>(a);
     vce_combine_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a);
@@ -637,7 +719,7 @@ extern "C" int b4c_vocab_ce_fwd(const void *h, int ld_h, const void *wt, int ld_
 }
 
 template <int KD>
-static int vce_dw_launch(VceDwArgs a, const int32_t *labels, hipStream_t st) {
+static int vce_dw_launch(VceDwArgs a, const int32_t *labels, float *tmp, hipStream_t st) {
     const int nvt = (a.V + 127) / 128;
     const int64_t ntt = ceil_div64(a.R, 128);
     a.tsplit = vce_pick_split(nvt, ntt);
@@ -645,13 +727,17 @@ static int vce_dw_launch(VceDwArgs a, const int32_t *labels, hipStream_t st) {
     static thread_local bool done = false;
     if (!done) { vce_allow_lds(vce_dw_kernel<KD>, lds); done = true; }
     vce_dw_kernel<KD><<<dim3((unsigned)nvt, (unsigned)a.tsplit), 512, lds, st>>>(a);
-    vce_label_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a, labels);
+    (void)hipMemsetAsync(tmp, 0, (size_t)a.V * KD * 4, st);
+    vce_label_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a, labels, tmp);
+    vce_label_add_kernel<KD><<<dim3((unsigned)((a.V + 31) / 32), KD / 32), 256, 0, st>>>(a.dW, a.ldw, tmp, a.V);
     return b4c_check_launch("vocab_ce_dw");
 }
 
 extern "C" int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
-                               const float *rowscal, float *dW, int ldw, float *db, int64_t R, int V, int K, void *stream) {
-    B4C_REQUIRE(h && wt && labels && rowscal && dW, "vocab_ce_dw: null pointer");
+                               const float *rowscal, float *dW, int ldw, float *db, void *workspace, int64_t workspace_bytes,
+                               int64_t R, int V, int K, void *stream) {
+    B4C_REQUIRE(h && wt && labels && rowscal && dW && workspace, "vocab_ce_dw: null pointer");
+    B4C_REQUIRE(workspace_bytes >= (int64_t)V * K * 4, "vocab_ce_dw: workspace too small");
     B4C_REQUIRE(vce_shape_ok(K), "vocab_ce_dw: K=%d unsupported (64 or 128)", K);
     B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K && ldw >= V, "vocab_ce_dw: shape");
     B4C_REQUIRE(ld_h % 8 == 0 && ld_w % 8 == 0 && ((((uintptr_t)h | (uintptr_t)wt | (uintptr_t)rowscal) & 15) == 0),
@@ -660,5 +746,6 @@ extern "C" int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w
     VceDwArgs a = {};
     a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.rowscal = rowscal; a.dW = dW; a.db = db;
     a.ld_h = ld_h; a.ld_w = ld_w; a.ldw = ldw; a.R = R; a.V = V;
-    return K == 128 ? vce_dw_launch<128>(a, labels, (hipStream_t)stream) : vce_dw_launch<64>(a, labels, (hipStream_t)stream);
+    return K == 128 ? vce_dw_launch<128>(a, labels, (float *)workspace, (hipStream_t)stream)
+                    : vce_dw_launch<64>(a, labels, (float *)workspace, (hipStream_t)stream);
 }

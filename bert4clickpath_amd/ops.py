@@ -393,6 +393,15 @@ def vocab_ce_supported(h, K):
     return h.dtype == torch.bfloat16 and K in (64, 128) and h.shape[1] == K
 
 
+def _vce_workspace(h, R, V, K):
+    need = L.lib().b4c_vocab_ce_workspace_bytes(R, V, K)
+    ws = _vce_ws.get(h.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=h.device)
+        _vce_ws[h.device] = ws
+    return ws
+
+
 def vocab_ce_fwd(h, wt, bias, labels_i32, grad_scale, V, variant=L.CE_TF):
     """h [R, K] bf16, wt [>=V, K] bf16, bias fp32 [>=V] -> (item_loss [R], dh [R, K] bf16 already scaled by
     grad_scale, rowscal [R, 8] for vocab_ce_dw).  The (R x V) logits never exist in memory."""
@@ -403,11 +412,7 @@ def vocab_ce_fwd(h, wt, bias, labels_i32, grad_scale, V, variant=L.CE_TF):
     rowscal = torch.empty(R, 8, dtype=torch.float32, device=h.device)
     if R == 0:
         return item, dh, rowscal
-    need = L.lib().b4c_vocab_ce_workspace_bytes(R, V, K)
-    ws = _vce_ws.get(h.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=h.device)
-        _vce_ws[h.device] = ws
+    ws = _vce_workspace(h, R, V, K)
     nsweep = 3 if variant == L.CE_TF else 2
     with _record('vocab_ce_fwd', R * K * 2 * 2 + V * K * 2, 2 * R * V * K * (2 * nsweep - 1)):
         L.check(L.lib().b4c_vocab_ce_fwd(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(grad_scale),
@@ -421,9 +426,10 @@ def vocab_ce_dw(h, wt, bias, labels_i32, rowscal, V, dW, db):
     R, K = h.shape
     if R == 0:
         return
+    ws = _vce_workspace(h, R, V, K)
     with _record('vocab_ce_dw', R * K * 2 + V * K * 2 + V * K * 4, 4 * R * V * K):
         L.check(L.lib().b4c_vocab_ce_dw(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(rowscal),
-                                        _p(dW), dW.stride(0), _p(db), R, V, K, _st()), 'vocab_ce_dw')
+                                        _p(dW), dW.stride(0), _p(db), ws.data_ptr(), ws.numel(), R, V, K, _st()), 'vocab_ce_dw')
 
 
 def topk_rows(scores, V, k, labels_i32=None):
@@ -761,7 +767,7 @@ class VocabCEFn(torch.autograd.Function):
         if not ctx.unit_grad:
             dh = dh * g.to(dh.dtype)
             rowscal = rowscal.clone()
-            rowscal[:, [1, 2, 4]] *= g.to(torch.float32)
+            rowscal[:, 1:5] *= g.to(torch.float32)      # c, +-a, b, yd are linear in the upstream gradient
         wt, _, b = ctx.pack.get(h.dtype, h.shape[1], False)
         if _inplace_ok(kernel, bias):
             vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel.grad, bias.grad)

@@ -189,14 +189,16 @@ int b4c_softmax_ce_fwd_bwd(void *logits, int ld, const int32_t *labels, float *i
  *   bias [V] fp32 or NULL, labels [R] int32 (< 0: ignored row), grad_scale: device scalar d total / d row loss.
  * b4c_vocab_ce_fwd:  item_loss[R], dh [R][ld_dh] bf16 = grad_scale * d row_loss / d h, rowscal [R][8] fp32
  *   (scratch handed to b4c_vocab_ce_dw); workspace >= b4c_vocab_ce_workspace_bytes(R, V, K), 16-B aligned.
- * b4c_vocab_ce_dw:   dW [K][ldw] fp32 += d loss / d kernel (Keras layout [in][out]), db [V] += (or NULL).
+ * b4c_vocab_ce_dw:   dW [K][ldw] fp32 += d loss / d kernel (Keras layout [in][out]), db [V] += (or NULL);
+ *   same workspace (scratch, contents not carried over).
  * K in {64, 128}; variant B4C_CE_TF (clip-renormalised, as the TF backend) or B4C_CE_PLAIN. */
 int64_t b4c_vocab_ce_workspace_bytes(int64_t R, int V, int K);
 int b4c_vocab_ce_fwd(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
                      const float *grad_scale, float *item_loss, void *dh, int ld_dh, float *rowscal,
                      void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, int variant, void *stream);
 int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
-                    const float *rowscal, float *dW, int ldw, float *db, int64_t R, int V, int K, void *stream);
+                    const float *rowscal, float *dW, int ldw, float *db, void *workspace, int64_t workspace_bytes,
+                    int64_t R, int V, int K, void *stream);
 
 /* ---- R15: top-k ids, HitRate@k / NDCG@k -------------------------------------------------
  * replaces tf.math.top_k + the Recall / NDCG update_state arithmetic (utils.py:161-190, 225-255).
