@@ -47,6 +47,8 @@ def parse():
     ap.add_argument('--n_batches', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_rows', type=int, default=48, help='sequences in the bounded CPU-baseline sample')
+    ap.add_argument('--record_steps', type=int, default=-1,
+                    help='timed steps whose launches are bracketed by HIP events for the roofline (-1 = all, 0 = none)')
     ap.add_argument('--materialised_logits', action='store_true',
                     help='A/B: vocabulary projection writes the (R x V) logits and the CE reads them (ops.flash_ce = False)')
     ap.add_argument('--traffic_json', default=None, help='optional JSON with PMC-derived HBM bytes per launch')
@@ -192,13 +194,17 @@ def main():
 
     for i in range(a.warmup):
         loss = step(i)
-    if rank == 0:
-        ops.start_recording()      # HIP events around every hot-path launch of the timed steps (rank 0)
+    nrec = a.steps if a.record_steps < 0 else min(a.record_steps, a.steps)
+    if rank == 0 and nrec > 0:
+        ops.start_recording()      # HIP events around every hot-path launch of the first nrec timed steps (rank 0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    fams = None
     for i in range(a.steps):
+        if i == nrec and rank == 0 and nrec > 0:
+            fams = ops.pause_recording()
         loss = step(a.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
@@ -212,12 +218,13 @@ def main():
     dt, items = float(tt[0]), float(rr[0])
 
     if rank == 0:
-        fams = ops.stop_recording()
-        roof = roofline_from(fams, a.steps, MFMA_BF16_PEAK_TF if a.dtype == 'bf16' else 157.3)
+        fams = ops.stop_recording(fams)
+        roof = roofline_from(fams, max(nrec, 1), MFMA_BF16_PEAK_TF if a.dtype == 'bf16' else 157.3) if fams else None
         tj = a.traffic_json or os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tj):      # rocprofv3 PMC passes (separate runs), HBM bytes per launch of each family
             with open(tj) as f:
-                roof['traffic'] = json.load(f).get(roof['family'])
+                if roof:
+                    roof['traffic'] = json.load(f).get(roof['family'])
         out = {
             'metric': 'masked-items/sec (whole node)', 'value': items / dt, 'unit': 'masked-items/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,

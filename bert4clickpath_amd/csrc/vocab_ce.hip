@@ -54,38 +54,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t vce_rsrc(const void *base, int
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (unsigned)bytes, 0x00020000);
 }
 
-// A [128 rows][KD] bf16 tile: in flight (registers) and in LDS.
-// KD = 128: rows are exactly one 256-B bank row; the 16-B chunk c of row j sits at chunk c ^ f(j),
-//   f(j) = ((j & 3) << 2) | ((j >> 2) & 3):  a transposed read (32-lane group: 4 consecutive rows x the same 64 B) and
-//   a direct fragment read (ds_read_b128 16-lane groups: rows {0-3,12-15,20-27} / {4-11,16-19,28-31}, same chunk)
-//   both land on 16 distinct 16-B slots -- no padding, no conflicts (MI355X_MICROARCH.md, LDS).
-// KD = 64: 128-B rows padded to 144 B.
+// A [128 rows][KD] bf16 tile in LDS, filled by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write).
+// Rows are unpadded (KD * 2 bytes); the 16-B chunk c of row j sits at chunk c ^ f(j):
+//   KD = 128 (a row = one 256-B bank row):   f(j) = ((j & 3) << 2) | ((j >> 2) & 3)
+//   KD =  64 (two rows per bank row):        f(j) = (((j >> 1) & 1) << 2) | ((j >> 2) & 3)
+// so that a transposed read (32-lane group: 4 consecutive rows x the same 64 B) and a direct fragment read
+// (ds_read_b128 16-lane groups: rows {0-3,12-15,20-27} / {4-11,16-19,28-31}, same chunk) both land on distinct
+// 16-B slots of the 64 banks (MI355X_MICROARCH.md, LDS).  An LDS-DMA wave instruction writes 64 x 16 B
+// contiguously (lane l -> base + 16 l), so the swizzle is applied to the SOURCE address of each lane.
 template <int KD> struct VTile {
-    static constexpr int CH = KD / 8;
-    static constexpr int NIT = 128 * CH / 512;   // 4 (KD = 128) or 2 (KD = 64)
-    static constexpr bool SWZ = KD == 128;
-    static constexpr int STR = SWZ ? 256 : KD * 2 + 16;
+    static constexpr int CH = KD / 8;            // 16-B chunks per row
+    static constexpr int NIT = 128 * CH / 512;   // DMA instructions per thread: 4 (KD = 128) or 2 (KD = 64)
+    static constexpr int STR = KD * 2;
     static constexpr int BYTES = 128 * STR;
-    vu32x4 reg[NIT];
-    static __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-    static __device__ __forceinline__ int chunk_off(int row, int chunk) {
-        return row * STR + ((SWZ ? (chunk ^ swz(row)) : chunk) << 4);
+    static __device__ __forceinline__ int swz(int row) {
+        return KD == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
     }
-    // rows [row0, row0 + 128) of P (row pitch ld elements); rows >= nrows read as zeros
-    __device__ __forceinline__ void load(const bf16_t *__restrict__ P, int ld, int64_t row0, int64_t nrows, int tid) {
+    static __device__ __forceinline__ int chunk_off(int row, int chunk) { return row * STR + ((chunk ^ swz(row)) << 4); }
+    // rows [row0, row0 + 128) of P (row pitch ld elements) -> LDS tile at `dst`; rows >= nrows arrive as zeros.
+    // Completion is on the VM counter: s_waitcnt vmcnt(0) + a barrier before any wave reads the tile.
+    static __device__ __forceinline__ void dma(const bf16_t *__restrict__ P, int ld, int64_t row0, int64_t nrows, char *dst, int tid) {
         const int64_t left = nrows - row0;
         const __amdgpu_buffer_rsrc_t rs = vce_rsrc(P + row0 * ld, left < 128 ? left : 128, (int64_t)ld * 2);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int c = tid + i * 512;
-            reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((c / CH) * ld + (c % CH) * 8) * 2, 0, 0);
-        }
-    }
-    __device__ __forceinline__ void store(char *s, int tid) const {
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int c = tid + i * 512;
-            *reinterpret_cast<vu32x4 *>(s + chunk_off(c / CH, c % CH)) = reg[i];
+            const int c = tid + i * 512, row = c / CH, slot = c % CH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst + ((c & ~63) << 4)), 16,
+                                                     (row * ld + ((slot ^ swz(row)) << 3)) * 2, 0, 0, 0);
         }
     }
     // per-lane offsets, relative to a row base that is a multiple of 16 rows:
@@ -98,6 +93,7 @@ template <int KD> struct VTile {
         return chunk_off(row, e >> 3) + (e & 7) * 2;
     }
 };
+#define VCE_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 __device__ __forceinline__ bf16x8 vce_frag_tr2(const char *p0, const char *p1) {
     const vs16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((vs16x4 __attribute__((address_space(3))) *)(p0));
     const vs16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((vs16x4 __attribute__((address_space(3))) *)(p1));
@@ -193,22 +189,18 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
         toff[dt][1] = VTile<KD>::tr_off(hf, li, g, dt, 1) + vh * 64 * STR;
     }
 
-    VTile<KD> wt;
+    // tile vt -> LDS buffer `buf` (DMA), its bias -> a register (stored to LDS after the current tile's reads)
     float breg = 0.f;
-    auto fetch = [&](int vt) {
-        wt.load(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, tid);
+    auto fetch = [&](int vt, int buf) {
+        VTile<KD>::dma(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, smem + buf * TILE_B, tid);
         if (tid < 128) {
             const int v = vt * 128 + tid;
             breg = (vt < vt1 && v < a.V) ? (a.bias ? a.bias[v] : 0.f) : -INFINITY;   // rows past V: logit = -inf
         }
     };
-    auto commit = [&](int buf) {
-        wt.store(smem + buf * TILE_B, tid);
-        if (tid < 128) sBias[buf * 128 + tid] = breg;
-    };
-    fetch(vt0);
-    commit(0);
-    fetch(vt0 + 1);
+    fetch(vt0, 0);
+    if (tid < 128) sBias[tid] = breg;
+    VCE_DMA_WAIT();
     __syncthreads();
 
     // running state of the lane's token over its (hf, vh) share of the vocabulary
@@ -226,6 +218,7 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
         constexpr int buf = decltype(BUF)::value;
         const char *w = smem + buf * TILE_B;
         const float *bs = sBias + buf * 128;
+        fetch(vt + 1, buf ^ 1);        // the other buffer was last read one tile ago (behind the previous barrier)
         f32x16 acc[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -279,6 +272,7 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
+            __builtin_amdgcn_sched_barrier(0);       // keep one 32-row tile's temporaries live at a time
             float p[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -305,9 +299,8 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
                 }
             }
         }
-        // the other buffer was last read one tile ago (behind the previous barrier)
-        commit(buf ^ 1);
-        fetch(vt + 2);
+        if (tid < 128) sBias[(buf ^ 1) * 128 + tid] = breg;
+        VCE_DMA_WAIT();
         B4C_LDS_BARRIER();
     };
     for (int vt = vt0; vt < vt1; vt += 2) {
@@ -491,22 +484,17 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
     }
     const int roff = (th * 64 + 4 * hf) * 16;       // the lane's first row-scalar entry (bytes)
 
-    VTile<KD> ht;
     f32x4 rreg = {INFINITY, 0.f, 0.f, 0.f};
-    auto fetch = [&](int64_t tt) {
-        ht.load(a.h, a.ld_h, tt * 128, tt < tt1 ? a.R : 0, tid);
+    auto fetch = [&](int64_t tt, int buf) {
+        VTile<KD>::dma(a.h, a.ld_h, tt * 128, tt < tt1 ? a.R : 0, smem + buf * TILE_B, tid);
         if (tid < 128) {
             const int64_t row = tt * 128 + tid;
             rreg = (tt < tt1 && row < a.R) ? *reinterpret_cast<const f32x4 *>(a.rowscal + row * 8) : (f32x4){INFINITY, 0.f, 0.f, 0.f};
         }
     };
-    auto commit = [&](int buf) {
-        ht.store(smem + buf * TILE_B, tid);
-        if (tid < 128) sRow[buf * 128 + tid] = rreg;
-    };
-    fetch(tt0);
-    commit(0);
-    fetch(tt0 + 1);
+    fetch(tt0, 0);
+    if (tid < 128) sRow[tid] = rreg;
+    VCE_DMA_WAIT();
     __syncthreads();
 
     f32x16 dW[NDT];
@@ -521,10 +509,12 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
         const char *hh = smem + buf * TILE_B;
         const f32x4 *rs = sRow + buf * 128;
         const char *rsl = reinterpret_cast<const char *>(rs) + roff;
+        fetch(tt + 1, buf ^ 1);        // the other buffer was last read one tile ago (behind the previous barrier)
         // row scalars {lse2, c = a - b, +-a, b}: a < 0 marks a row whose probabilities leave the clip range
         const bool any_clip = __any(rs[th * 64 + lane][2] < 0.f);     // the wave's 64 token rows
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
+            __builtin_amdgcn_sched_barrier(0);       // keep one 32-token tile's temporaries live at a time
             f32x16 acc;
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[t] = bv;
@@ -563,8 +553,8 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
                 }
             }
         }
-        commit(buf ^ 1);
-        fetch(tt + 2);
+        if (tid < 128) sRow[(buf ^ 1) * 128 + tid] = rreg;
+        VCE_DMA_WAIT();
         B4C_LDS_BARRIER();
     };
     for (int64_t tt = tt0; tt < tt1; tt += 2) {
@@ -694,9 +684,25 @@ static int vce_fwd_launch(VceArgs a, hipStream_t st) {
         done = true;
     }
     dim3 grid((unsigned)ntt, (unsigned)a.parts);
+    // B4C_VCE_TIMING=1: HIP events around the kernels, read back (without synchronising) at the next call
+    static const bool dbg = getenv("B4C_VCE_TIMING") != nullptr;
+    static hipEvent_t ev[4];
+    static bool have = false;
+    if (dbg) {
+        if (have && hipEventQuery(ev[3]) == hipSuccess) {
+            float t1 = 0, t2 = 0, t3 = 0;
+            (void)hipEventElapsedTime(&t1, ev[0], ev[1]); (void)hipEventElapsedTime(&t2, ev[1], ev[2]); (void)hipEventElapsedTime(&t3, ev[2], ev[3]);
+            fprintf(stderr, "[vce_fwd] previous call: sweep %.3f ms, clipped sweep %.3f ms, combine %.3f ms (parts %d)\n", t1, t2, t3, a.parts);
+        }
+        if (!have) { for (auto &e : ev) (void)hipEventCreate(&e); have = true; }
+        (void)hipEventRecord(ev[0], st);
+    }
     vce_token_kernel<KD, 1><<<grid, 512, lds, st>>>(a);
+    if (dbg) (void)hipEventRecord(ev[1], st);
     if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2><<<grid, 512, lds, st>>>(a);
+    if (dbg) (void)hipEventRecord(ev[2], st);
     vce_combine_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a);
+    if (dbg) (void)hipEventRecord(ev[3], st);
     return b4c_check_launch("vocab_ce_fwd");
 }
 

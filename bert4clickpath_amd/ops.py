@@ -34,10 +34,18 @@ def start_recording():
     _rec = {}
 
 
-def stop_recording():
-    """-> {family: {'ms': total, 'launches': n, 'bytes': algorithmic bytes, 'flops': algorithmic flops}} (synchronises)."""
+def pause_recording():
+    """Stop bracketing launches WITHOUT synchronising; hand the result to stop_recording() later."""
     global _rec
     rec, _rec = _rec, None
+    return rec
+
+
+def stop_recording(rec=None):
+    """-> {family: {'ms': total, 'launches': n, 'bytes': algorithmic bytes, 'flops': algorithmic flops}} (synchronises)."""
+    global _rec
+    if rec is None:
+        rec, _rec = _rec, None
     torch.cuda.synchronize()
     out = {}
     for fam, items in (rec or {}).items():
