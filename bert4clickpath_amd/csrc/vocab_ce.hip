@@ -596,21 +596,46 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
 // K5: the [j = y] term of dlogit: dW[:, y] -= yd h_row, db[y] -= yd.  dW is [K][V] (a label touches a column),
 // so the rows are first added into a vocabulary-major scratch [V][KD] (coalesced atomics, one wave per row), which
 // is then added transposed.
+#define VCE_HOT 64          // labels < VCE_HOT (the head of a frequency-ranked vocabulary) are pre-summed in LDS
+#define VCE_LABEL_ROWS 512  // rows per workgroup
 template <int KD>
 __global__ void __launch_bounds__(256) vce_label_kernel(VceDwArgs a, const int32_t *__restrict__ labels, float *__restrict__ tmp) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.R) return;
-    const int y = labels[row];
-    if (y < 0 || y >= a.V) return;
-    const float yd = a.rowscal[row * 8 + 4];
-    if (yd == 0.f) return;
+    __shared__ float hot[VCE_HOT][KD + 1];      // [..][KD] = the bias term
+    __shared__ int touched[VCE_HOT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < VCE_HOT * (KD + 1); i += 256) (&hot[0][0])[i] = 0.f;
+    if (tid < VCE_HOT) touched[tid] = 0;
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * VCE_LABEL_ROWS;
+    for (int i = wave; i < VCE_LABEL_ROWS; i += 4) {
+        const int64_t row = row0 + i;
+        if (row >= a.R) break;
+        const int y = labels[row];
+        if (y < 0 || y >= a.V) continue;
+        const float yd = a.rowscal[row * 8 + 4];
+        if (yd == 0.f) continue;
+        if (y < VCE_HOT) {        // wave-uniform
 #pragma unroll
-    for (int e = 0; e < KD / 64; ++e) {
-        const int d = lane + 64 * e;
-        atomicAdd(tmp + (int64_t)y * KD + d, -yd * (float)a.h[row * a.ld_h + d]);
+            for (int e = 0; e < KD / 64; ++e) {
+                const int d = lane + 64 * e;
+                atomicAdd(&hot[y][d], -yd * (float)a.h[row * a.ld_h + d]);
+            }
+            if (lane == 0) { atomicAdd(&hot[y][KD], -yd); touched[y] = 1; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < KD / 64; ++e) {
+                const int d = lane + 64 * e;
+                atomicAdd(tmp + (int64_t)y * KD + d, -yd * (float)a.h[row * a.ld_h + d]);
+            }
+            if (lane == 0 && a.db) atomicAdd(a.db + y, -yd);
+        }
     }
-    if (lane == 0 && a.db) atomicAdd(a.db + y, -yd);
+    __syncthreads();
+    for (int i = tid; i < VCE_HOT * KD; i += 256) {
+        const int y = i / KD, d = i % KD;
+        if (touched[y]) atomicAdd(tmp + (int64_t)y * KD + d, hot[y][d]);
+    }
+    if (tid < VCE_HOT && touched[tid] && a.db) atomicAdd(a.db + tid, hot[tid][KD]);
 }
 template <int KD>
 __global__ void __launch_bounds__(256) vce_label_add_kernel(float *__restrict__ dW, int ldw, const float *__restrict__ tmp, int V) {
@@ -734,7 +759,7 @@ static int vce_dw_launch(VceDwArgs a, const int32_t *labels, float *tmp, hipStre
     if (!done) { vce_allow_lds(vce_dw_kernel<KD>, lds); done = true; }
     vce_dw_kernel<KD><<<dim3((unsigned)nvt, (unsigned)a.tsplit), 512, lds, st>>>(a);
     (void)hipMemsetAsync(tmp, 0, (size_t)a.V * KD * 4, st);
-    vce_label_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a, labels, tmp);
+    vce_label_kernel<KD><<<(unsigned)ceil_div64(a.R, VCE_LABEL_ROWS), 256, 0, st>>>(a, labels, tmp);
     vce_label_add_kernel<KD><<<dim3((unsigned)((a.V + 31) / 32), KD / 32), 256, 0, st>>>(a.dW, a.ldw, tmp, a.V);
     return b4c_check_launch("vocab_ce_dw");
 }

@@ -421,8 +421,8 @@ def vocab_ce_fwd(h, wt, bias, labels_i32, grad_scale, V, variant=L.CE_TF):
     if R == 0:
         return item, dh, rowscal
     ws = _vce_workspace(h, R, V, K)
-    nsweep = 3 if variant == L.CE_TF else 2
-    with _record('vocab_ce_fwd', R * K * 2 * 2 + V * K * 2, 2 * R * V * K * (2 * nsweep - 1)):
+    # algorithmic work: the logits GEMM and the P.W GEMM (the clipped-row sweep is data dependent and not counted)
+    with _record('vocab_ce_fwd', R * K * 2 * 2 + V * K * 2, 4 * R * V * K):
         L.check(L.lib().b4c_vocab_ce_fwd(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(grad_scale),
                                          _p(item), _p(dh), dh.stride(0), _p(rowscal), ws.data_ptr(), ws.numel(), R, V, K,
                                          variant, _st()), 'vocab_ce_fwd')
