@@ -61,17 +61,46 @@ template <> struct Vec8<bf16_t> {
     }
 };
 
-// ---- counter-based dropout mask (splitmix64 finaliser; two 24-bit uniforms per hash) ----
-__host__ __device__ __forceinline__ uint64_t b4c_mix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
+// ---- counter-based dropout mask ----
+// Threefry-2x32 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11), 12 rounds,
+// key = seed, counter = e >> 2: 64 random bits = four 16-bit uniforms, one per element.  Adds, rotates and xors
+// only: 32-bit integer multiplies run at quarter rate on CDNA, and the 64-bit-multiply mixer used first made the
+// mask the most expensive part of every dropout site (0.9 ms of the 19.2 ms C2 step).
+__host__ __device__ __forceinline__ uint32_t b4c_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__host__ __device__ __forceinline__ uint64_t b4c_rand64(uint64_t seed, uint64_t ctr) {
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), k2 = 0x1BD11BDAu ^ k0 ^ k1;
+    uint32_t x0 = (uint32_t)ctr + k0, x1 = (uint32_t)(ctr >> 32) + k1;
+#define B4C_TF_ROUND(R) x0 += x1; x1 = b4c_rotl32(x1, R); x1 ^= x0;
+    B4C_TF_ROUND(13) B4C_TF_ROUND(15) B4C_TF_ROUND(26) B4C_TF_ROUND(6)
+    x0 += k1; x1 += k2 + 1u;
+    B4C_TF_ROUND(17) B4C_TF_ROUND(29) B4C_TF_ROUND(16) B4C_TF_ROUND(24)
+    x0 += k2; x1 += k0 + 2u;
+    B4C_TF_ROUND(13) B4C_TF_ROUND(15) B4C_TF_ROUND(26) B4C_TF_ROUND(6)
+    x0 += k0; x1 += k1 + 3u;
+#undef B4C_TF_ROUND
+    return (uint64_t)x0 | ((uint64_t)x1 << 32);
 }
-// keep element e?  u in [0,1) with 24 bits; keep iff u >= rate.
+// element e is kept iff its 16-bit uniform >= ceil(rate * 65536)
+__host__ __device__ __forceinline__ uint32_t b4c_keep_threshold(float rate) {
+    const float t = rate * 65536.0f;
+    uint32_t thr = (uint32_t)t;
+    if ((float)thr < t) ++thr;
+    return thr;
+}
 __host__ __device__ __forceinline__ bool b4c_keep_elem(uint64_t seed, uint64_t e, float rate) {
-    const uint64_t h = b4c_mix64(seed + ((e >> 1) + 1) * 0x9E3779B97F4A7C15ULL);
-    const uint32_t bits = (e & 1) ? (uint32_t)(h >> 40) : (uint32_t)((h >> 8) & 0xFFFFFFu);
-    return (float)bits * (1.0f / 16777216.0f) >= rate;
+    const uint64_t h = b4c_rand64(seed, e >> 2);
+    return (uint32_t)((h >> (16 * (e & 3))) & 0xFFFFu) >= b4c_keep_threshold(rate);
+}
+// keep bits of the 8 consecutive elements e0 .. e0+7 (e0 % 4 == 0): bit k = element e0 + k.  Two hashes.
+__host__ __device__ __forceinline__ uint32_t b4c_keep8(uint64_t seed, uint64_t e0, uint32_t thr) {
+    const uint64_t h0 = b4c_rand64(seed, e0 >> 2), h1 = b4c_rand64(seed, (e0 >> 2) + 1);
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m |= (((uint32_t)(h0 >> (16 * k)) & 0xFFFFu) >= thr ? 1u : 0u) << k;
+        m |= (((uint32_t)(h1 >> (16 * k)) & 0xFFFFu) >= thr ? 1u : 0u) << (4 + k);
+    }
+    return m;
 }
 
 // ---- wave / block reductions ----

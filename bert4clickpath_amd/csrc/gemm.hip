@@ -283,6 +283,166 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, i
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// NT + residual + dropout + LayerNorm (bf16, N <= 128 = one tile wide): the out-projection / FFN2 GEMM of an
+// encoder layer and the "x + dropout(y) -> LayerNorm" that follows it (transformer.py:204-206, 211-213) in one
+// pass: y never goes to HBM (2 of the 6 [T][d] passes of the pair).  Mainloop = gemm_nt_kernel.  The epilogue
+// stages the whole 128 x 128 bf16 tile in LDS, then 16 consecutive lanes own one row (8 columns each), exactly
+// the lane layout and the summation order of add_ln_fwd_kernel<bf16, 16>: z, out and stats are bit-identical
+// to gemm_nt followed by add_ln_fwd.
+// ------------------------------------------------------------------------------------------
+#define LN_OUT_STRIDE 264   // bytes per staged row: 256 + 8 (8-byte writes of 16 rows spread over the 32 write banks)
+
+__global__ void __launch_bounds__(256) gemm_nt_ln_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ Bt, int ldb,
+                                                         const float *__restrict__ bias, const bf16_t *__restrict__ x, int ldx,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         bf16_t *__restrict__ z, bf16_t *__restrict__ out, float *__restrict__ stats,
+                                                         int M, int N, int K, float eps, float rate, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * TILE;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+    const int nk = (K + MM<bf16_t>::BKE - 1) / MM<bf16_t>::BKE;
+    u32x4 xa[4], xb[4];
+    nt_load<bf16_t>(A, lda, m0, M, 0, K, tid, xa);
+    nt_load<bf16_t>(Bt, ldb, 0, N, 0, K, tid, xb);
+    // epilogue chunk q of this thread: row (tid >> 4) + 16 q of the tile, columns 8 (tid & 15) ...
+    const int part = tid & 15, col = part * 8;
+    float bv[8], gv[8], be[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { bv[k] = 0.f; gv[k] = 0.f; be[k] = 0.f; }
+    if (col < N) {
+        if (bias) Vec8<float>::load(bias + col, bv);
+        Vec8<float>::load(gamma + col, gv);
+        Vec8<float>::load(beta + col, be);
+    }
+    nt_store(smem, tid, xa);
+    nt_store(smem + TILE_BYTES, tid, xb);
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t xrs = tile_rsrc(x + (int64_t)m0 * ldx, (int64_t)M - m0, TILE, (int64_t)ldx * 2);
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            nt_load<bf16_t>(A, lda, m0, M, (kt + 1) * MM<bf16_t>::BKE, K, tid, xa);
+            nt_load<bf16_t>(Bt, ldb, 0, N, (kt + 1) * MM<bf16_t>::BKE, K, tid, xb);
+        } else {
+            // residual chunks 0..3 ride under the last tile's MFMAs (xa is idle by now)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xa[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ((((tid >> 4) + 16 * i) * ldx + col) * 2) | oob_if(col >= N), 0, 0);
+        }
+        mma_stage<bf16_t>(smem + TILE_BYTES, smem, wn, wm, r, h, acc);
+        __syncthreads();
+        if (more) {
+            nt_store(smem, tid, xa);
+            nt_store(smem + TILE_BYTES, tid, xb);
+            __syncthreads();
+        }
+    }
+    // acc[j][i] register t: n = wn*64 + j*32 + (t&3) + 8*(t>>2) + 4*h, m = wm*64 + i*32 + r  ->  LDS [m][n] bf16
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+                bf16x4_t w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = (bf16_t)acc[j][i][4 * tq + k];
+                *reinterpret_cast<bf16x4_t *>(smem + (wm * 64 + i * 32 + r) * LN_OUT_STRIDE + (wn * 64 + j * 32 + 8 * tq + 4 * h) * 2) = w;
+            }
+    __syncthreads();
+    const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
+    const float inv_d = 1.0f / (float)N;
+    // two halves of four chunks: chunks 4..7 of the residual are requested while 0..3 are processed (the loop over
+    // the halves is not unrolled: the epilogue is VALU work -- dropout hashes -- and needs occupancy, i.e. few registers)
+#pragma unroll 1
+    for (int hq = 0; hq < 2; ++hq) {
+      if (hq == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xb[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ((((tid >> 4) + 16 * (4 + i)) * ldx + col) * 2) | oob_if(col >= N), 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = hq * 4 + i;
+        const int row = (tid >> 4) + 16 * q;
+        const int64_t grow = m0 + row;
+        const bool on = grow < M && col < N;     // rows are uniform over their 16 lanes
+        const u32x4 xcur = xa[i];
+        float v[8];
+        float sum = 0.f;
+        if (on) {
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(smem + row * LN_OUT_STRIDE + part * 16);
+            const u32x2 hi = *reinterpret_cast<const u32x2 *>(smem + row * LN_OUT_STRIDE + part * 16 + 8);
+            const u32x4 w4 = {lo[0], lo[1], hi[0], hi[1]};
+            const bf16x8 cv = __builtin_bit_cast(bf16x8, w4);
+            const bf16x8 xv = __builtin_bit_cast(bf16x8, xcur);
+            const uint32_t km = rate > 0.f ? b4c_keep8(seed, (uint64_t)(grow * N + col), b4c_keep_threshold(rate)) : 0xFFu;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float yy = (float)(bf16_t)((float)cv[k] + bv[k]);      // the bf16 y that gemm_nt would have stored
+                if (rate > 0.f) yy = ((km >> k) & 1u) ? yy * inv_keep : 0.f;
+                v[k] = (float)xv[k] + yy;
+                sum += v[k];
+            }
+            if (z) Vec8<bf16_t>::store(z + grow * N + col, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+        const float mean = group_sum<16>(sum) * inv_d;
+        float sq = 0.f;
+        if (on) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float dlt = v[k] - mean;
+                sq += dlt * dlt;
+            }
+        }
+        const float var = group_sum<16>(sq) * inv_d;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (on) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (v[k] - mean) * rstd * gv[k] + be[k];
+            Vec8<bf16_t>::store(out + grow * N + col, o);
+            if (part == 0 && stats) {
+                stats[grow * 2] = mean;
+                stats[grow * 2 + 1] = rstd;
+            }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xa[i] = xb[i];
+    }
+}
+
+extern "C" int b4c_gemm_nt_add_ln(const void *A, int lda, const void *Bt, int ldb, const float *bias, const void *x, int ldx,
+                                  const float *gamma, const float *beta, void *z, void *out, float *stats, int M, int N, int K,
+                                  float eps, float dropout_rate, uint64_t seed, int dtype, void *stream) {
+    B4C_REQUIRE(A && Bt && x && gamma && beta && out, "gemm_nt_add_ln: null pointer");     // z / stats may be NULL (inference)
+    B4C_REQUIRE(dtype == B4C_BF16, "gemm_nt_add_ln: bf16 only (dtype %d)", dtype);
+    B4C_REQUIRE(M > 0 && N > 0 && N <= TILE && N % 8 == 0 && K > 0 && K % 8 == 0, "gemm_nt_add_ln: M=%d N=%d K=%d (N <= 128, N, K %% 8 == 0)", M, N, K);
+    B4C_REQUIRE(lda >= K && ldb >= K && ldx >= N && lda % 8 == 0 && ldb % 8 == 0 && ldx % 8 == 0, "gemm_nt_add_ln: pitches");
+    B4C_REQUIRE(((((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)x | (uintptr_t)z | (uintptr_t)out) & 15) == 0) &&
+                ((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)bias) & 15) == 0), "gemm_nt_add_ln: operands must be 16-byte aligned");
+    B4C_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f, "gemm_nt_add_ln: dropout_rate %f", (double)dropout_rate);
+    const int grid = (M + TILE - 1) / TILE;
+    gemm_nt_ln_kernel<<<grid, 256, STAGE_BYTES, (hipStream_t)stream>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, bias,
+                                                                       (const bf16_t *)x, ldx, gamma, beta, (bf16_t *)z,
+                                                                       (bf16_t *)out, stats, M, N, K, eps, dropout_rate, seed);
+    return b4c_check_launch("gemm_nt_add_ln");
+}
+
 // Wide-N, small-K form (the vocabulary projection: [R][128] x [V][128]^T -> [R][V]).  The generic kernel
 // above spends most of its time outside stores and MFMAs there (with both removed it still runs at half its
 // full duration: 125 k workgroups each pay tile loads, staging and barriers for 32 KB of output).  Here a

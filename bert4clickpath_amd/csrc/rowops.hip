@@ -65,10 +65,11 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(EmbedArgs a, const float
         // host let them; the host guarantees every feature dim % 8 == 0.
         Vec8<float>::load(src, v);
         Vec8<float>::load(pe + (int64_t)s * d + c, p);
+        const uint32_t km = rate > 0.f ? b4c_keep8(seed, (uint64_t)(t * d + c), b4c_keep_threshold(rate)) : 0xFFu;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float x = v[k] * scale + p[k];
-            if (rate > 0.f) x = b4c_keep_elem(seed, (uint64_t)(t * d + c + k), rate) ? x * inv_keep : 0.f;
+            if (rate > 0.f) x = ((km >> k) & 1u) ? x * inv_keep : 0.f;
             v[k] = x;
         }
         Vec8<T>::store(out + t * ld_out + c, v);
@@ -221,10 +222,11 @@ __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const T *__restrict__ x
                     float a[8], b[8];
                     Vec8<T>::load(x + row * d + c, a);
                     Vec8<T>::load(y + row * d + c, b);
+                    const uint32_t km = rate > 0.f ? b4c_keep8(seed, (uint64_t)(row * d + c), b4c_keep_threshold(rate)) : 0xFFu;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         float yy = b[k];
-                        if (rate > 0.f) yy = b4c_keep_elem(seed, (uint64_t)(row * d + c + k), rate) ? yy * inv_keep : 0.f;
+                        if (rate > 0.f) yy = ((km >> k) & 1u) ? yy * inv_keep : 0.f;
                         v[p][k] = a[k] + yy;
                         sum += v[p][k];
                     }
@@ -333,9 +335,9 @@ __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const T *__restrict__ d
                     for (int k = 0; k < 8; ++k) o[k] = rstd * (gv[p][k] - s1 - xh[p][k] * s2);
                     Vec8<T>::store(dz + row * d + c, o);
                     if (rate > 0.f && dy) {
+                        const uint32_t km = b4c_keep8(seed, (uint64_t)(row * d + c), b4c_keep_threshold(rate));
 #pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            o[k] = b4c_keep_elem(seed, (uint64_t)(row * d + c + k), rate) ? o[k] * inv_keep : 0.f;
+                        for (int k = 0; k < 8; ++k) o[k] = ((km >> k) & 1u) ? o[k] * inv_keep : 0.f;
                         Vec8<T>::store(dy + row * d + c, o);
                     }
                 }

@@ -304,6 +304,31 @@ def add_dropout_layernorm_fwd(x, y, gamma, beta, rate, seed, save=True):
     return z, out, stats
 
 
+fused_ln = True      # bf16, d_model <= 128: the GEMM in front of "x + dropout(y) -> LayerNorm" does it in its epilogue
+
+
+def gemm_ln_supported(a, n):
+    return fused_ln and a.dtype == torch.bfloat16 and n <= 128 and n % 8 == 0
+
+
+def gemm_nt_add_ln(a, bt, bias, x, gamma, beta, rate, seed, save=True):
+    """LayerNorm(x + dropout(a @ bt^T + bias)) in one kernel (== gemm_nt + add_dropout_layernorm_fwd, bit for bit).
+    a: [M, Kp], bt: [>=n, Kp], x: [M, n] -> (z, out, stats) as add_dropout_layernorm_fwd."""
+    M, K = a.shape
+    n = x.shape[1]
+    z = torch.empty_like(x) if save else None
+    out = torch.empty_like(x)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device) if save else None
+    if M == 0:
+        return z, out, stats
+    es = a.element_size()
+    with _record('gemm_nt_ln', M * K * es + n * K * es + M * n * es * (3 if save else 2), 2 * M * n * K):
+        L.check(L.lib().b4c_gemm_nt_add_ln(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(bias), _p(x), x.stride(0), _p(gamma),
+                                           _p(beta), _p(z), _p(out), _p(stats), M, n, K, LN_EPS, rate, seed,
+                                           dt_code(a.dtype), _st()), 'gemm_nt_add_ln')
+    return z, out, stats
+
+
 def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed, into=None):
     rows, d = z.shape
     dz = torch.empty_like(z)
@@ -460,17 +485,36 @@ def adam_step_(p, g, m, v, lr_t, beta1, beta2, eps, grad_mul=1.0):
 
 
 def keep_mask(seed, n, rate):
-    """Host regeneration of a dropout keep-mask (tests): element e kept iff b4c_keep(seed,e,rate)."""
+    """Host regeneration of a dropout keep-mask (tests): element e kept iff b4c_keep(seed, e, rate) --
+    Threefry-2x32, 12 rounds, key = seed, counter = e >> 2, one 16-bit uniform per element (csrc/common.h)."""
     import numpy as np
+    M = np.uint64(0xFFFFFFFF)
+
+    def rotl(x, r):
+        return ((x << np.uint64(r)) | (x >> np.uint64(32 - r))) & M
+
     e = np.arange(n, dtype=np.uint64)
-    with np.errstate(over='ignore'):
-        z = np.uint64(seed) + ((e >> np.uint64(1)) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    bits = np.where((e & np.uint64(1)) == 1, z >> np.uint64(40), (z >> np.uint64(8)) & np.uint64(0xFFFFFF))
-    u = bits.astype(np.float32) * np.float32(1.0 / 16777216.0)
-    return u >= np.float32(rate)
+    ctr = e >> np.uint64(2)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
+    k2 = np.uint64(0x1BD11BDA) ^ k0 ^ k1
+    x0 = ((ctr & M) + k0) & M
+    x1 = ((ctr >> np.uint64(32)) + k1) & M
+    inject = [(k1, k2, 1), (k2, k0, 2), (k0, k1, 3)]
+    rounds = [(13, 15, 26, 6), (17, 29, 16, 24), (13, 15, 26, 6)]
+    for rs, (a0, a1, j) in zip(rounds, inject):
+        for r in rs:
+            x0 = (x0 + x1) & M
+            x1 = rotl(x1, r) ^ x0
+        x0 = (x0 + a0) & M
+        x1 = (x1 + a1 + np.uint64(j)) & M
+    h = x0 | (x1 << np.uint64(32))
+    u16 = (h >> (np.uint64(16) * (e & np.uint64(3)))) & np.uint64(0xFFFF)
+    t = np.float32(rate) * np.float32(65536.0)
+    thr = int(t)
+    if np.float32(thr) < t:
+        thr += 1
+    return u16 >= np.uint64(thr)
 
 
 # --------------------------------------------------------------------------------------
@@ -618,9 +662,13 @@ class AttnBlockFn(torch.autograd.Function):
             qkv = gemm_nt(x, wt_qkv, 3 * d, b_qkv)
         with _timed('attn_fwd'):
             o, lse = attn_fwd(qkv, key_pad, B, S, H, dh)
-        y = gemm_nt(o, wt_o, d, b_o)
-        z, out, stats = add_dropout_layernorm_fwd(x, y, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
-                                                  save=training)
+        if gemm_ln_supported(o, d):
+            z, out, stats = gemm_nt_add_ln(o, wt_o, b_o, x, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
+                                           save=training)
+        else:
+            y = gemm_nt(o, wt_o, d, b_o)
+            z, out, stats = add_dropout_layernorm_fwd(x, y, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
+                                                      save=training)
         if training:
             ctx.save_for_backward(x, key_pad, qkv, o, lse, z, stats, gamma)
             ctx.pk = (pk_qkv, pk_o)
@@ -665,9 +713,13 @@ class FFNBlockFn(torch.autograd.Function):
         Fp = pk1.Np
         wt2, _, bb2 = pk2.get(x.dtype, Fp, training)
         h = gemm_nt(x, wt1, Fp, bb1, act=L.ACT_RELU)
-        y = gemm_nt(h, wt2, d, bb2)
-        z, out, stats = add_dropout_layernorm_fwd(x, y, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
-                                                  save=training)
+        if gemm_ln_supported(h, d):
+            z, out, stats = gemm_nt_add_ln(h, wt2, bb2, x, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
+                                           save=training)
+        else:
+            y = gemm_nt(h, wt2, d, bb2)
+            z, out, stats = add_dropout_layernorm_fwd(x, y, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
+                                                      save=training)
         if training:
             ctx.save_for_backward(x, h, z, stats, gamma)
             ctx.pk = (pk1, pk2)

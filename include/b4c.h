@@ -104,6 +104,14 @@ int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void *C, int ld
                 const float *bias, int act, const void *gate, int ldg, const void *residual, int ldr,
                 int dtype, int out_dtype, void *stream);
 
+/* R9/R10 fused with the GEMM that feeds them (bf16, N <= 128):
+ *   y = A . Bt^T + bias;  z = x + dropout(y);  out = LayerNorm(z) * gamma + beta;  stats = (mean, rstd)
+ * == b4c_gemm_nt followed by b4c_add_dropout_layernorm_fwd, bit for bit, without y in HBM.
+ * z / out [M][N] bf16 (pitch N), stats [M][2] fp32, x pitch ldx. */
+int b4c_gemm_nt_add_ln(const void *A, int lda, const void *Bt, int ldb, const float *bias, const void *x, int ldx,
+                       const float *gamma, const float *beta, void *z, void *out, float *stats, int M, int N, int K,
+                       float eps, float dropout_rate, uint64_t seed, int dtype, void *stream);
+
 /* dW[K][N] += A[M][K]^T . G[M][N]   and  db[N] += colsum(G)   (fp32 outputs ADDED to what is there: the
  * caller zeroes or accumulates; db may be NULL).  The reduction over the M (token) axis is split over
  * workgroups when the output has few 128x128 tiles; the partial tiles are then summed

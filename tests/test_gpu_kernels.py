@@ -339,3 +339,23 @@ def test_errors_are_loud(ops):
         ops.gemm_nt(a, a, 4)
     with pytest.raises(B4CError):
         ops.mask_positions(torch.zeros(2, 2, dtype=torch.int64), 1)   # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize('M,N,K,rate', [(300, 128, 128, 0.1), (129, 128, 104, 0.0), (77, 64, 64, 0.2), (1, 128, 128, 0.5),
+                                        (4096, 128, 256, 0.1)])
+def test_gemm_nt_add_ln_is_bit_identical_to_the_two_kernels(ops, M, N, K, rate):
+    """b4c_gemm_nt_add_ln == b4c_gemm_nt followed by b4c_add_dropout_layernorm_fwd (transformer.py:204-213), bit for bit."""
+    rng = np.random.default_rng(M + N + K)
+    a = torch.tensor(rng.standard_normal((M, K)), dtype=torch.float32, device='cuda').bfloat16()
+    w = torch.tensor(rng.standard_normal((N, K)) * 0.2, dtype=torch.float32, device='cuda').bfloat16()
+    bias = torch.tensor(rng.standard_normal(N), dtype=torch.float32, device='cuda')
+    x = torch.tensor(rng.standard_normal((M, N)), dtype=torch.float32, device='cuda').bfloat16()
+    gamma = torch.tensor(1.0 + 0.1 * rng.standard_normal(N), dtype=torch.float32, device='cuda')
+    beta = torch.tensor(0.1 * rng.standard_normal(N), dtype=torch.float32, device='cuda')
+    seed = 12345
+    y = ops.gemm_nt(a, w, N, bias)
+    z0, o0, s0 = ops.add_dropout_layernorm_fwd(x, y, gamma, beta, rate, seed)
+    z1, o1, s1 = ops.gemm_nt_add_ln(a, w, bias, x, gamma, beta, rate, seed)
+    assert torch.equal(z0, z1) and torch.equal(o0, o1) and torch.equal(s0, s1)
+    _, o2, _ = ops.gemm_nt_add_ln(a, w, bias, x, gamma, beta, rate, seed, save=False)
+    assert torch.equal(o0, o2)
