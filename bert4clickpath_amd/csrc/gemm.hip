@@ -155,14 +155,24 @@ template <typename T, typename OutT, bool EPI>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, int lda, const T *__restrict__ Bt, int ldb,
                                                       OutT *__restrict__ C, int ldc, int M, int N, int K,
                                                       const float *__restrict__ bias, int act, const T *__restrict__ gate,
-                                                      int ldg, const T *__restrict__ residual, int ldr, int vec_ok) {
+                                                      int ldg, const T *__restrict__ residual, int ldr, int vec_ok, int xcd_map) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     // blockIdx.x walks the N tiles first: neighbours in dispatch order share the A tile (L2) and write
     // adjacent 256-B segments of the same output rows (DRAM pages), which matters for the vocabulary GEMM
     const int ntn = (N + TILE - 1) / TILE;
-    const int m0 = (blockIdx.x / ntn) * TILE, n0 = (blockIdx.x % ntn) * TILE;
+    int mt_i = blockIdx.x / ntn, nt_i = blockIdx.x % ntn;
+    if (xcd_map) {
+        // Workgroup ids go round-robin over the 8 XCDs, each with its own L2: with the N tiles of one M tile on
+        // consecutive ids, its A tile is fetched from HBM once per N tile (measured: the QKV projection, 3 N tiles,
+        // moved 1.5x its algorithmic bytes).  Here ids i, i+8, i+16, ... (one XCD) walk the N tiles of one M tile.
+        const int grp = blockIdx.x / (8 * ntn), rem = blockIdx.x % (8 * ntn);
+        mt_i = grp * 8 + (rem & 7);
+        nt_i = rem >> 3;
+    }
+    const int m0 = mt_i * TILE, n0 = nt_i * TILE;
+    if (m0 >= M) return;          // (the XCD map rounds the M tiles up to a multiple of 8)
     const bool vec = (sizeof(OutT) == 2) && vec_ok;
     f32x16 acc[2][2];   // acc[j][i]: rows = n (tile j of this wave's 64 columns), col = m (tile i of its 64 rows)
 #pragma unroll
@@ -659,7 +669,9 @@ extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void
         gemm_nt_wide_kernel<<<mt * chunks, 512, shm_w, st_w>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, mt, tpc);
         return b4c_check_launch("gemm_nt_wide");
     }
-    const int64_t nblocks = ceil_div64(M, TILE) * ceil_div64(N, TILE);
+    const int64_t mt_n = ceil_div64(M, TILE), nt_n = ceil_div64(N, TILE);
+    const int xcd_map = (nt_n > 1 && nt_n <= 8) ? 1 : 0;      // few N tiles: keep one M tile's workgroups on one XCD (L2)
+    const int64_t nblocks = (xcd_map ? ceil_div64(mt_n, 8) * 8 : mt_n) * nt_n;
     B4C_REQUIRE(nblocks < (1ll << 31), "gemm_nt: too many tiles");
     dim3 grid((unsigned)nblocks);
     hipStream_t st = (hipStream_t)stream;
@@ -669,7 +681,7 @@ extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void
                        (!gate || (ldg % 8 == 0 && ((uintptr_t)gate & 15) == 0)) &&
                        (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0)) &&
                        (!bias || ((uintptr_t)bias & 15) == 0);
-#define NT_ARGS(TT, OT) (const TT *)A, lda, (const TT *)Bt, ldb, (OT *)C, ldc, M, N, K, bias, act, (const TT *)gate, ldg, (const TT *)residual, ldr, vec_ok
+#define NT_ARGS(TT, OT) (const TT *)A, lda, (const TT *)Bt, ldb, (OT *)C, ldc, M, N, K, bias, act, (const TT *)gate, ldg, (const TT *)residual, ldr, vec_ok, xcd_map
     const bool epi = gate || residual;
     if (dtype == B4C_F32) {
         if (epi) gemm_nt_kernel<float, float, true><<<grid, 256, shm, st>>>(NT_ARGS(float, float));
