@@ -47,8 +47,10 @@ def parse():
     ap.add_argument('--n_batches', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_rows', type=int, default=48, help='sequences in the bounded CPU-baseline sample')
-    ap.add_argument('--record_steps', type=int, default=-1,
-                    help='timed steps whose launches are bracketed by HIP events for the roofline (-1 = all, 0 = none)')
+    ap.add_argument('--record_steps', type=int, default=5,
+                    help='timed steps (the first N of the timed region) whose launches are bracketed by HIP events for the roofline; '
+                         '-1 = all (costs ~0.4 ms/step of event overhead), 0 = none')
+    ap.add_argument('--ops_flags', default='', help='A/B switches of bert4clickpath_amd.ops, e.g. "fused_ln=0,sorted_embed_bwd=0"')
     ap.add_argument('--materialised_logits', action='store_true',
                     help='A/B: vocabulary projection writes the (R x V) logits and the CE reads them (ops.flash_ce = False)')
     ap.add_argument('--traffic_json', default=None, help='optional JSON with PMC-derived HBM bytes per launch')
@@ -174,6 +176,10 @@ def main():
 
     if a.materialised_logits:
         ops.flash_ce = False
+    for kv in filter(None, a.ops_flags.split(',')):
+        k, v = kv.split('=')
+        assert hasattr(ops, k), 'unknown ops flag %s' % k
+        setattr(ops, k, bool(int(v)))
     model = build_model(a, device)
     opt = optim.Adam(model.parameters(), order=backward_order(model))
     arena = opt.arena

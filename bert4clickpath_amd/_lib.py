@@ -53,6 +53,7 @@ def lib():
             'b4c_keep': (i32, [u64, u64, f32]),
             'b4c_embed_concat_pe_fwd': (i32, [i32, pp, pp, c.POINTER(i32), c.POINTER(i64), vp, f32, vp, i32, vp, i32, i32, i32, f32, u64, i32, vp]),
             'b4c_embed_concat_pe_bwd': (i32, [i32, pp, pp, c.POINTER(i32), c.POINTER(i64), f32, vp, i32, i32, i32, i32, f32, u64, i32, vp]),
+            'b4c_embed_concat_pe_bwd_sorted': (i32, [i32, pp, pp, pp, c.POINTER(i32), c.POINTER(i64), f32, vp, i32, i32, i32, i32, f32, u64, i32, vp]),
             'b4c_pack_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, vp]),
             'b4c_gemm_nt': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
             'b4c_gemm_nt_add_ln': (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, vp]),

@@ -66,6 +66,13 @@ int b4c_embed_concat_pe_bwd(int n_feat, const int64_t *const *h_ids, float *cons
                             const int *h_dims, const int64_t *h_rows, float scale, const void *dout,
                             int ld_dout, int B, int S, int d_model, float dropout_rate, uint64_t seed,
                             int dtype, void *stream);
+/* same, given for every feature the token indices sorted by id (order[f][p], int32, any order among equal ids):
+ * runs of one id are summed in registers and written once -- two float atomics per distinct id and wave boundary
+ * instead of one per token and column.  The sort is the caller's (one radix sort of B*S keys per feature). */
+int b4c_embed_concat_pe_bwd_sorted(int n_feat, const int64_t *const *h_ids, const int32_t *const *h_order,
+                                   float *const *h_dtables, const int *h_dims, const int64_t *h_rows, float scale,
+                                   const void *dout, int ld_dout, int B, int S, int d_model, float dropout_rate,
+                                   uint64_t seed, int dtype, void *stream);
 
 /* ---- dense layers (R8 projections, R9 FFN, R12 head) --------------------------------
  * replaces tf.keras.layers.Dense call sites transformer.py:112-116,165-166; head.py:35-36.

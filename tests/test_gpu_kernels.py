@@ -144,6 +144,40 @@ def test_embed_concat_pe(ops, dtype, rate):
 
 
 @pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('rate', [0.0, 0.25])
+def test_embed_bwd_sorted_matches_numpy_scatter(ops, dtype, rate):
+    """The sorted (run-summing) embedding backward against np.add.at: Zipf ids with long runs, PAD rows with zero
+    gradient, two features of different widths (one wider than a 128-column pass), ragged last wave."""
+    rng = np.random.default_rng(21)
+    B, S, dims, rows = 37, 131, [136, 8], [500, 7]          # 4847 tokens >= the 4096 threshold of the sorted path
+    d = sum(dims)
+    ids = [np.minimum(rng.zipf(1.3, (B, S)) - 1, r - 1).astype(np.int64) for r in rows]
+    ids[0][:, -5:] = 0
+    tabs = [np.zeros((r, k), np.float32) for r, k in zip(rows, dims)]
+    scale, seed = 3.0, 777
+    dout = rng.normal(size=(B, S, d)).astype(np.float32)
+    dout[:, -5:, :] = 0.0
+    dd = dev(torch.from_numpy(dout), dtype)
+    assert ops.sorted_embed_bwd
+    dtabs = ops.embed_concat_pe_bwd([dev(i) for i in ids], [dev(t) for t in tabs], dd, scale, rate, seed)
+    ops.sorted_embed_bwd = False
+    try:
+        dref = ops.embed_concat_pe_bwd([dev(i) for i in ids], [dev(t) for t in tabs], dd, scale, rate, seed)
+    finally:
+        ops.sorted_embed_bwd = True
+    gd = dd.double().cpu().numpy() * scale
+    if rate > 0:
+        gd = gd * ops.keep_mask(seed, B * S * d, rate).reshape(B, S, d) / (1 - rate)
+    off = 0
+    for f in range(2):
+        ref = np.zeros_like(tabs[f], dtype=np.float64)
+        np.add.at(ref, ids[f].reshape(-1), gd[..., off:off + dims[f]].reshape(-1, dims[f]))
+        off += dims[f]
+        assert rel_err(dtabs[f], torch.from_numpy(ref)) < 1e-5
+        assert rel_err(dtabs[f], dref[f]) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('d,rate', [(64, 0.0), (128, 0.1), (24, 0.0), (256, 0.3), (1024, 0.0)])
 def test_add_dropout_layernorm(ops, dtype, d, rate):
     g = torch.Generator().manual_seed(d)
