@@ -100,6 +100,7 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16_t *__rest
     float *sMask = reinterpret_cast<float *>(sV + S_pad * KSTR);
     int *sLive = reinterpret_cast<int *>(sMask + S_pad);          // per key tile: any unmasked key?
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const float scale2 = scale * 1.4426950408889634f;
     const int li = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
     const int64_t tok0 = (int64_t)b * S;
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16_t *__rest
     __syncthreads();
     for (int k = tid; k < S_pad; k += 512) {
         const bool live = k < S && !key_pad[tok0 + k];
-        sMask[k] = (k >= S) ? -INFINITY : (live ? 0.f : -1e9f);
+        sMask[k] = (k >= S) ? -INFINITY : (live ? 0.f : -1e9f * 1.4426950408889634f);
         if (live) sLive[k >> 5] = 1;     // benign race: every writer stores 1
     }
     __syncthreads();
@@ -169,8 +170,8 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16_t *__rest
                 acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc[kt], 0, 0, 0);
             }
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float sc = acc[kt][t] * scale + sMask[kt * 32 + rowmap(t, hf)];
+            for (int t = 0; t < 16; ++t) {      // scores in log2 units: exp(x) = 2^(x log2 e) costs a multiply less per value
+                const float sc = __builtin_fmaf(acc[kt][t], scale2, sMask[kt * 32 + rowmap(t, hf)]);
                 acc[kt][t] = sc;
                 m = fmaxf(m, sc);
             }
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16_t *__rest
         if (kt < nkt && (sLive[kt] | force)) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const float p = __expf(acc[kt][t] - m);
+                const float p = __builtin_amdgcn_exp2f(acc[kt][t] - m);
                 acc[kt][t] = p;
                 l += p;
             }
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16_t *__rest
                 for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(oacc[dt][4 * tq + j] * inv);
                 *reinterpret_cast<bf16x4 *>(orow + dt * 32 + 8 * tq + 4 * hf) = w;
             }
-        if (hf == 0 && lse) lse[((int64_t)b * H + hh) * S + qrow] = m + logf(l);
+        if (hf == 0 && lse) lse[((int64_t)b * H + hh) * S + qrow] = (m + __log2f(l)) * 0.6931471805599453f;
     }
 }
 
@@ -476,12 +477,13 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
             }
         }
     }
-    for (int q = tid; q < S_pad; q += 512) sLseA[q] = (q < S) ? lbase[q] : INFINITY;
+    for (int q = tid; q < S_pad; q += 512) sLseA[q] = (q < S) ? lbase[q] * 1.4426950408889634f : INFINITY;   // log2 units
 
     const int kt = wave;
     const int key = kt * 32 + r;
     const bool key_live = kt < nkt && key < S && !key_pad[tok0 + key];
-    const float madd = (kt >= nkt || key >= S) ? -INFINITY : (key_live ? 0.f : -1e9f);
+    const float madd = (kt >= nkt || key >= S) ? -INFINITY : (key_live ? 0.f : -1e9f * 1.4426950408889634f);
+    const float scale2 = scale * 1.4426950408889634f;
     const bool tile_live = __any(key_live);
     f32x16 dk[NDT], dv[NDT];
 #pragma unroll
@@ -516,7 +518,7 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int q = rowmap(t, hf);
-                const float p = __expf(sa[t] * scale + madd - sLse[q]);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[t], scale2, madd - sLse[q]));
                 pv[t] = p;
                 dsv[t] = p * (pa[t] - sDelta[q]);
                 *reinterpret_cast<bf16_t *>(sDS + q * TSTR + (kt * 32 + r) * 2) = (bf16_t)dsv[t];
