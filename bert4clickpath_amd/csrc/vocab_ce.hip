@@ -3,18 +3,23 @@
 //
 // At C2 the materialised form moves the 4.1 GB logits tensor through HBM five times per step (projection
 // write, CE read + write, dX read, dW read).  The MI355X has ~300 FLOP per HBM byte to spare, so the logits
-// are recomputed instead: 128 x 128 tiles of  x = h W^T + b  live only in MFMA accumulators, three times:
+// are recomputed instead: 128 x 128 tiles of  x = h W^T + b  live only in MFMA accumulators, twice
+// (three times for rows that TF's clip touches):
 //
-//   K1  stats   (token-owned)  running max / sum-exp / min of every row             -> lse, "clipped" flag
-//   K2  U       (token-owned)  p = exp(x - lse) feeds  U = P W  from the accumulator registers (the P^T tile
-//                              is the B operand of the next MFMA, as in the attention kernels);
-//                              MODE 1 repeats the sweep for rows whose probabilities leave [1e-7, 1-1e-7]
-//                              (TF's clip, backend.py sparse_categorical_crossentropy): Ud = P(1-u) W, S, Pu
-//   K3  combine (row)          loss, dh = gs (Uc / S - G U - yd W_y), row scalars for K4
-//   K4  dW      (vocab-owned)  dlogit = p (u a - b) feeds  dW^T = h^T dlogit  from registers; db = colsum
-//   K5  label term             dW[:, y] -= yd h_row,  db[y] -= yd
+//   sweep 1  (token-owned, vce_token_kernel<K,1>)  online softmax against a lazily raised reference (flash
+//            attention with V = W): p' = 2^(x log2e - m2) feeds  U = P' W  from the accumulator registers (the
+//            P'^T tile is the B operand of the next MFMA); per row: m2, l = sum p', min x, max x -> lse, clip flag
+//   sweep 1b (vce_token_kernel<K,2>)  only for rows whose probabilities leave [1e-7, 1-1e-7] (TF's clip,
+//            backend.py sparse_categorical_crossentropy): Ud = P (1-u) W, S = sum clip(p), Pu = sum u p
+//   combine  (one wave per row)  loss, dh = gs (Uc / S - G U - yd W_y), row scalars for sweep 2
+//   sweep 2  (vocabulary-owned, vce_dw_kernel)  dlogit = p (u a - b) feeds  dW^T = h^T dlogit  from registers;
+//            db = column sums
+//   label term  dW[:, y] -= yd h_row, db[y] -= yd  (coalesced scatter into a vocabulary-major scratch, added transposed)
 //
-// HBM traffic: h, W (L2 / MALL resident, 12.8 MB), per-row partial sums.  Work: 5 GEMM units + 3 R V exps.
+// HBM traffic: h, W (L2 / MALL resident, 12.8 MB), per-row partial sums.  Work: 4 GEMM units + 2 R V exps.
+// W / h tiles arrive by LDS-DMA (buffer_load ... lds) into an XOR-swizzled image that both the direct
+// (ds_read_b128) and the transposed (ds_read_b64_tr_b16) fragment reads hit without bank conflicts.
+// B4C_VCE_TIMING=1 prints per-kernel HIP-event times of the previous call (no synchronisation).
 //
 // MFMA 32x32x16 bf16 maps (lane l: r = l & 31, hf = l >> 5): A[row r][k = 8 hf + j], B[k = 8 hf + j][col r],
 // D reg t: row (t&3) + 8 (t>>2) + 4 hf, col r.  An accumulator tile used as B operand of the next MFMA sums
