@@ -352,6 +352,29 @@ def gemm_nt_add_ln(a, bt, bias, x, gamma, beta, rate, seed, save=True):
     return z, out, stats
 
 
+_lnbwd_ws = {}
+
+
+def gemm_nt_ln_bwd(a, bt, residual, z, stats, gamma, rate, seed, dgamma, dbeta):
+    """(dz, dy) = LayerNorm-backward(a @ bt^T + residual) with dgamma / dbeta accumulated in place:
+    == gemm_nt(residual=) + add_dropout_layernorm_bwd (dz, dy bit for bit), without the intermediate in HBM."""
+    M, K = a.shape
+    n = z.shape[1]
+    dz = torch.empty_like(z)
+    dy = torch.empty_like(z) if rate > 0 else None
+    need = L.lib().b4c_gemm_nt_ln_bwd_workspace_bytes(M)
+    ws = _lnbwd_ws.get(a.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=a.device)
+        _lnbwd_ws[a.device] = ws
+    es = a.element_size()
+    with _record('gemm_nt_ln_bwd', M * K * es + n * K * es + M * n * es * (4 if rate > 0 else 3), 2 * M * n * K):
+        L.check(L.lib().b4c_gemm_nt_ln_bwd(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(residual), residual.stride(0), _p(z),
+                                           _p(stats), _p(gamma), _p(dz), _p(dy), _p(dgamma), _p(dbeta), ws.data_ptr(),
+                                           ws.numel(), M, n, K, rate, seed, dt_code(a.dtype), _st()), 'gemm_nt_ln_bwd')
+    return dz, dy
+
+
 def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed, into=None):
     rows, d = z.shape
     dz = torch.empty_like(z)
