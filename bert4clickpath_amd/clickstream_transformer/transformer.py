@@ -221,6 +221,16 @@ class Encoder(nn.Module):
             raise NotImplementedError('Encoder input dropout is fused into Transformer\'s embedding kernel; '
                                       'call the Transformer, or use training=False / dropout_rate=0')
         x = inputs
+        B, S, d = x.shape
+        layers = [{'mha': l.mha, 'ffn': l.ffn, 'ln1': l.layernorm1, 'ln2': l.layernorm2} for l in self.enc_layers]
+        if mask is not None and mask.dtype == torch.uint8 and mask.dim() == 2 and \
+                ops.encoder_stack_supported(x, layers, bool(training), self.dropout_rate):
+            # one autograd node for the whole stack: LayerNorm backward runs in GEMM epilogues (ops.EncoderStackFn)
+            for lay in layers:
+                lay['s1'], lay['s2'] = dropout_seeds.next(), dropout_seeds.next()
+            out = ops.EncoderStackFn.apply(x.reshape(B * S, d), mask, layers, B, S, self.enc_layers[0].num_heads,
+                                           float(self.dropout_rate))
+            return out.view(B, S, d)
         for layer in self.enc_layers:
             x = layer(x, training, mask)
         return x
