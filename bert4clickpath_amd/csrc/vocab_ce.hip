@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
 // so the rows are first added into a vocabulary-major scratch [V][KD] (coalesced atomics, one wave per row), which
 // is then added transposed.
 #define VCE_HOT 64          // labels < VCE_HOT (the head of a frequency-ranked vocabulary) are pre-summed in LDS
-#define VCE_LABEL_ROWS 512  // rows per workgroup
+#define VCE_LABEL_ROWS 128  // rows per workgroup
 template <int KD>
 __global__ void __launch_bounds__(256) vce_label_kernel(VceDwArgs a, const int32_t *__restrict__ labels, float *__restrict__ tmp) {
     __shared__ float hot[VCE_HOT][KD + 1];      // [..][KD] = the bias term
@@ -661,16 +661,17 @@ __global__ void __launch_bounds__(256) vce_label_add_kernel(float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-static int vce_pick_split(int64_t units, int64_t max_split) {
-    // smallest power of two <= 8 that fills the 256 CUs to >= 90 % in the last round
+// Split `units` workgroup-sized pieces of work into units * p workgroups for 256 CUs (one workgroup per CU at a time):
+// time ~ rounds(p) / p, plus a cost per extra split (partial results to combine: `penalty`, in units of one
+// unsplit workgroup's run time).  C2: 320 token tiles -> 4 parts (1280 workgroups, 5 full rounds);
+// 391 vocabulary tiles -> 5 token splits (8 rounds instead of 13 for 8 splits, and 5/8 of the dW atomics).
+static int vce_pick_split(int64_t units, int64_t max_split, double penalty) {
     int best = 1;
-    double best_eff = 0.0;
-    for (int p = 1; p <= 8; p *= 2) {
+    double best_t = 1e30;
+    for (int p = 1; p <= 8; ++p) {
         if (p > max_split) break;
-        const int64_t wg = units * p;
-        const double eff = (double)wg / (double)(ceil_div64(wg, 256) * 256);
-        if (eff > best_eff + 0.02) { best_eff = eff; best = p; }
-        if (best_eff >= 0.9) break;
+        const double t = (double)ceil_div64(units * p, 256) / p + penalty * p;
+        if (t < best_t - 1e-9) { best_t = t; best = p; }
     }
     return best;
 }
@@ -701,7 +702,7 @@ template <int KD>
 static int vce_fwd_launch(VceArgs a, hipStream_t st) {
     const int64_t ntt = ceil_div64(a.R, 128);
     const int nvt = (a.V + 127) / 128;
-    a.parts = vce_pick_split(ntt, nvt);
+    a.parts = vce_pick_split(ntt, nvt, 0.005);
     float *ws = a.st1;
     a.u = ws + (int64_t)a.parts * a.R * 4;
     a.ud = a.u + (int64_t)a.parts * a.R * KD;
@@ -758,7 +759,7 @@ template <int KD>
 static int vce_dw_launch(VceDwArgs a, const int32_t *labels, float *tmp, hipStream_t st) {
     const int nvt = (a.V + 127) / 128;
     const int64_t ntt = ceil_div64(a.R, 128);
-    a.tsplit = vce_pick_split(nvt, ntt);
+    a.tsplit = vce_pick_split(nvt, ntt, 0.025);
     const size_t lds = vce_dw_lds<KD>();
     static thread_local bool done = false;
     if (!done) { vce_allow_lds(vce_dw_kernel<KD>, lds); done = true; }
