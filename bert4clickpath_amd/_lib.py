@@ -25,6 +25,13 @@ class PackDesc(ctypes.Structure):
                 ('ld_c', ctypes.c_int32), ('col_off', ctypes.c_int32), ('_pad', ctypes.c_int32)]
 
 
+class TNDesc(ctypes.Structure):
+    """b4c_tn_desc of include/b4c.h."""
+    _fields_ = [('A', ctypes.c_void_p), ('G', ctypes.c_void_p), ('dW', ctypes.c_void_p * 4), ('db', ctypes.c_void_p * 4),
+                ('lda', ctypes.c_int32), ('ldg', ctypes.c_int32), ('K', ctypes.c_int32), ('n_seg', ctypes.c_int32),
+                ('seg_width', ctypes.c_int32), ('ldw', ctypes.c_int32)]
+
+
 def declared_symbols(header_path=HEADER_PATH):
     """Names of every function include/b4c.h declares (used by the symbol-export test)."""
     with open(header_path) as f:
@@ -59,6 +66,8 @@ def lib():
             'b4c_gemm_nt_add_ln': (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, vp]),
             'b4c_gemm_nt_ln_bwd_workspace_bytes': (i64, [i32]),
             'b4c_gemm_nt_ln_bwd': (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, u64, i32, vp]),
+            'b4c_gemm_tn_group_workspace_bytes': (i64, [vp, i32, i32]),
+            'b4c_gemm_tn_group': (i32, [vp, i32, i32, i32, vp, i64, vp]),
             'b4c_gemm_tn_workspace_bytes': (i64, [i32, i32, i32, i32]),
             'b4c_gemm_tn': (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i64, vp]),
             'b4c_gemm_tn_seg': (i32, [vp, i32, vp, i32, i32, pp, pp, i32, i32, i32, i32, vp, i64, vp]),

@@ -919,11 +919,12 @@ __device__ __forceinline__ float *tn_b_ptr(const TNOut &o, int col) {
 //   TN_DIRECT: one split only -> plain read-modify-write;
 //   TN_ATOMIC: float atomics (no workspace given).  256 splits hitting the same 512 cache lines serialise
 //              at the memory-side atomic unit: 28 us for 16 MB at C2, which is why TN_WS exists.
+struct TNBlock { int bx, by, bz, gx, gy; };     // tile coordinates / tile-grid size of one problem (a launch may hold several)
 __device__ __forceinline__ void tn_emit_tile(const TNOut &out, const f32x16 (&acc)[2][2], int k0, int n0, int K, int N,
-                                             int wave, int lane) {
+                                             int wave, int lane, const TNBlock &bk) {
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     if (out.mode == TN_WS) {
-        const int64_t tile = ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y;
+        const int64_t tile = ((int64_t)bk.bz * bk.gx + bk.bx) * bk.gy + bk.by;
         f32x4 *w = reinterpret_cast<f32x4 *>(out.ws) + tile * 4096;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -953,10 +954,10 @@ __device__ __forceinline__ void tn_emit_tile(const TNOut &out, const f32x16 (&ac
         }
 }
 // column sums of the workgroup's 128 columns (red[128] in LDS, complete)
-__device__ __forceinline__ void tn_emit_bias(const TNOut &out, const float *red, int n0, int N, int tid) {
+__device__ __forceinline__ void tn_emit_bias(const TNOut &out, const float *red, int n0, int N, int tid, const TNBlock &bk) {
     if (tid >= 128) return;
     if (out.mode == TN_WS) {
-        out.ws_db[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * 128 + tid] = red[tid];
+        out.ws_db[((int64_t)bk.bz * bk.gy + bk.by) * 128 + tid] = red[tid];
     } else if (n0 + tid < N) {
         float *p = tn_b_ptr(out, n0 + tid);
         if (out.mode == TN_DIRECT) *p += red[tid];
@@ -967,13 +968,13 @@ __device__ __forceinline__ void tn_emit_bias(const TNOut &out, const float *red,
 // Second pass of TN_WS (latency-bound: every thread has at most ceil(nsplit/64) independent 16-B loads in
 // flight).  Blocks [0, tiles*256): 1024 threads = 16 float4 groups of one output tile x 64 split phases;
 // shuffles, then LDS across the 16 waves, then dW += sum.  Blocks [tiles*256, +tn): column sums.
-__global__ void __launch_bounds__(1024) tn_reduce_kernel(TNOut out, int K, int N, int tk, int tn, int nsplit) {
+__device__ __forceinline__ void tn_reduce_body(const TNOut &out, int K, int N, int tk, int tn, int nsplit, int blk) {
     __shared__ f32x4 part[16][16];
     const int tid = threadIdx.x;
     const int tiles = tk * tn;
-    if ((int)blockIdx.x >= tiles * 256) {
+    if (blk >= tiles * 256) {
         if (!out.db[0]) return;
-        const int by = blockIdx.x - tiles * 256, c = tid & 127, zp = tid >> 7;
+        const int by = blk - tiles * 256, c = tid & 127, zp = tid >> 7;
         float s = 0.f;
         for (int z = zp; z < nsplit; z += 8) s += out.ws_db[((int64_t)z * tn + by) * 128 + c];
         float *red = reinterpret_cast<float *>(part);
@@ -987,7 +988,7 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(TNOut out, int K, int N
         }
         return;
     }
-    const int tile = blockIdx.x >> 8, grp = ((blockIdx.x & 255) << 4) + (tid & 15), zp = tid >> 4;
+    const int tile = blk >> 8, grp = ((blk & 255) << 4) + (tid & 15), zp = tid >> 4;
     const f32x4 *w = reinterpret_cast<const f32x4 *>(out.ws) + (int64_t)tile * 4096 + grp;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     const int64_t zstride = (int64_t)tiles * 4096;
@@ -1013,6 +1014,10 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(TNOut out, int K, int N
             for (int k = 0; k < 4; ++k)
                 if (row + k < K) *tn_w_ptr(out, row + k, col) += v[k];
     }
+}
+
+__global__ void __launch_bounds__(1024) tn_reduce_kernel(TNOut out, int K, int N, int tk, int tn, int nsplit) {
+    tn_reduce_body(out, K, N, tk, tn, nsplit, (int)blockIdx.x);
 }
 
 template <typename T> struct TNStage;
@@ -1140,7 +1145,8 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T *__restrict__ A, i
             __syncthreads();
         }
     }
-    tn_emit_tile(out, acc, k0, n0, K, N, wave, lane);
+    const TNBlock bk = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y};
+    tn_emit_tile(out, acc, k0, n0, K, N, wave, lane, bk);
     if (want_db) {
         // the 4 waves hold partial sums of the same features over different tokens
         float *red = reinterpret_cast<float *>(smem);  // all MFMA reads are behind the last barrier
@@ -1150,7 +1156,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T *__restrict__ A, i
         __syncthreads();
         if (tid < 128) red[tid] = tmp[tid] + tmp[128 + tid] + tmp[256 + tid] + tmp[384 + tid];
         __syncthreads();
-        tn_emit_bias(out, red, n0, N, tid);
+        tn_emit_bias(out, red, n0, N, tid, bk);
     }
 }
 
@@ -1187,14 +1193,13 @@ __device__ __forceinline__ void tn_store16(char *s, int tid, const u32x4 (&reg)[
 }
 
 template <int D>
-__global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ G, int ldg,
-                                                           TNOut out, int64_t M,
-                                                           int K, int N, int64_t chunk) {
+__device__ __forceinline__ void tn_bf16_body(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ G, int ldg,
+                                             const TNOut &out, int64_t M, int K, int N, int64_t chunk, const TNBlock &bk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5, li = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
-    const int64_t m_begin = blockIdx.z * chunk;
+    const int k0 = bk.bx * TILE, n0 = bk.by * TILE;
+    const int64_t m_begin = bk.bz * chunk;
     const int64_t m_end = (m_begin + chunk < M) ? m_begin + chunk : M;
     f32x16 acc[2][2];
 #pragma unroll
@@ -1206,7 +1211,7 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restr
     float bs[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bs[k] = 0.f;
-    const bool want_db = (out.db[0] != nullptr) && blockIdx.x == 0;
+    const bool want_db = (out.db[0] != nullptr) && bk.bx == 0;
     const int nsteps = (int)((m_end - m_begin + 63) / 64);
     char *sA = smem, *sG = smem + TN_TILE_BYTES;
     // D register sets: while the MFMAs run on the tile in LDS, tiles st+1 .. st+D are in flight (the barriers
@@ -1263,7 +1268,7 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restr
             }
         }
     }
-    tn_emit_tile(out, acc, k0, n0, K, N, wave, lane);
+    tn_emit_tile(out, acc, k0, n0, K, N, wave, lane, bk);
     if (want_db) {
         float *red = reinterpret_cast<float *>(smem);   // all fragment reads are behind the last barrier
         float *tmp = red + 128;                          // [16 token rows of the staging pattern][128 columns]
@@ -1277,7 +1282,54 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restr
             red[tid] = t;
         }
         __syncthreads();
-        tn_emit_bias(out, red, n0, N, tid);
+        tn_emit_bias(out, red, n0, N, tid, bk);
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ G, int ldg,
+                                                           TNOut out, int64_t M, int K, int N, int64_t chunk) {
+    const TNBlock bk = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y};
+    tn_bf16_body<D>(A, lda, G, ldg, out, M, K, N, chunk, bk);
+}
+
+// Several dW problems over the SAME token axis in one launch (the four weight gradients of an encoder layer):
+// blockIdx.x walks the output tiles of all problems, blockIdx.z the token splits.  The ~256 workgroups are shared
+// by all problems, so each output tile has ~256 / tiles partial sums instead of 256 -- 6x less partial-tile
+// traffic at C2 -- and the layer needs one main + one reduce launch instead of four of each.
+#define TN_GROUP_MAX 8
+struct TNProb {
+    const bf16_t *A, *G;
+    int lda, ldg, K, N, tk, tn, tile0;      // tile0 = index of the problem's first tile in the launch
+    TNOut out;
+};
+struct TNGroup {
+    TNProb p[TN_GROUP_MAX];
+    int np, tiles;
+};
+template <int D>
+__global__ void __launch_bounds__(256) gemm_tn_bf16_group_kernel(TNGroup g, int64_t M, int64_t chunk) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < TN_GROUP_MAX; ++i)
+        if (i < g.np && (int)blockIdx.x >= g.p[i].tile0) pi = i;
+    const TNProb &pr = g.p[pi];
+    const int lt = blockIdx.x - pr.tile0;
+    const TNBlock bk = {lt / pr.tn, lt % pr.tn, (int)blockIdx.z, pr.tk, pr.tn};
+    tn_bf16_body<D>(pr.A, pr.lda, pr.G, pr.ldg, pr.out, M, pr.K, pr.N, chunk, bk);
+}
+
+// one reduce launch for the whole group: blocks are laid out problem after problem (tiles * 256 + tn blocks each)
+__global__ void __launch_bounds__(1024) tn_reduce_group_kernel(TNGroup g, int nsplit) {
+    int blk = blockIdx.x;
+    for (int i = 0; i < g.np; ++i) {
+        const TNProb &pr = g.p[i];
+        const int nb = pr.tk * pr.tn * 256 + pr.tn;
+        if (blk < nb) {
+            tn_reduce_body(pr.out, pr.K, pr.N, pr.tk, pr.tn, nsplit, blk);
+            return;
+        }
+        blk -= nb;
     }
 }
 
@@ -1360,4 +1412,71 @@ extern "C" int b4c_gemm_tn_seg(const void *A, int lda, const void *G, int ldg, i
         out.db[i] = h_db ? h_db[i] : nullptr;
     }
     return gemm_tn_launch(A, lda, G, ldg, out, M, K, n_seg * seg_width, dtype, workspace, workspace_bytes, stream);
+}
+
+// ---- grouped dW: several (A_i^T G_i) over the same M tokens in one launch ----
+static void tn_group_plan(int M, int tiles, int64_t *nsplit, int64_t *chunk) {
+    int64_t ns = (256 + tiles / 2) / tiles;
+    const int64_t max_split = ceil_div64(M, 64 * 4);
+    if (ns > max_split) ns = max_split;
+    if (ns < 1) ns = 1;
+    *chunk = ceil_div64(ceil_div64(M, ns), 64) * 64;
+    *nsplit = ceil_div64(M, *chunk);
+}
+static int tn_group_tiles(const b4c_tn_desc *d, int n) {
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += (int)(ceil_div64(d[i].K, TILE) * ceil_div64((int64_t)d[i].n_seg * d[i].seg_width, TILE));
+    return tiles;
+}
+
+extern "C" int64_t b4c_gemm_tn_group_workspace_bytes(const b4c_tn_desc *h_desc, int n_prob, int M) {
+    if (!h_desc || n_prob <= 0 || M <= 0) return 0;
+    int64_t nsplit, chunk, bytes = 0;
+    tn_group_plan(M, tn_group_tiles(h_desc, n_prob), &nsplit, &chunk);
+    for (int i = 0; i < n_prob; ++i) {
+        const int64_t tk = ceil_div64(h_desc[i].K, TILE), tn = ceil_div64((int64_t)h_desc[i].n_seg * h_desc[i].seg_width, TILE);
+        bytes += nsplit * (tk * tn * 16384 + tn * 128) * 4;
+    }
+    return bytes;
+}
+
+extern "C" int b4c_gemm_tn_group(const b4c_tn_desc *h_desc, int n_prob, int M, int dtype, void *workspace, int64_t workspace_bytes,
+                                 void *stream) {
+    B4C_REQUIRE(h_desc && n_prob >= 1 && n_prob <= TN_GROUP_MAX && M > 0, "gemm_tn_group: n_prob %d (1..%d), M %d", n_prob, TN_GROUP_MAX, M);
+    B4C_REQUIRE(dtype == B4C_BF16, "gemm_tn_group: bf16 only (dtype %d)", dtype);
+    B4C_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= b4c_gemm_tn_group_workspace_bytes(h_desc, n_prob, M),
+                "gemm_tn_group: workspace missing / too small");
+    TNGroup g = {};
+    g.np = n_prob;
+    int64_t nsplit, chunk;
+    tn_group_plan(M, tn_group_tiles(h_desc, n_prob), &nsplit, &chunk);
+    float *ws = (float *)workspace;
+    int reduce_blocks = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        const b4c_tn_desc &d = h_desc[i];
+        const int N = d.n_seg * d.seg_width;
+        B4C_REQUIRE(d.A && d.G && d.K > 0 && N > 0 && d.n_seg >= 1 && d.n_seg <= 4 && d.lda >= d.K && d.ldg >= N, "gemm_tn_group: problem %d shape", i);
+        B4C_REQUIRE(d.lda % 8 == 0 && d.ldg % 8 == 0 && ((((uintptr_t)d.A | (uintptr_t)d.G) & 15) == 0), "gemm_tn_group: problem %d needs 16-byte aligned operands, pitches %% 8 == 0", i);
+        TNProb &p = g.p[i];
+        p.A = (const bf16_t *)d.A; p.G = (const bf16_t *)d.G; p.lda = d.lda; p.ldg = d.ldg; p.K = d.K; p.N = N;
+        p.tk = (int)ceil_div64(d.K, TILE); p.tn = (int)ceil_div64(N, TILE); p.tile0 = g.tiles;
+        g.tiles += p.tk * p.tn;
+        p.out = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}, d.seg_width, d.ldw, nsplit == 1 ? TN_DIRECT : TN_WS, nullptr, nullptr};
+        for (int sgi = 0; sgi < d.n_seg; ++sgi) {
+            B4C_REQUIRE(d.dW[sgi], "gemm_tn_group: problem %d segment %d has no dW", i, sgi);
+            p.out.dW[sgi] = d.dW[sgi];
+            p.out.db[sgi] = d.db[sgi];
+        }
+        B4C_REQUIRE(d.ldw >= d.seg_width, "gemm_tn_group: problem %d ldw", i);
+        if (nsplit > 1) {
+            p.out.ws = ws;
+            p.out.ws_db = ws + nsplit * p.tk * p.tn * 16384;
+            ws = p.out.ws_db + nsplit * p.tn * 128;
+        }
+        reduce_blocks += p.tk * p.tn * 256 + p.tn;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    gemm_tn_bf16_group_kernel<2><<<dim3(g.tiles, 1, (unsigned)nsplit), 256, 2 * TN_TILE_BYTES, st>>>(g, M, chunk);
+    if (nsplit > 1) tn_reduce_group_kernel<<<reduce_blocks, 1024, 0, st>>>(g, (int)nsplit);
+    return b4c_check_launch("gemm_tn_group");
 }

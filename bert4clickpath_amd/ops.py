@@ -268,6 +268,54 @@ def _gemm_tn_impl(a, g, K, N, want_bias, into):
     return dW, db
 
 
+# ---- grouped weight gradients: the dW GEMMs of an encoder layer are off the critical path (nothing in backward
+# consumes them), so in arena mode they are queued and launched together (b4c_gemm_tn_group: one main + one reduce
+# kernel per layer instead of four of each, and ~6x less partial-tile traffic).
+grouped_dw = True
+_pending_dw = []        # (a, g, K, N, dWs, dbs, params) -- the tensors are kept alive until the flush
+
+
+def queue_dw(a, g, K, N, dWs, dbs, params):
+    """dW_i += a^T g (column segments), db_i += colsum(g) -- now or with the next flush_pending_dw()."""
+    ok = grouped_dw and a.dtype == torch.bfloat16 and a.stride(0) % 8 == 0 and g.stride(0) % 8 == 0 and \
+        a.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and a.shape[0] >= 4096
+    if not ok:
+        gemm_tn(a, g, K, N, into=(dWs, dbs))
+        _ready(*params)
+        return
+    if _pending_dw and (_pending_dw[0][0].shape[0] != a.shape[0] or len(_pending_dw) == 8):
+        flush_pending_dw()
+    _pending_dw.append((a, g, K, N, dWs, dbs, params))
+
+
+def flush_pending_dw():
+    if not _pending_dw:
+        return
+    items = list(_pending_dw)
+    del _pending_dw[:]
+    M = items[0][0].shape[0]
+    descs = (L.TNDesc * len(items))()
+    nbytes = flops = 0
+    for d, (a, g, K, N, dWs, dbs, _) in zip(descs, items):
+        d.A, d.G, d.lda, d.ldg, d.K = a.data_ptr(), g.data_ptr(), a.stride(0), g.stride(0), K
+        d.n_seg, d.seg_width, d.ldw = len(dWs), N // len(dWs), dWs[0].stride(0)
+        for i, (w, b) in enumerate(zip(dWs, dbs)):
+            d.dW[i] = w.data_ptr()
+            d.db[i] = b.data_ptr() if b is not None else None
+        nbytes += M * (K + N) * a.element_size() + K * N * 4
+        flops += 2 * M * K * N
+    need = L.lib().b4c_gemm_tn_group_workspace_bytes(descs, len(items), M)
+    dev = items[0][0].device
+    ws = _tn_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=dev)
+        _tn_ws[dev] = ws
+    with _record('gemm_tn', nbytes, flops):
+        L.check(L.lib().b4c_gemm_tn_group(descs, len(items), M, L.BF16, ws.data_ptr(), ws.numel(), _st()), 'gemm_tn_group')
+    for it in items:
+        _ready(*it[6])
+
+
 # ---- in-place gradient accumulation (arena mode, optim.FlatArena): weight-gradient kernels add with float
 # atomics anyway, so they add straight into param.grad and autograd receives None for those inputs.
 inplace_grads = False
@@ -685,6 +733,7 @@ class EmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _):
+        flush_pending_dw()
         saved = ctx.saved_tensors
         ids, tables = list(saved[:ctx.n]), list(saved[ctx.n:])
         if _inplace_ok(*tables):
@@ -734,16 +783,21 @@ class AttnBlockFn(torch.autograd.Function):
                                                           into=(gam.grad, bet.grad) if inplace else None)
         _, wc_o, _ = pk_o.get(x.dtype, d, True)
         _, wc_qkv, _ = pk_qkv.get(x.dtype, d, True)
-        dWo, dbo = gemm_tn(o, dy, d, d, into=([wo.grad], [bo.grad]) if inplace else None)
+        if inplace:
+            queue_dw(o, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
+        else:
+            dWo, dbo = gemm_tn(o, dy, d, d)
         d_o = gemm_nt(dy, wc_o, d)
         with _timed('attn_bwd'):
             dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh)
-        with _timed('qkv_dw'):
-            dWqkv, dbqkv = gemm_tn(x, dqkv, d, 3 * d,
-                                   into=([wq.grad, wk.grad, wv.grad], [bq.grad, bk.grad, bv.grad]) if inplace else None)
+        if inplace:
+            queue_dw(x, dqkv, d, 3 * d, [wq.grad, wk.grad, wv.grad], [bq.grad, bk.grad, bv.grad], (wq, bq, wk, bk, wv, bv))
+        else:
+            dWqkv, dbqkv = gemm_tn(x, dqkv, d, 3 * d)
         dx = gemm_nt(dqkv, wc_qkv, d, residual=dz)
         if inplace:
-            _ready(*ctx.params)
+            _ready(gam, bet)
+            flush_pending_dw()          # this layer's four weight gradients (two queued by FFNBlockFn.backward) in one launch
             return (dx,) + (None,) * 19
         (gq, gk, gv), (gbq, gbk, gbv) = pk_qkv.split_grads(dWqkv, dbqkv)
         return (dx, None, gq, gbq, gk, gbk, gv, gbv, dWo, dbo, dgamma, dbeta) + (None,) * 8
@@ -785,12 +839,18 @@ class FFNBlockFn(torch.autograd.Function):
                                                           into=(gam.grad, bet.grad) if inplace else None)
         _, wc1, _ = pk1.get(x.dtype, d, True)
         _, wc2, _ = pk2.get(x.dtype, Fp, True)
-        dW2, db2 = gemm_tn(h, dy, pk2.K, d, into=([w2.grad], [b2.grad]) if inplace else None)
+        if inplace:
+            queue_dw(h, dy, pk2.K, d, [w2.grad], [b2.grad], (w2, b2))
+        else:
+            dW2, db2 = gemm_tn(h, dy, pk2.K, d)
         dh = gemm_nt(dy, wc2, Fp, gate=h)
-        dW1, db1 = gemm_tn(x, dh, d, pk1.N, into=([w1.grad], [b1.grad]) if inplace else None)
+        if inplace:
+            queue_dw(x, dh, d, pk1.N, [w1.grad], [b1.grad], (w1, b1))
+        else:
+            dW1, db1 = gemm_tn(x, dh, d, pk1.N)
         dx = gemm_nt(dh, wc1, d, residual=dz)
         if inplace:
-            _ready(*ctx.params)
+            _ready(gam, bet)
             return (dx,) + (None,) * 11
         return (dx, dW1, db1, dW2, db2, dgamma, dbeta) + (None,) * 5
 

@@ -93,6 +93,8 @@ class GradReducer:
 
     def finish(self):
         """Call after loss.backward(): reduces whatever has not been launched and waits."""
+        from . import ops
+        ops.flush_pending_dw()          # queued weight-gradient GEMMs (ops.queue_dw) must land before their bucket is reduced
         if self.world <= 1:
             return
         if self._pending is None:

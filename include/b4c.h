@@ -148,6 +148,21 @@ int b4c_gemm_tn_seg(const void *A, int lda, const void *G, int ldg, int n_seg, f
                     float *const *h_db, int seg_width, int M, int K, int dtype, void *workspace,
                     int64_t workspace_bytes, void *stream);
 
+/* several dW problems over the SAME M tokens in one launch (bf16; the four weight gradients of an encoder layer):
+ * the ~256 workgroups of the split are shared by all problems, so every output tile has ~256 / (total tiles)
+ * partial sums, and the group needs one main + one reduce kernel.  Problem i: dW_i[K][n_seg * seg_width] split into
+ * n_seg column segments as b4c_gemm_tn_seg.  h_desc is a HOST array.  Always deterministic (workspace required). */
+typedef struct {
+    const void *A;          /* [M][lda], K columns used */
+    const void *G;          /* [M][ldg], n_seg * seg_width columns used */
+    float *dW[4];           /* device pointers, [K][ldw] each */
+    float *db[4];           /* or NULL */
+    int32_t lda, ldg, K, n_seg, seg_width, ldw;
+} b4c_tn_desc;
+int64_t b4c_gemm_tn_group_workspace_bytes(const b4c_tn_desc *h_desc, int n_prob, int M);
+int b4c_gemm_tn_group(const b4c_tn_desc *h_desc, int n_prob, int M, int dtype, void *workspace, int64_t workspace_bytes,
+                      void *stream);
+
 /* ---- R8: attention -------------------------------------------------------------------
  * replaces MultiHeadAttention.split_heads + scaled_dot_product_attention + merge
  * (transformer.py:64-97, 130-156).  qkv: [B*S][ld_qkv] with q | k | v column blocks of d_model

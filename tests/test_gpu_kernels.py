@@ -416,3 +416,32 @@ def test_gemm_nt_ln_bwd_is_bit_identical_to_the_two_kernels(ops, M, N, K, rate):
     else:
         assert dy1 is None
     assert rel_err(dg1, dg0) < 1e-5 and rel_err(db1, db0) < 1e-5
+
+
+def test_gemm_tn_group_matches_single_launches(ops):
+    """b4c_gemm_tn_group (the weight gradients of an encoder layer in one launch) == the single launches: exact on
+    integer data, segments (Q | K | V) included; accumulates into existing values; bit-repeatable."""
+    from bert4clickpath_amd import _lib as L
+    rng = np.random.default_rng(9)
+    M = 5000
+    probs = [(104, 128, 1), (128, 104, 1), (128, 128, 1), (128, 384, 3)]
+    items, refs = [], []
+    for K, N, nseg in probs:
+        Kp, Np = (K + 7) // 8 * 8, (N + 7) // 8 * 8
+        a = torch.tensor(rng.integers(-3, 4, (M, Kp)), dtype=torch.float32, device='cuda').bfloat16()
+        g = torch.tensor(rng.integers(-3, 4, (M, Np)), dtype=torch.float32, device='cuda').bfloat16()
+        dWs = [torch.ones(K, N // nseg, device='cuda') for _ in range(nseg)]
+        dbs = [torch.ones(N // nseg, device='cuda') for _ in range(nseg)]
+        items.append((a, g, K, N, dWs, dbs, ()))
+        dW = a[:, :K].double().T @ g[:, :N].double()
+        refs.append((dW, g[:, :N].double().sum(0)))
+    assert ops.grouped_dw
+    for it in items:
+        ops.queue_dw(*it)
+    assert len(ops._pending_dw) == 4
+    ops.flush_pending_dw()
+    assert not ops._pending_dw
+    for (a, g, K, N, dWs, dbs, _), (dW, db) in zip(items, refs):
+        got = torch.cat(dWs, dim=1).double() - 1.0
+        assert torch.equal(got, dW), (K, N)
+        assert torch.equal(torch.cat(dbs).double() - 1.0, db)
