@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, i
 // ------------------------------------------------------------------------------------------
 #define LN_OUT_STRIDE 264   // bytes per staged row: 256 + 8 (8-byte writes of 16 rows spread over the 32 write banks)
 
-__global__ void __launch_bounds__(256) gemm_nt_ln_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ Bt, int ldb,
+__global__ void __launch_bounds__(256, 3) gemm_nt_ln_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ Bt, int ldb,
                                                          const float *__restrict__ bias, const bf16_t *__restrict__ x, int ldx,
                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
                                                          bf16_t *__restrict__ z, bf16_t *__restrict__ out, float *__restrict__ stats,
