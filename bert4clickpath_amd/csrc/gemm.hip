@@ -152,7 +152,7 @@ __device__ __forceinline__ void epilogue8(float (&v)[8], int64_t row, int col, O
 #define OUT_STRIDE 136   // bytes per staged output row (128 + 8: 8-byte writes spread over the banks)
 
 template <typename T, typename OutT, bool EPI>
-__global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, int lda, const T *__restrict__ Bt, int ldb,
+__global__ void __launch_bounds__(256, 3) gemm_nt_kernel(const T *__restrict__ A, int lda, const T *__restrict__ Bt, int ldb,
                                                       OutT *__restrict__ C, int ldc, int M, int N, int K,
                                                       const float *__restrict__ bias, int act, const T *__restrict__ gate,
                                                       int ldg, const T *__restrict__ residual, int ldr, int vec_ok, int xcd_map) {
@@ -207,8 +207,10 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, i
             nt_load<T>(A, lda, m0, M, (kt + 1) * MM<T>::BKE, K, tid, xa);
             nt_load<T>(Bt, ldb, n0, N, (kt + 1) * MM<T>::BKE, K, tid, xb);
         } else if (EPI && vec && epi) {
+            // the first half of the epilogue operand rides under the last tile's MFMAs, the second half is requested
+            // right after them (16 registers less: three workgroups per CU instead of two)
 #pragma unroll
-            for (int q = 0; q < (EPI ? 8 : 1); ++q) {
+            for (int q = 0; q < (EPI ? 4 : 1); ++q) {
                 const int64_t grow = m0 + wm * 64 + ((lane + q * 64) >> 3);
                 pe[q] = (grow < M && gcol < N) ? *reinterpret_cast<const u32x4 *>(epi + grow * lde + gcol) : (u32x4){0u, 0u, 0u, 0u};
             }
@@ -223,6 +225,13 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T *__restrict__ A, i
     }
     // acc[j][i] register t: n = j*32 + (t&3) + 8*(t>>2) + 4*h (4 consecutive n per t>>2), m = i*32 + r.
     if (vec) {
+        if (EPI && epi) {
+#pragma unroll
+            for (int q = 4; q < (EPI ? 8 : 4); ++q) {
+                const int64_t grow = m0 + wm * 64 + ((lane + q * 64) >> 3);
+                pe[EPI ? q : 0] = (grow < M && gcol < N) ? *reinterpret_cast<const u32x4 *>(epi + grow * lde + gcol) : (u32x4){0u, 0u, 0u, 0u};
+            }
+        }
         char *ws = smem + wave * (64 * OUT_STRIDE);
 #pragma unroll
         for (int j = 0; j < 2; ++j)

@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const T *__restrict__ x
 // backward: dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dout * gamma.
 // dgamma/dbeta: per-thread partials over the block's rows -> LDS -> one atomic per column per block.
 template <typename T, int G>
-__global__ void __launch_bounds__(256) add_ln_bwd_kernel(const T *__restrict__ dout, const T *__restrict__ z,
+__global__ void __launch_bounds__(256, 4) add_ln_bwd_kernel(const T *__restrict__ dout, const T *__restrict__ z,
                                                          const float *__restrict__ stats, const float *__restrict__ gamma,
                                                          T *__restrict__ dz, T *__restrict__ dy, float *__restrict__ dgamma,
                                                          float *__restrict__ dbeta, int64_t rows, int d, float rate,
