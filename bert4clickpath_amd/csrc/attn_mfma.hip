@@ -88,7 +88,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 // forward: 512 threads, wave w owns query tile w (S <= 256 -> at most 8 tiles)
 // ------------------------------------------------------------------------------------------
 template <int DH>
-__global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
+__global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
                                                             bf16_t *__restrict__ o, int ld_o, float *__restrict__ lse, int S, int H,
                                                             float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -157,64 +157,68 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16_t *__rest
     for (int kt = 0; kt < ATT_MAX_KT; ++kt) any_live |= (kt < nkt) ? sLive[kt] : 0;
     const int force = !any_live;
 
-    f32x16 acc[ATT_MAX_KT];
-    float m = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < ATT_MAX_KT; ++kt) {
-        if (kt < nkt && (sLive[kt] | force)) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[kt][t] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sK + (kt * 32 + r) * KSTR + ks * 32 + hf * 16);
-                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc[kt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {      // scores in log2 units: exp(x) = 2^(x log2 e) costs a multiply less per value
-                const float sc = __builtin_fmaf(acc[kt][t], scale2, sMask[kt * 32 + rowmap(t, hf)]);
-                acc[kt][t] = sc;
-                m = fmaxf(m, sc);
-            }
-        }
-    }
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < ATT_MAX_KT; ++kt) {
-        if (kt < nkt && (sLive[kt] | force)) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float p = __builtin_amdgcn_exp2f(acc[kt][t] - m);
-                acc[kt][t] = p;
-                l += p;
-            }
-        }
-    }
-    l += __shfl_xor(l, 32);
+    // Online softmax over the key tiles (one 32 x 32 score tile live at a time instead of all of them: ~100 registers,
+    // two workgroups per CU).  Scores are in log2 units; p = 2^(s - m) against a per-query reference m that is raised
+    // -- with l and O rescaled -- only when a score exceeds it by 2^12 (after the first live tile that is rare), so
+    // the usual per-tile rescale of O disappears.  The two lanes of a query (key halves) share m: their P values
+    // meet in the same PV MFMA.
+    float m = -INFINITY, l = 0.f;
     f32x16 oacc[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int t = 0; t < 16; ++t) oacc[dt][t] = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (!(sLive[kt] | force)) continue;       // wave-uniform
+        f32x16 acc;
 #pragma unroll
-    for (int kt = 0; kt < ATT_MAX_KT; ++kt) {
-        if (kt < nkt && (sLive[kt] | force)) {
+        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                float pv[8];
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sK + (kt * 32 + r) * KSTR + ks * 32 + hf * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
+        }
+        float tm = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pv[j] = acc[kt][8 * s2 + j];
-                const bf16x8 pf = pack8(pv);
+        for (int t = 0; t < 16; ++t) {
+            acc[t] = __builtin_fmaf(acc[t], scale2, sMask[kt * 32 + rowmap(t, hf)]);
+            tm = fmaxf(tm, acc[t]);
+        }
+        tm = fmaxf(tm, __shfl_xor(tm, 32));
+        const bool raise = tm > m + 12.0f;
+        if (__any(raise)) {
+            if (raise) {
+                const float al = __builtin_amdgcn_exp2f(m - tm);      // 0 at the first live tile (m = -inf)
+                m = tm;
+                l *= al;
 #pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    // V^T[dh = dt*32 + r][keys kt*32 + 16 s2 + 4 hf + {0..3, 8..11}] from row-major V
-                    const char *vb = sV + (kt * 32 + 16 * s2 + 4 * hf + (li >> 2)) * KSTR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
-                    const bf16x8 vf = frag_tr(vb, 8 * KSTR);
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) oacc[dt][t] *= al;
+            }
+        }
+        const float mref = (m == -INFINITY) ? 0.f : m;                 // a tile of -inf scores only: p = 0
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            acc[t] = __builtin_amdgcn_exp2f(acc[t] - mref);
+            l += acc[t];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = acc[8 * s2 + j];
+            const bf16x8 pf = pack8(pv);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                // V^T[dh = dt*32 + r][keys kt*32 + 16 s2 + 4 hf + {0..3, 8..11}] from row-major V
+                const char *vb = sV + (kt * 32 + 16 * s2 + 4 * hf + (li >> 2)) * KSTR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
+                const bf16x8 vf = frag_tr(vb, 8 * KSTR);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
             }
         }
     }
+    l += __shfl_xor(l, 32);
     if (qvalid) {
         const float inv = 1.0f / l;
         bf16_t *orow = o + (tok0 + qrow) * ld_o + hh * DH;
