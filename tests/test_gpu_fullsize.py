@@ -118,3 +118,38 @@ def test_two_feature_model_matches_oracle_fp32(gpu):
     want = nr.softmax_head(head_in, hP, 1)
     assert probs.shape == want.shape
     assert float(np.abs(probs.detach().cpu().numpy() - want).max()) < 1e-6
+
+
+def test_c2_logits_free_head_agrees_with_the_materialised_head(gpu):
+    """Two independent implementations of R12-R14 at the full C2 size (R ~ 40,900 rows x V = 50,000): the logits-free
+    sweeps (csrc/vocab_ce.hip) against projection GEMM + fused softmax / CE on materialised bf16 logits.  Same loss to
+    bf16-logit precision; dh, dW, db agree to the bf16 rounding of P / dlogits (1 % L2)."""
+    from bert4clickpath_amd import ops, _lib as L
+    g = torch.Generator(device='cuda').manual_seed(3)
+    R, V, K = 40900, 50000, 128
+    h = (torch.randn(R, K, device='cuda', generator=g) * 0.7).bfloat16()
+    wt = (torch.randn(V, K, device='cuda', generator=g) * 0.12).bfloat16()
+    bias = torch.randn(V, device='cuda', generator=g) * 0.3
+    y = torch.randint(0, V, (R,), device='cuda', generator=g, dtype=torch.int32)
+    y[::97] = -1                                        # ignored rows
+    n = int((y >= 0).sum())
+    gs = torch.tensor([1.0 / n], device='cuda')
+    item, dh, rowscal = ops.vocab_ce_fwd(h, wt, bias, y, gs, V, L.CE_TF)
+    dW = torch.zeros(K, V, device='cuda')
+    db = torch.zeros(V, device='cuda')
+    ops.vocab_ce_dw(h, wt, bias, y, rowscal, V, dW, db)
+    clipped = int((rowscal[:, 2] < 0).sum())
+    assert 0 < clipped < R                               # both the fast and the clipped paths ran
+    # materialised path
+    logits = ops.gemm_nt(h, wt, V, bias)
+    item_m = ops.softmax_ce_fwd_bwd_(logits, y, gs, V, L.CE_TF)     # logits <- dlogits (bf16)
+    dh_m = ops.gemm_nt(logits, wt.t().contiguous(), K)
+    dW_m, db_m = ops.gemm_tn(h, logits, K, V)
+
+    def rel(a, b):
+        return float((a.float() - b.float()).norm() / b.float().norm())
+    assert abs(float(item.sum() - item_m.sum())) / n < 5e-3      # bf16 logits carry 8 bits: ~3e-2 abs per row, averaging out
+    assert rel(item, item_m) < 5e-3
+    assert rel(dh, dh_m) < 2e-2 and rel(dW, dW_m) < 2e-2 and rel(db, db_m) < 2e-2
+    ign = (y < 0)
+    assert float(item[ign].abs().max()) == 0.0 and float(dh[ign].float().abs().max()) == 0.0
