@@ -1004,14 +1004,17 @@ class MLPFn(torch.autograd.Function):
             _, wc, _ = pk.get(a.dtype, a.shape[1], True)
             last = i == len(packs) - 1
             kern, bias = ctx.params[2 * i], ctx.params[2 * i + 1]
-            with _timed('vocab_proj_dw' if last else 'head_mlp_dw'):
-                dW, db = gemm_tn(a, g, pk.K, pk.N, into=([kern.grad], [bias.grad]) if inplace else None)
-            if inplace:
-                _ready(kern, bias)
+            if inplace:          # queued: the layers' weight gradients go out as one grouped launch below
+                queue_dw(a, g, pk.K, pk.N, [kern.grad], [bias.grad], (kern, bias))
+                dW = db = None
+            else:
+                dW, db = gemm_tn(a, g, pk.K, pk.N)
             grads[2 * i], grads[2 * i + 1] = dW, db
             with _timed('vocab_proj_dx' if last else 'head_mlp_dx'):
                 g = gemm_nt(g, wc, a.shape[1], gate=a if i > 0 else None)
             dx = g
+        if inplace:
+            flush_pending_dw()
         return (dx, None, None, None) + tuple(grads)
 
 
