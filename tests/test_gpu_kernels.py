@@ -36,7 +36,8 @@ TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 104, 128), (37, 384, 104), (300, 50, 1024), (513, 264, 8)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 104, 128), (37, 384, 104), (300, 50, 1024), (513, 264, 8),
+                                   (2100, 640, 128), (1025, 1024, 64)])      # 17 x 5 and 9 x 8 tiles: the XCD-aware tile map, ragged M
 def test_gemm_nt_exact_integers(ops, dtype, M, N, K):
     # small integers are exact in bf16 and their dot products exact in fp32: bit-exact check of the
     # MFMA fragment / accumulator layouts, tile edges and K tails.
