@@ -22,6 +22,16 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 #define ATT_MAX_KT 8   // key tiles of 32 -> S <= 256
 
+// -DB4C_ATTN_PHASES: per-workgroup timestamps (100 MHz) of the resident backward: start, images in LDS, tile loop done,
+// stores issued -> g_attn_phases[blockIdx][4] once b4c_attn_phases_set() was given a buffer (scratch/attn_phases.py).
+#ifdef B4C_ATTN_PHASES
+__device__ unsigned long long *g_attn_phases = nullptr;
+extern "C" void b4c_attn_phases_set(void *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_phases), &p, sizeof(p)); }
+#define ATT_STAMP(i) do { if (tid == 0) att_t[i] = wall_clock64(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
+
 template <typename K> static void allow_lds_attn(K kernel, size_t bytes) {
     static thread_local const void *done[8];
     static thread_local size_t done_bytes[8];
@@ -436,6 +446,8 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
     char *sDS = sGa + S_pad * KSTR;                       // [32][TSTR] bf16
     float *sLseA = reinterpret_cast<float *>(sDS + 32 * TSTR);
     float *sDeltaA = sLseA + S_pad;
+    int *sNZ = reinterpret_cast<int *>(sDeltaA + S_pad);  // [ATT_MAX_KT][SPT]: does this slice of the query tile hold a nonzero dO?
+    constexpr int RPW = 64 / CH, SPT = 32 / RPW;          // rows one wave stages per pass, such slices per query tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int li = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
@@ -447,6 +459,10 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
     const bf16_t *obase = o + tok0 * ld_o + hh * DH;
     const float *lbase = lse + ((int64_t)b * H + hh) * S;
 
+#ifdef B4C_ATTN_PHASES
+    unsigned long long att_t[4] = {0, 0, 0, 0};
+#endif
+    ATT_STAMP(0);
     {   // all global loads of the workgroup are issued before the first LDS write (one latency, not one per pass)
         constexpr int NIT = (256 * CH + 511) / 512;
         u32x4 rk[NIT], rv[NIT], rq[NIT], rg[NIT], ro[NIT];
@@ -478,6 +494,9 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
                 for (int k = 0; k < 8; ++k) pd += (float)g8[k] * (float)o8[k];
                 pd = group_sum<CH>(pd);     // CH consecutive lanes share a row
                 if (part == 0) sDeltaA[row] = pd;
+                // rows past S were loaded as zeros; +0 only (a -0 row takes the dense path, so the result bits match)
+                const int nz = __any((rg[it][0] | rg[it][1] | rg[it][2] | rg[it][3]) != 0u);
+                if (lane == 0) sNZ[(row >> 5) * SPT + (wave % SPT)] = nz;
             }
         }
     }
@@ -500,8 +519,25 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
             *reinterpret_cast<bf16_t *>(sDS + rowmap(t, hf) * TSTR + (kt * 32 + r) * 2) = (bf16_t)0.f;
     }
     __syncthreads();
+    ATT_STAMP(1);
+    // query tiles that hold a nonzero dO, as a wave-uniform bit mask (lane i < nkt * SPT reads one slice flag)
+    const unsigned long long nzb = __ballot(lane < nkt * SPT && sNZ[lane < nkt * SPT ? lane : 0] != 0);
+    unsigned q_live_mask = 0;
+#pragma unroll
+    for (int t = 0; t < ATT_MAX_KT; ++t)
+        if ((nzb >> (t * SPT)) & ((1ull << SPT) - 1)) q_live_mask |= 1u << t;
 
+    // A query tile whose dO is all +0 (padded positions under a [MASK]-only loss) has P o (dP - delta) = 0: nothing
+    // reaches dK / dV and its dQ rows are +0 -- the bits the dense path would write.  Those rows are zeroed here and
+    // the tile loop visits the other tiles only (the mask is uniform over the workgroup).
     for (int qt = 0; qt < nkt; ++qt) {
+        if (!((q_live_mask >> qt) & 1u) && tid < 32 * CH) {
+            const int q = qt * 32 + tid / CH;
+            if (q < S) *reinterpret_cast<u32x4 *>(dqkv + (tok0 + q) * ld_dq + hh * DH + (tid % CH) * 8) = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
+    for (unsigned todo = q_live_mask & ((1u << nkt) - 1u); todo; todo &= todo - 1u) {
+        const int qt = __builtin_ctz(todo);
         const int q0 = qt * 32;
         const char *sQ = sQa + q0 * KSTR, *sdO = sGa + q0 * KSTR;
         const float *sLse = sLseA + q0, *sDelta = sDeltaA + q0;
@@ -559,9 +595,12 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
         }
         B4C_LDS_BARRIER();                                // dS consumed
     }
-    if (kt < nkt && key < S) {
-        bf16_t *krow = dqkv + (tok0 + key) * ld_dq + dm + hh * DH;
-        bf16_t *vrow = krow + dm;
+    ATT_STAMP(2);
+    // dK / dV: each wave turns its accumulators (dh on the registers, key on the lane) into row-major bf16 through its
+    // own slice of LDS (every image is dead after the last barrier), then writes whole 16-B chunks: full rows per
+    // store instruction instead of 8 B per lane scattered over 64 rows.
+    if (kt < nkt) {
+        char *stK = smem + wave * (2 * 32 * KSTR), *stV = stK + 32 * KSTR;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -572,10 +611,27 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
                     wk[j] = (bf16_t)(dk[dt][4 * tq + j] * scale);
                     wv[j] = (bf16_t)dv[dt][4 * tq + j];
                 }
-                *reinterpret_cast<bf16x4 *>(krow + dt * 32 + 8 * tq + 4 * hf) = wk;
-                *reinterpret_cast<bf16x4 *>(vrow + dt * 32 + 8 * tq + 4 * hf) = wv;
+                *reinterpret_cast<bf16x4 *>(stK + r * KSTR + (dt * 32 + 8 * tq + 4 * hf) * 2) = wk;
+                *reinterpret_cast<bf16x4 *>(stV + r * KSTR + (dt * 32 + 8 * tq + 4 * hf) * 2) = wv;
             }
+#pragma unroll
+        for (int i = 0; i < 32 * CH / 64; ++i) {
+            const int c = lane + 64 * i, row = c / CH, part = c % CH;
+            const u32x4 k4 = *reinterpret_cast<const u32x4 *>(stK + row * KSTR + part * 16);
+            const u32x4 v4 = *reinterpret_cast<const u32x4 *>(stV + row * KSTR + part * 16);
+            if (kt * 32 + row < S) {
+                bf16_t *krow = dqkv + (tok0 + kt * 32 + row) * ld_dq + dm + hh * DH + part * 8;
+                *reinterpret_cast<u32x4 *>(krow) = k4;
+                *reinterpret_cast<u32x4 *>(krow + dm) = v4;
+            }
+        }
     }
+#ifdef B4C_ATTN_PHASES
+    if (tid == 0 && g_attn_phases) {
+        att_t[3] = wall_clock64();
+        for (int i = 0; i < 4; ++i) g_attn_phases[(size_t)blockIdx.x * 4 + i] = att_t[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -605,7 +661,7 @@ int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const
     const int S_pad = (S + 31) / 32 * 32;
     const size_t kstr = dh * 2 + 16, tstr = S_pad * 2 + 16;
     const size_t shm = 2 * S_pad * kstr + 2 * (2 * 32 * kstr + 256) + 32 * tstr;
-    const size_t shm_res = 4 * S_pad * kstr + 32 * tstr + 2 * (size_t)S_pad * 4;
+    const size_t shm_res = 4 * S_pad * kstr + 32 * tstr + 2 * (size_t)S_pad * 4 + ATT_MAX_KT * 4 * 4;
     const float scale = 1.0f / sqrtf((float)dh);
     if (shm_res <= 160 * 1024) {
         if (dh == 64) {

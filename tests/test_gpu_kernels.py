@@ -251,6 +251,43 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, dh):
     assert float(kv_grad[0, S - 4:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('B,S,H,dh', [(3, 200, 2, 64), (2, 224, 1, 64), (3, 130, 2, 32)])
+def test_attention_bwd_zero_do_tiles(ops, B, S, H, dh):
+    """Query tiles whose dO rows are all +0 (padded positions under a [MASK]-only loss) are skipped by the bf16 kernel:
+    the result must equal the fp64 reference, give exact zeros on those dQ rows, and a -0 tile (dense path) must give
+    the same dK / dV."""
+    g = torch.Generator().manual_seed(7 * S + dh)
+    d = H * dh
+    qkv = torch.randn(B * S, 3 * d, generator=g) * 0.8
+    pad = torch.zeros(B, S, dtype=torch.uint8)
+    pad[0, 70:S - 1] = 1                       # live: 0..69 and the trailing [SEP]
+    pad[1, 33:] = 1
+    do = torch.randn(B, S, d, generator=g)
+    do[0, 64:S - 1] = 0.0                      # whole tiles 2.. of sequence 0 (the last tile keeps one live row)
+    do[1, 32:] = 0.0                           # every tile but the first
+    if B > 2:
+        do[2] = 0.0                            # a sequence without any gradient
+    do = do.reshape(B * S, d)
+    qd, dod = dev(qkv, torch.bfloat16), dev(do, torch.bfloat16)
+    o, lse = ops.attn_fwd(qd, pad.cuda(), B, S, H, dh)
+    q64 = qd.double().cpu().requires_grad_(True)
+    o_ref, _ = _attn_ref(q64, pad, B, S, H, dh)
+    o_ref.backward(dod.double().cpu())
+    dqkv = ops.attn_bwd(qd, pad.cuda(), o, dod, lse, B, S, H, dh)
+    assert rel_err(dqkv, q64.grad) < 2.5e-2
+    dq = dqkv[:, :d].reshape(B, S, d)
+    assert float(dq[1, 32:].abs().max()) == 0.0 and float(dq[0, 64:S - 1].abs().max()) == 0.0
+    if B > 2:
+        assert float(dqkv.reshape(B, S, 3 * d)[2].abs().max()) == 0.0
+    # the same gradient with the zero rows written as -0: the kernel takes the dense path; dK / dV must not move
+    dneg = dod.clone()
+    zero_rows = (dod == 0).all(dim=1)
+    dneg[zero_rows] = -0.0
+    dqkv2 = ops.attn_bwd(qd, pad.cuda(), o, dneg, lse, B, S, H, dh)
+    assert torch.equal(dqkv2[:, d:], dqkv[:, d:])
+    assert torch.equal(dqkv2[:, :d].float().abs(), dqkv[:, :d].float().abs())   # dQ: +0 vs -0 at most
+
+
 # ---------------------------------------------------------------------------------------------
 def test_mask_positions_and_gather(ops):
     rng = np.random.default_rng(3)
