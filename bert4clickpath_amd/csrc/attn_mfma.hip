@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__r
         if (live) sLive[k >> 5] = 1;     // benign race: every writer stores 1
     }
     __syncthreads();
-    if (wave >= nkt) return;            // wave-uniform; no barrier below
+    const bool active = wave < nkt;     // wave-uniform
     // Fully padded key tiles contribute exp(-1e9 - m) == 0 and are skipped -- unless the sequence has no
     // unmasked key at all (never the case for chained inputs: [CLS]/[SEP] are real tokens), where the
     // reference's softmax degenerates to uniform weights: then every tile is processed.
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__r
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int t = 0; t < 16; ++t) oacc[dt][t] = 0.f;
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = 0; kt < (active ? nkt : 0); ++kt) {
         if (!(sLive[kt] | force)) continue;       // wave-uniform
         f32x16 acc;
 #pragma unroll
@@ -229,9 +229,13 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__r
         }
     }
     l += __shfl_xor(l, 32);
-    if (qvalid) {
+    // O^T (dh on the registers, query on the lane) -> row-major bf16 through the wave's slice of the K image (dead once
+    // every wave has left the key loop), then whole 16-B chunks: full rows per store instruction instead of 8 B per lane
+    // scattered over 32 rows.
+    B4C_LDS_BARRIER();
+    if (active) {
         const float inv = 1.0f / l;
-        bf16_t *orow = o + (tok0 + qrow) * ld_o + hh * DH;
+        char *st = smem + wave * (32 * KSTR);
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -239,9 +243,15 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__r
                 bf16x4 w;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(oacc[dt][4 * tq + j] * inv);
-                *reinterpret_cast<bf16x4 *>(orow + dt * 32 + 8 * tq + 4 * hf) = w;
+                *reinterpret_cast<bf16x4 *>(st + r * KSTR + (dt * 32 + 8 * tq + 4 * hf) * 2) = w;
             }
-        if (hf == 0 && lse) lse[((int64_t)b * H + hh) * S + qrow] = (m + __log2f(l)) * 0.6931471805599453f;
+#pragma unroll
+        for (int i = 0; i < 32 * CH / 64; ++i) {
+            const int c = lane + 64 * i, row = c / CH, part = c % CH;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(st + row * KSTR + part * 16);
+            if (wave * 32 + row < S) *reinterpret_cast<u32x4 *>(o + (tok0 + wave * 32 + row) * ld_o + hh * DH + part * 8) = v;
+        }
+        if (qvalid && hf == 0 && lse) lse[((int64_t)b * H + hh) * S + qrow] = (m + __log2f(l)) * 0.6931471805599453f;
     }
 }
 
