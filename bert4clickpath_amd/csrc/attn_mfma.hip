@@ -443,7 +443,7 @@ template <int DH>
 __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
                                                                 const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o,
                                                                 int ld_do, const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
-                                                                int ld_dq, int S, int H, float scale) {
+                                                                int ld_dq, int S, int H, float scale, int n_items, int *__restrict__ work_counter) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSTR = DH * 2 + 16;
     constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8;
@@ -457,10 +457,22 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
     float *sLseA = reinterpret_cast<float *>(sDS + 32 * TSTR);
     float *sDeltaA = sLseA + S_pad;
     int *sNZ = reinterpret_cast<int *>(sDeltaA + S_pad);  // [ATT_MAX_KT][SPT]: does this slice of the query tile hold a nonzero dO?
+    int *sNext = sNZ + ATT_MAX_KT * 4;                    // the item this workgroup takes next
     constexpr int RPW = 64 / CH, SPT = 32 / RPW;          // rows one wave stages per pass, such slices per query tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int dm = H * DH;
+    // One workgroup per CU walks the (sequence, head) items: no dispatch gap between items, and the stores of one item
+    // drain under the loads of the next.  After its first item a workgroup takes items from a global counter (ragged
+    // sequences and skipped query tiles make item times differ by several x; a static split leaves CUs idle at the end).
+    // (Prefetching the next item's loads into registers across the loop was measured slower: 256 VGPRs, and the only
+    // window is the 1 us epilogue.)
+    for (int item = blockIdx.x; item < n_items;) {
+    // the lane coordinates are re-derived per item behind an opaque zero: hoisted out of this loop, the per-lane LDS
+    // addresses of every access pattern stay live across it and push the kernel into spills
+    int opaque0;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(opaque0));
+    const int tid = threadIdx.x + opaque0, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int li = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
+    const int b = item / H, hh = item % H;
     const int64_t tok0 = (int64_t)b * S;
     const bf16_t *qbase = qkv + tok0 * ld + hh * DH;
     const bf16_t *kbase = qbase + dm;
@@ -528,8 +540,10 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
         for (int t = 0; t < 16; ++t)
             *reinterpret_cast<bf16_t *>(sDS + rowmap(t, hf) * TSTR + (kt * 32 + r) * 2) = (bf16_t)0.f;
     }
-    __syncthreads();
+    B4C_LDS_BARRIER();            // LDS only: the previous item's stores keep draining
     ATT_STAMP(1);
+    int next_item = 0;            // asked for now, needed at the end of the item
+    if (tid == 0) next_item = (int)gridDim.x + atomicAdd(work_counter, 1);
     // query tiles that hold a nonzero dO, as a wave-uniform bit mask (lane i < nkt * SPT reads one slice flag)
     const unsigned long long nzb = __ballot(lane < nkt * SPT && sNZ[lane < nkt * SPT ? lane : 0] != 0);
     unsigned q_live_mask = 0;
@@ -546,6 +560,14 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
             if (q < S) *reinterpret_cast<u32x4 *>(dqkv + (tok0 + q) * ld_dq + hh * DH + (tid % CH) * 8) = (u32x4){0u, 0u, 0u, 0u};
         }
     }
+    // this wave's K / V fragments do not change over the query tiles
+    bf16x8 fkr[NKS], fvr[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int krow = (kt < nkt ? kt : 0) * 32 + r;
+        fkr[ks] = *reinterpret_cast<const bf16x8 *>(sK + krow * KSTR + ks * 32 + hf * 16);
+        fvr[ks] = *reinterpret_cast<const bf16x8 *>(sV + krow * KSTR + ks * 32 + hf * 16);
+    }
     for (unsigned todo = q_live_mask & ((1u << nkt) - 1u); todo; todo &= todo - 1u) {
         const int qt = __builtin_ctz(todo);
         const int q0 = qt * 32;
@@ -558,11 +580,9 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const bf16x8 fq = *reinterpret_cast<const bf16x8 *>(sQ + r * KSTR + ks * 32 + hf * 16);
-                const bf16x8 fk = *reinterpret_cast<const bf16x8 *>(sK + (kt * 32 + r) * KSTR + ks * 32 + hf * 16);
-                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq, fk, sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq, fkr[ks], sa, 0, 0, 0);
                 const bf16x8 fg = *reinterpret_cast<const bf16x8 *>(sdO + r * KSTR + ks * 32 + hf * 16);
-                const bf16x8 fv = *reinterpret_cast<const bf16x8 *>(sV + (kt * 32 + r) * KSTR + ks * 32 + hf * 16);
-                pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg, fv, pa, 0, 0, 0);
+                pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg, fvr[ks], pa, 0, 0, 0);
             }
             float pv[16], dsv[16];
 #pragma unroll
@@ -639,12 +659,26 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
 #ifdef B4C_ATTN_PHASES
     if (tid == 0 && g_attn_phases) {
         att_t[3] = wall_clock64();
-        for (int i = 0; i < 4; ++i) g_attn_phases[(size_t)blockIdx.x * 4 + i] = att_t[i];
+        for (int i = 0; i < 4; ++i) g_attn_phases[(size_t)item * 4 + i] = att_t[i];
     }
 #endif
+    if (tid == 0) *sNext = next_item;
+    B4C_LDS_BARRIER();            // the staging slices are read back before the next item's images land
+    item = __builtin_amdgcn_readfirstlane(*sNext);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
+static int att_num_cus() {
+    static thread_local int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
 static bool mfma_shape_ok(int S, int dh) { return (dh == 32 || dh == 64) && S <= 32 * ATT_MAX_KT; }
 
 int b4c_attn_fwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, void *o, int ld_o, float *lse, int B, int S,
@@ -667,19 +701,21 @@ int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const
                       int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B, int S, int H, int dh,
                       hipStream_t st) {
     if (!mfma_shape_ok(S, dh)) return B4C_EUNSUPPORTED;
-    (void)delta;   // delta is computed while staging dO / O tiles
     const int S_pad = (S + 31) / 32 * 32;
     const size_t kstr = dh * 2 + 16, tstr = S_pad * 2 + 16;
     const size_t shm = 2 * S_pad * kstr + 2 * (2 * 32 * kstr + 256) + 32 * tstr;
-    const size_t shm_res = 4 * S_pad * kstr + 32 * tstr + 2 * (size_t)S_pad * 4 + ATT_MAX_KT * 4 * 4;
+    const size_t shm_res = 4 * S_pad * kstr + 32 * tstr + 2 * (size_t)S_pad * 4 + ATT_MAX_KT * 4 * 4 + 16;
     const float scale = 1.0f / sqrtf((float)dh);
     if (shm_res <= 160 * 1024) {
+        const int grid_res = B * H < att_num_cus() ? B * H : att_num_cus();   // > 80 KB of LDS: one workgroup per CU
+        // delta itself is computed while staging dO / O; its first word is the work counter of the persistent grid
+        if (hipMemsetAsync(delta, 0, sizeof(int), st) != hipSuccess) return B4C_ELAUNCH;
         if (dh == 64) {
             allow_lds_attn(attn_bwd_resident_kernel<64>, shm_res);
-            attn_bwd_resident_kernel<64><<<B * H, 512, shm_res, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale);
+            attn_bwd_resident_kernel<64><<<grid_res, 512, shm_res, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, B * H, (int *)delta);
         } else {
             allow_lds_attn(attn_bwd_resident_kernel<32>, shm_res);
-            attn_bwd_resident_kernel<32><<<B * H, 512, shm_res, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale);
+            attn_bwd_resident_kernel<32><<<grid_res, 512, shm_res, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, B * H, (int *)delta);
         }
         return b4c_check_launch("attn_bwd_resident");
     }
