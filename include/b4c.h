@@ -171,7 +171,8 @@ int b4c_gemm_tn_group(const b4c_tn_desc *h_desc, int n_prob, int M, int dtype, v
  *   lse[B][H][S] = log-sum-exp of the masked, scaled logits (saved for backward) */
 int b4c_attn_fwd(const void *qkv, int ld_qkv, const uint8_t *key_pad, void *o, int ld_o, float *lse, int B,
                  int S, int H, int dh, int dtype, void *stream);
-/* dqkv [B*S][ld_dqkv] from do; delta[B][H][S] is scratch (fp32). */
+/* dqkv [B*S][ld_dqkv] from do; delta[B][H][S] is scratch (fp32): the row kernels keep rowsum(dO o O) there, the
+ * bf16 MFMA kernel computes it in LDS and uses the first word as the work counter of its persistent grid. */
 int b4c_attn_bwd(const void *qkv, int ld_qkv, const uint8_t *key_pad, const void *o, int ld_o,
                  const void *d_o, int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B,
                  int S, int H, int dh, int dtype, void *stream);
