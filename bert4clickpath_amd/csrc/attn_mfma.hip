@@ -42,6 +42,10 @@ template <typename K> static void allow_lds_attn(K kernel, size_t bytes) {
     if (ndone < 8) { done[ndone] = (const void *)kernel; done_bytes[ndone++] = bytes; }
 }
 
+template <bool NT> __device__ __forceinline__ void att_store16(bf16_t *p, const u32x4 &v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+    else *reinterpret_cast<u32x4 *>(p) = v;
+}
 __device__ __forceinline__ bf16x8 pack8(const float *p) {
     bf16x8 v;
 #pragma unroll
@@ -249,7 +253,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__r
         for (int i = 0; i < 32 * CH / 64; ++i) {
             const int c = lane + 64 * i, row = c / CH, part = c % CH;
             const u32x4 v = *reinterpret_cast<const u32x4 *>(st + row * KSTR + part * 16);
-            if (wave * 32 + row < S) *reinterpret_cast<u32x4 *>(o + (tok0 + wave * 32 + row) * ld_o + hh * DH + part * 8) = v;
+            if (wave * 32 + row < S) att_store16<B4C_NT(B4C_NT_ATTN_O)>(o + (tok0 + wave * 32 + row) * ld_o + hh * DH + part * 8, v);
         }
         if (qvalid && hf == 0 && lse) lse[((int64_t)b * H + hh) * S + qrow] = (m + __log2f(l)) * 0.6931471805599453f;
     }
@@ -651,8 +655,8 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
             const u32x4 v4 = *reinterpret_cast<const u32x4 *>(stV + row * KSTR + part * 16);
             if (kt * 32 + row < S) {
                 bf16_t *krow = dqkv + (tok0 + kt * 32 + row) * ld_dq + dm + hh * DH + part * 8;
-                *reinterpret_cast<u32x4 *>(krow) = k4;
-                *reinterpret_cast<u32x4 *>(krow + dm) = v4;
+                att_store16<B4C_NT(B4C_NT_ATTN_DQKV)>(krow, k4);
+                att_store16<B4C_NT(B4C_NT_ATTN_DQKV)>(krow + dm, v4);
             }
         }
     }

@@ -33,6 +33,19 @@ int b4c_check_launch(const char *what);
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- element IO: 8 consecutive elements <-> 8 floats (16 B for bf16, 32 B for fp32) ----
+// Which streaming outputs use nontemporal stores (bit per site): measured per site on the C2 step.
+#ifndef B4C_NT_MASK
+#define B4C_NT_MASK 255
+#endif
+#define B4C_NT(site) (((B4C_NT_MASK) >> (site)) & 1)
+#define B4C_NT_EMBED 0
+#define B4C_NT_GEMM 1
+#define B4C_NT_GEMMLN_Z 2
+#define B4C_NT_GEMMLN_OUT 3
+#define B4C_NT_LNBWD_DZ 4
+#define B4C_NT_LNBWD_DY 5
+#define B4C_NT_ATTN_O 6
+#define B4C_NT_ATTN_DQKV 7
 template <typename T> struct Vec8;
 template <> struct Vec8<float> {
     static __device__ __forceinline__ void load(const float *p, float (&v)[8]) {
@@ -46,6 +59,15 @@ template <> struct Vec8<float> {
         *reinterpret_cast<f32x4 *>(p) = a;
         *reinterpret_cast<f32x4 *>(p + 4) = b;
     }
+    // streaming store (nt bit): for outputs that are far larger than L2 and are next read by another kernel
+    static __device__ __forceinline__ void store_nt(float *p, const float (&v)[8]) {
+        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        __builtin_nontemporal_store(a, reinterpret_cast<f32x4 *>(p));
+        __builtin_nontemporal_store(b, reinterpret_cast<f32x4 *>(p + 4));
+    }
+    template <bool NT> static __device__ __forceinline__ void store_sel(float *p, const float (&v)[8]) {
+        if (NT) store_nt(p, v); else store(p, v);
+    }
 };
 template <> struct Vec8<bf16_t> {
     static __device__ __forceinline__ void load(const bf16_t *p, float (&v)[8]) {
@@ -58,6 +80,15 @@ template <> struct Vec8<bf16_t> {
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
         *reinterpret_cast<bf16x8 *>(p) = a;
+    }
+    static __device__ __forceinline__ void store_nt(bf16_t *p, const float (&v)[8]) {
+        bf16x8 a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+        __builtin_nontemporal_store(a, reinterpret_cast<bf16x8 *>(p));
+    }
+    template <bool NT> static __device__ __forceinline__ void store_sel(bf16_t *p, const float (&v)[8]) {
+        if (NT) store_nt(p, v); else store(p, v);
     }
 };
 

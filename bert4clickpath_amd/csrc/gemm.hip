@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256, 3) gemm_nt_kernel(const T *__restrict__ A
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
                 }
-                Vec8<OutT>::store(C + grow * ldc + gcol, v);
+                Vec8<OutT>::template store_sel<B4C_NT(B4C_NT_GEMM)>(C + grow * ldc + gcol, v);
             }
         }
         return;
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256, 3) gemm_nt_ln_kernel(const bf16_t *__rest
                 v[k] = (float)xv[k] + yy;
                 sum += v[k];
             }
-            if (z) Vec8<bf16_t>::store(z + grow * N + col, v);
+            if (z) Vec8<bf16_t>::store_sel<B4C_NT(B4C_NT_GEMMLN_Z)>(z + grow * N + col, v);
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = 0.f;
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256, 3) gemm_nt_ln_kernel(const bf16_t *__rest
             float o[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (v[k] - mean) * rstd * gv[k] + be[k];
-            Vec8<bf16_t>::store(out + grow * N + col, o);
+            Vec8<bf16_t>::store_sel<B4C_NT(B4C_NT_GEMMLN_OUT)>(out + grow * N + col, o);
             if (part == 0 && stats) {
                 stats[grow * 2] = mean;
                 stats[grow * 2 + 1] = rstd;

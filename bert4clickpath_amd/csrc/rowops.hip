@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(EmbedArgs a, const float
             if (rate > 0.f) x = ((km >> k) & 1u) ? x * inv_keep : 0.f;
             v[k] = x;
         }
-        Vec8<T>::store(out + t * ld_out + c, v);
+        Vec8<T>::template store_sel<B4C_NT(B4C_NT_EMBED)>(out + t * ld_out + c, v);
     }
 }
 
@@ -452,12 +452,12 @@ __global__ void __launch_bounds__(256, 4) add_ln_bwd_kernel(const T *__restrict_
                     float o[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) o[k] = rstd * (gv[p][k] - s1 - xh[p][k] * s2);
-                    Vec8<T>::store(dz + row * d + c, o);
+                    Vec8<T>::template store_sel<B4C_NT(B4C_NT_LNBWD_DZ)>(dz + row * d + c, o);
                     if (rate > 0.f && dy) {
                         const uint32_t km = b4c_keep8(seed, (uint64_t)(row * d + c), b4c_keep_threshold(rate));
 #pragma unroll
                         for (int k = 0; k < 8; ++k) o[k] = ((km >> k) & 1u) ? o[k] * inv_keep : 0.f;
-                        Vec8<T>::store(dy + row * d + c, o);
+                        Vec8<T>::template store_sel<B4C_NT(B4C_NT_LNBWD_DY)>(dy + row * d + c, o);
                     }
                 }
             }
