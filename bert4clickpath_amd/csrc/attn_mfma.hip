@@ -462,6 +462,7 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
     float *sDeltaA = sLseA + S_pad;
     int *sNZ = reinterpret_cast<int *>(sDeltaA + S_pad);  // [ATT_MAX_KT][SPT]: does this slice of the query tile hold a nonzero dO?
     int *sNext = sNZ + ATT_MAX_KT * 4;                    // the item this workgroup takes next
+    char *sDQ = reinterpret_cast<char *>(sNext + 4);      // [32][KSTR] bf16: the dQ tile on its way out as row chunks
     constexpr int RPW = 64 / CH, SPT = 32 / RPW;          // rows one wave stages per pass, such slices per query tile
     const int dm = H * DH;
     // One workgroup per CU walks the (sequence, head) items: no dispatch gap between items, and the stores of one item
@@ -622,12 +623,15 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
                 qa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fs, fk, qa, 0, 0, 0);
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int q = q0 + qi * 16 + 4 * g + t;
-                if (q < S) dqkv[(tok0 + q) * ld_dq + hh * DH + di * 16 + li] = (bf16_t)(qa[t] * scale);
-            }
+            for (int t = 0; t < 4; ++t)
+                *reinterpret_cast<bf16_t *>(sDQ + (qi * 16 + 4 * g + t) * KSTR + (di * 16 + li) * 2) = (bf16_t)(qa[t] * scale);
         }
-        B4C_LDS_BARRIER();                                // dS consumed
+        B4C_LDS_BARRIER();                                // dS consumed, dQ tile staged
+        if (tid < 32 * CH) {                              // one 16-B chunk per lane: whole rows per store instruction
+            const int row = tid / CH, part = tid % CH;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(sDQ + row * KSTR + part * 16);
+            if (q0 + row < S) att_store16<B4C_NT(B4C_NT_ATTN_DQKV)>(dqkv + (tok0 + q0 + row) * ld_dq + hh * DH + part * 8, v);
+        }
     }
     ATT_STAMP(2);
     // dK / dV: each wave turns its accumulators (dh on the registers, key on the lane) into row-major bf16 through its
@@ -708,7 +712,7 @@ int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const
     const int S_pad = (S + 31) / 32 * 32;
     const size_t kstr = dh * 2 + 16, tstr = S_pad * 2 + 16;
     const size_t shm = 2 * S_pad * kstr + 2 * (2 * 32 * kstr + 256) + 32 * tstr;
-    const size_t shm_res = 4 * S_pad * kstr + 32 * tstr + 2 * (size_t)S_pad * 4 + ATT_MAX_KT * 4 * 4 + 16;
+    const size_t shm_res = 4 * S_pad * kstr + 32 * tstr + 2 * (size_t)S_pad * 4 + ATT_MAX_KT * 4 * 4 + 16 + 32 * kstr;
     const float scale = 1.0f / sqrtf((float)dh);
     if (shm_res <= 160 * 1024) {
         const int grid_res = B * H < att_num_cus() ? B * H : att_num_cus();   // > 80 KB of LDS: one workgroup per CU
