@@ -127,7 +127,7 @@ struct VceArgs {
     float *u;             // [parts][R][KD]: sum 2^(x log2e - m2) W   (un-normalised P W)
     float *ud;            // [parts][R][KD]: sum over clipped p of p W (normalised)
     float *sp;            // [parts][R][2]: S, Pu
-    float *rowscal;       // [R][8]: lse2, c = a - b, a (negated on clipped rows), b, yd, -, -, -
+    float *rowscal;       // [R][8]: lse2, c = a - b, nb = -b, lo (clip range, -inf / +inf on rows that stay inside), yd, hi, -, -
     float *item_loss;     // [R]
     bf16_t *dh;           // [R][ld_dh]
     int ld_h, ld_w, ld_dh;
@@ -279,18 +279,33 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
         for (int rt = 0; rt < 2; ++rt) {
             __builtin_amdgcn_sched_barrier(0);       // keep one 32-row tile's temporaries live at a time
             float p[16];
+            if (MODE == 2 && tail) {                 // the last tile only (wave-uniform): rows past V must not count
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -e2));
-                if (MODE == 1) l += pv;
-                if (MODE == 2) {
-                    const bool valid = !tail || (vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V);
+                for (int t = 0; t < 16; ++t) {
+                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -e2));
+                    const bool valid = vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V;
                     const float pc = __builtin_amdgcn_fmed3f(pv, VCE_EPS, 1.0f - VCE_EPS);
                     const bool un = pc == pv;              // inside the clip range
                     if (valid) { S += pc; Pu += un ? pv : 0.f; }
-                    pv = (un || !valid) ? 0.f : pv;        // the clipped part feeds Ud
+                    p[t] = (un || !valid) ? 0.f : pv;      // the clipped part feeds Ud
                 }
-                p[t] = pv;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -e2));
+                    if (MODE == 1) {
+                        l += pv;
+                        p[t] = pv;
+                    } else {
+                        // the per-entry validity test of the tail path costs a compare, two selects and a spilled lane
+                        // mask per entry: with it the clipped sweep ran 18 VALU slots per entry, without it 11
+                        const float pc = __builtin_amdgcn_fmed3f(pv, VCE_EPS, 1.0f - VCE_EPS);
+                        const float pu = (pc == pv) ? pv : 0.f;    // inside the clip range
+                        S += pc;
+                        Pu += pu;
+                        p[t] = pv - pu;                            // the clipped part feeds Ud (exact: pv - pv or pv - 0)
+                    }
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -382,8 +397,8 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
         for (int e = 0; e < E; ++e) dh[lane * E + e] = (bf16_t)0.f;
         if (lane == 0) {
             a.item_loss[row] = (y >= a.V) ? NAN : 0.f;
-            *reinterpret_cast<f32x4 *>(rs) = (f32x4){INFINITY, 0.f, 0.f, 0.f};     // lse2 = +inf: p = 0
-            *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(rs) = (f32x4){INFINITY, 0.f, 0.f, -INFINITY};     // lse2 = +inf: p = 0
+            *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){0.f, INFINITY, 0.f, 0.f};
         }
         return;
     }
@@ -435,9 +450,10 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
     }
     if (lane == 0) {
         a.item_loss[row] = loss;
+        // dlogit_j = p_j (u_j a - b): inside the clip range [lo, hi] that is p_j c, outside it p_j nb
         const float ra = gs * invS, rb = gs * G;
-        *reinterpret_cast<f32x4 *>(rs) = (f32x4){lse2, ra - rb, clipped ? -ra : ra, rb};
-        *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){gs * yd, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(rs) = (f32x4){lse2, ra - rb, -rb, clipped ? VCE_EPS : -INFINITY};
+        *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){gs * yd, clipped ? 1.0f - VCE_EPS : INFINITY, 0.f, 0.f};
     }
 }
 
@@ -489,12 +505,12 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
     }
     const int roff = (th * 64 + 4 * hf) * 16;       // the lane's first row-scalar entry (bytes)
 
-    f32x4 rreg = {INFINITY, 0.f, 0.f, 0.f};
+    f32x4 rreg = {INFINITY, 0.f, 0.f, -INFINITY};
     auto fetch = [&](int64_t tt, int buf) {
         VTile<KD>::dma(a.h, a.ld_h, tt * 128, tt < tt1 ? a.R : 0, smem + buf * TILE_B, tid);
         if (tid < 128) {
             const int64_t row = tt * 128 + tid;
-            rreg = (tt < tt1 && row < a.R) ? *reinterpret_cast<const f32x4 *>(a.rowscal + row * 8) : (f32x4){INFINITY, 0.f, 0.f, 0.f};
+            rreg = (tt < tt1 && row < a.R) ? *reinterpret_cast<const f32x4 *>(a.rowscal + row * 8) : (f32x4){INFINITY, 0.f, 0.f, -INFINITY};
         }
     };
     fetch(tt0, 0);
@@ -515,8 +531,9 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
         const f32x4 *rs = sRow + buf * 128;
         const char *rsl = reinterpret_cast<const char *>(rs) + roff;
         fetch(tt + 1, buf ^ 1);        // the other buffer was last read one tile ago (behind the previous barrier)
-        // row scalars {lse2, c = a - b, +-a, b}: a < 0 marks a row whose probabilities leave the clip range
-        const bool any_clip = __any(rs[th * 64 + lane][2] < 0.f);     // the wave's 64 token rows
+        // row scalars {lse2, c = a - b, nb = -b, lo}: lo > 0 marks a row whose probabilities leave the clip range
+        // [lo, 1 - lo] (the upper bound follows from the lower one: rows that stay inside carry lo = -inf)
+        const bool any_clip = __any(rs[th * 64 + lane][3] > 0.f);     // the wave's 64 token rows
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             __builtin_amdgcn_sched_barrier(0);       // keep one 32-token tile's temporaries live at a time
@@ -541,8 +558,8 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
                 for (int t = 0; t < 16; ++t) {
                     const f32x4 s = *reinterpret_cast<const f32x4 *>(rsl + (rt * 32 + (t & 3) + 8 * (t >> 2)) * 16);
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t], VCE_LOG2E, -s[0]));
-                    const bool un = (s[2] >= 0.f) || (p >= VCE_EPS && p <= 1.0f - VCE_EPS);
-                    gv[t] = p * ((un ? fabsf(s[2]) : 0.f) - s[3]);
+                    const bool un = __builtin_amdgcn_fmed3f(p, s[3], 1.0f - s[3]) == p;    // lo = -inf: always inside
+                    gv[t] = p * (un ? s[1] : s[2]);
                     dbv += gv[t];
                 }
             }
