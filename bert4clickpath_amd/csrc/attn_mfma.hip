@@ -547,8 +547,10 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
     }
     B4C_LDS_BARRIER();            // LDS only: the previous item's stores keep draining
     ATT_STAMP(1);
-    int next_item = 0;            // asked for now, needed at the end of the item
-    if (tid == 0) next_item = (int)gridDim.x + atomicAdd(work_counter, 1);
+    // The next item is taken now and needed at the end of this one.  atomicAdd() reads its result back on the spot (the
+    // compiler's atomic optimizer), a global round trip: the last wave does it -- with S <= 224 it owns no key tile and
+    // only waits at the next barrier anyway -- and leaves the answer in LDS.
+    if (tid == 448) *sNext = (int)gridDim.x + atomicAdd(work_counter, 1);
     // query tiles that hold a nonzero dO, as a wave-uniform bit mask (lane i < nkt * SPT reads one slice flag)
     const unsigned long long nzb = __ballot(lane < nkt * SPT && sNZ[lane < nkt * SPT ? lane : 0] != 0);
     unsigned q_live_mask = 0;
@@ -670,7 +672,6 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
         for (int i = 0; i < 4; ++i) g_attn_phases[(size_t)item * 4 + i] = att_t[i];
     }
 #endif
-    if (tid == 0) *sNext = next_item;
     B4C_LDS_BARRIER();            // the staging slices are read back before the next item's images land
     item = __builtin_amdgcn_readfirstlane(*sNext);
     }
