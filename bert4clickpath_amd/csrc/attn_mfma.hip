@@ -490,6 +490,11 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
     unsigned long long att_t[4] = {0, 0, 0, 0};
 #endif
     ATT_STAMP(0);
+    // the two small loads go out first, unconditional on clamped indices (a conditional scalar load is waited for on
+    // the spot; behind the staging they were two exposed round trips per item)
+    const float r_lse = lbase[tid < S ? tid : S - 1];                    // S_pad <= 256 < 512 threads
+    const int key_c = wave * 32 + r;
+    const uint8_t r_pad = key_pad[tok0 + (key_c < S ? key_c : S - 1)];
     {   // all global loads of the workgroup are issued before the first LDS write (one latency, not one per pass)
         constexpr int NIT = (256 * CH + 511) / 512;
         u32x4 rk[NIT], rv[NIT], rq[NIT], rg[NIT], ro[NIT];
@@ -527,11 +532,11 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
             }
         }
     }
-    for (int q = tid; q < S_pad; q += 512) sLseA[q] = (q < S) ? lbase[q] * 1.4426950408889634f : INFINITY;   // log2 units
+    if (tid < S_pad) sLseA[tid] = (tid < S) ? r_lse * 1.4426950408889634f : INFINITY;   // log2 units
 
     const int kt = wave;
     const int key = kt * 32 + r;
-    const bool key_live = kt < nkt && key < S && !key_pad[tok0 + key];
+    const bool key_live = kt < nkt && key < S && !r_pad;
     const float madd = (kt >= nkt || key >= S) ? -INFINITY : (key_live ? 0.f : -1e9f * 1.4426950408889634f);
     const float scale2 = scale * 1.4426950408889634f;
     const bool tile_live = __any(key_live);
