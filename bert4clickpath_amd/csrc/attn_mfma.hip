@@ -121,7 +121,9 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__r
     const bf16_t *kbase = qkv + tok0 * ld + dm + hh * DH;
     const bf16_t *vbase = kbase + dm;
 
-    // every global load of the workgroup is issued up front: Q fragments, then K / V rows
+    // every global load of the workgroup is issued up front: the key-padding byte (unconditional on a clamped index: a
+    // conditional load behind the staging barrier was an exposed round trip), Q fragments, then K / V rows
+    const uint8_t r_padk = key_pad[tok0 + (tid < S ? tid : S - 1)];       // S_pad <= 256 < 512 threads
     const int qrow = wave * 32 + r;
     const bool qvalid = wave < nkt && qrow < S;
     bf16x8 qf[NKS];
@@ -156,8 +158,9 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__r
         }
     }
     __syncthreads();
-    for (int k = tid; k < S_pad; k += 512) {
-        const bool live = k < S && !key_pad[tok0 + k];
+    if (tid < S_pad) {
+        const int k = tid;
+        const bool live = k < S && !r_padk;
         sMask[k] = (k >= S) ? -INFINITY : (live ? 0.f : -1e9f * 1.4426950408889634f);
         if (live) sLive[k >> 5] = 1;     // benign race: every writer stores 1
     }
