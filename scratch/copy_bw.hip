@@ -1,6 +1,7 @@
 // Achievable HBM bandwidth of a read+write stream on MI355X under different access recipes (scratch experiment).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <int MODE, int UNROLL>
 __global__ void __launch_bounds__(256) copyk(const u32x4 *__restrict__ a, const u32x4 *__restrict__ b, u32x4 *__restrict__ c, size_t n) {
@@ -32,7 +33,7 @@ template <int MODE, int UNROLL> void run(const char *name, u32x4 *a, u32x4 *b, u
     printf("%-44s grid %6d  %7.1f us  %6.0f GB/s\n", name, grid, ms / it * 1e3, bytes / (ms / it * 1e-3) / 1e9);
 }
 int main() {
-    const size_t n = (size_t)819200 * 128 * 2 / 16;   // one [T][128] bf16 tensor = 210 MB
+    const size_t n = (size_t)(getenv("COPY_MB") ? atol(getenv("COPY_MB")) : 210) * 1000000 / 16;   // bytes per tensor
     u32x4 *a, *b, *c;
     hipMalloc(&a, n * 16); hipMalloc(&b, n * 16); hipMalloc(&c, n * 16);
     hipMemset(a, 1, n * 16); hipMemset(b, 2, n * 16);
