@@ -246,24 +246,27 @@ __global__ void __launch_bounds__(256) embed_bwd_sorted_kernel(EmbedArgs a, Embe
                 }
             }
         };
-        for (int j0 = 0; j0 < np; j0 += 4) {
-            float g0[4], g1[4];
-            int tk[4];
-            int64_t idj[4];
+        constexpr int NR = 8;                        // rows in flight (16 measured slower)
+        const int colc = on ? col : 0;               // loads are unconditional on clamped indices (a conditional load is
+        for (int j0 = 0; j0 < np; j0 += NR) {        // waited for at its join: one row in flight instead of NR)
+            float g0[NR], g1[NR];
+            int tk[NR];
+            int64_t idj[NR];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {            // four rows in flight
+            for (int u = 0; u < NR; ++u) {
                 const int j = j0 + u;
-                tk[u] = __shfl(my_tok, j & 63);
+                tk[u] = __shfl(my_tok, j & 63);      // lanes past np hold token 0: a valid row
                 idj[u] = __shfl(my_id, j & 63);
-                g0[u] = g1[u] = 0.f;
-                if (j < np && on) {
-                    const T *src = dout + (int64_t)tk[u] * ld + c0 + col;
-                    g0[u] = (float)src[0];
-                    g1[u] = (float)src[1];
-                }
+                const T *src = dout + (int64_t)tk[u] * ld + c0 + colc;
+                g0[u] = (float)src[0];
+                g1[u] = (float)src[1];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NR; ++u) {
+                if (j0 + u >= np || !on) g0[u] = g1[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
                 if (j0 + u >= np) break;             // wave-uniform
                 if (idj[u] != cur) {                 // wave-uniform
                     flush(cur);
