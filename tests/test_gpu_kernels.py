@@ -251,6 +251,32 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, dh):
     assert float(kv_grad[0, S - 4:].abs().max()) == 0.0
 
 
+def test_attention_bwd_more_items_than_workgroups(ops):
+    """B * H = 700 (sequence, head) items on a 256-CU part: the persistent backward grid walks several items per
+    workgroup, taken from the work counter; ragged padding and sequences without any gradient in the mix."""
+    g = torch.Generator().manual_seed(11)
+    B, S, H, dh = 350, 72, 2, 64
+    d = H * dh
+    qkv = torch.randn(B * S, 3 * d, generator=g) * 0.7
+    lens = torch.randint(5, S + 1, (B,), generator=g)
+    pad = (torch.arange(S)[None, :] >= lens[:, None]).to(torch.uint8)
+    do = torch.randn(B, S, d, generator=g)
+    do[pad.bool()] = 0.0                       # padded positions carry no gradient (whole query tiles become +0)
+    do[::7] = 0.0                              # every seventh sequence has none at all
+    do = do.reshape(B * S, d)
+    qd, dod = dev(qkv, torch.bfloat16), dev(do, torch.bfloat16)
+    o, lse = ops.attn_fwd(qd, pad.cuda(), B, S, H, dh)
+    q64 = qd.double().cpu().requires_grad_(True)
+    o_ref, _ = _attn_ref(q64, pad, B, S, H, dh)
+    assert rel_err(o, o_ref.detach()) < 1.2e-2
+    o_ref.backward(dod.double().cpu())
+    dqkv = ops.attn_bwd(qd, pad.cuda(), o, dod, lse, B, S, H, dh)
+    assert rel_err(dqkv, q64.grad) < 2.5e-2
+    assert float(dqkv.reshape(B, S, 3 * d)[::7].abs().max()) == 0.0
+    again = ops.attn_bwd(qd, pad.cuda(), o, dod, lse, B, S, H, dh)     # item order differs from run to run, the result does not
+    assert torch.equal(again, dqkv)
+
+
 @pytest.mark.parametrize('B,S,H,dh', [(3, 200, 2, 64), (2, 224, 1, 64), (3, 130, 2, 32)])
 def test_attention_bwd_zero_do_tiles(ops, B, S, H, dh):
     """Query tiles whose dO rows are all +0 (padded positions under a [MASK]-only loss) are skipped by the bf16 kernel:
