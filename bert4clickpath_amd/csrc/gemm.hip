@@ -497,6 +497,16 @@ __global__ void __launch_bounds__(256) gemm_nt_lnbwd_kernel(const bf16_t *__rest
 #pragma unroll
     for (int k = 0; k < 8; ++k) gm[k] = 0.f;
     if (col < N) Vec8<float>::load(gamma + col, gm);
+    // mean / rstd of the lane's eight rows: requested now, used in the epilogue (loaded inside the epilogue loop under
+    // `if (on)` they were waited for on the spot: eight exposed round trips per workgroup)
+    float sma[4], sra[4], smb[4], srb[4];   // rows (tid >> 4) + 16 q: q = 0..3 and 4..7 (rotated like xa / xb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {            // unconditional, on clamped rows
+        const int64_t ra = m0 + (tid >> 4) + 16 * q, rb = ra + 64;
+        const float *pa = stats + (ra < M ? ra : M - 1) * 2, *pb = stats + (rb < M ? rb : M - 1) * 2;
+        sma[q] = pa[0]; sra[q] = pa[1];
+        smb[q] = pb[0]; srb[q] = pb[1];
+    }
     nt_store(smem, tid, xa);
     nt_store(smem + TILE_BYTES, tid, xb);
     __syncthreads();
@@ -565,8 +575,8 @@ __global__ void __launch_bounds__(256) gemm_nt_lnbwd_kernel(const bf16_t *__rest
         float gv[8], xh[8];
         float s1 = 0.f, s2 = 0.f, mean = 0.f, rstd = 0.f;
         if (on) {
-            mean = stats[grow * 2];
-            rstd = stats[grow * 2 + 1];
+            mean = sma[i];
+            rstd = sra[i];
             const u32x2 lo = *reinterpret_cast<const u32x2 *>(smem + row * LN_OUT_STRIDE + part * 16);
             const u32x2 hi = *reinterpret_cast<const u32x2 *>(smem + row * LN_OUT_STRIDE + part * 16 + 8);
             const u32x4 w4 = {lo[0], lo[1], hi[0], hi[1]};
@@ -603,7 +613,7 @@ __global__ void __launch_bounds__(256) gemm_nt_lnbwd_kernel(const bf16_t *__rest
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { xa[i] = xb[i]; za[i] = zb[i]; }
+      for (int i = 0; i < 4; ++i) { xa[i] = xb[i]; za[i] = zb[i]; sma[i] = smb[i]; sra[i] = srb[i]; }
     }
     // column sums of the workgroup's rows: 16 row groups -> LDS -> one 1-KB partial row (no global atomics: 6,400
     // workgroups adding to the same 256 addresses would serialise at ~100 ns per add)
