@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const T *__restrict__ x
 
 // backward: dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dout * gamma.
 // dgamma/dbeta: per-thread partials over the block's rows -> LDS -> one atomic per column per block.
-template <typename T, int G>
+template <typename T, int G, int NP>
 __global__ void __launch_bounds__(256, 4) add_ln_bwd_kernel(const T *__restrict__ dout, const T *__restrict__ z,
                                                          const float *__restrict__ stats, const float *__restrict__ gamma,
                                                          T *__restrict__ dz, T *__restrict__ dy, float *__restrict__ dgamma,
@@ -408,25 +408,26 @@ __global__ void __launch_bounds__(256, 4) add_ln_bwd_kernel(const T *__restrict_
     extern __shared__ __attribute__((aligned(16))) float red[];  // [2][d]
     const int lane_in_row = threadIdx.x & (G - 1);
     const int rows_per_block = 256 / G;
-    const int npass = (d + G * 8 - 1) / (G * 8);
     const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
     const float inv_d = 1.0f / (float)d;
     for (int i = threadIdx.x; i < 2 * d; i += 256) red[i] = 0.f;
     __syncthreads();
-    float pg[LN_MAX_PASS][8], pb[LN_MAX_PASS][8];
+    // NP = passes of G * 8 columns a row needs (1 for d <= 128 at G = 16): a runtime pass count kept the second pass's
+    // 64 registers allocated
+    float pg[NP][8], pb[NP][8];
 #pragma unroll
-    for (int p = 0; p < LN_MAX_PASS; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int k = 0; k < 8; ++k) pg[p][k] = pb[p][k] = 0.f;
 
     for (int64_t row = blockIdx.x * (int64_t)rows_per_block + threadIdx.x / G; row < rows;
          row += (int64_t)gridDim.x * rows_per_block) {
         const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-        float gv[LN_MAX_PASS][8], xh[LN_MAX_PASS][8];
+        float gv[NP][8], xh[NP][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int p = 0; p < LN_MAX_PASS; ++p) {
-            if (p < npass) {
+        for (int p = 0; p < NP; ++p) {
+            {
                 const int c = (p * G + lane_in_row) * 8;
                 if (c < d) {
                     float go[8], zz[8], gm[8];
@@ -448,8 +449,8 @@ __global__ void __launch_bounds__(256, 4) add_ln_bwd_kernel(const T *__restrict_
         s1 = group_sum<G>(s1) * inv_d;
         s2 = group_sum<G>(s2) * inv_d;
 #pragma unroll
-        for (int p = 0; p < LN_MAX_PASS; ++p) {
-            if (p < npass) {
+        for (int p = 0; p < NP; ++p) {
+            {
                 const int c = (p * G + lane_in_row) * 8;
                 if (c < d) {
                     float o[8];
@@ -467,8 +468,8 @@ __global__ void __launch_bounds__(256, 4) add_ln_bwd_kernel(const T *__restrict_
         }
     }
 #pragma unroll
-    for (int p = 0; p < LN_MAX_PASS; ++p) {
-        if (p < npass) {
+    for (int p = 0; p < NP; ++p) {
+        {
             const int c = (p * G + lane_in_row) * 8;
             if (c < d) {
 #pragma unroll
@@ -529,13 +530,25 @@ extern "C" int b4c_add_dropout_layernorm_bwd(const void *dout, const void *z, co
     B4C_REQUIRE(dropout_rate == 0.f || dy, "add_ln_bwd: dy required when dropout_rate > 0");
     const int g = ln_group(d);
     int grid = grid_for(rows * g, 256);
-    if (grid > 1024) grid = 1024;  // fewer blocks -> fewer dgamma/dbeta atomics
+    if (grid > 1024) grid = 1024;  // fewer blocks -> fewer dgamma/dbeta atomics (six per CU measured slower than four)
     const size_t shm = 2 * (size_t)d * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    const int npass = (d + g * 8 - 1) / (g * 8);      // 1, or 2 when d > 512
+#define LN_BWD_LAUNCH(TT, GG, NPP) add_ln_bwd_kernel<TT, GG, NPP><<<grid, 256, shm, st>>>((const TT *)dout, (const TT *)z, stats, gamma, (TT *)dz, (TT *)dy, dgamma, dbeta, rows, d, dropout_rate, seed)
+#define LN_BWD_DISPATCH(TT)                                                                              \
+    switch (g) {                                                                                         \
+        case 1: LN_BWD_LAUNCH(TT, 1, 1); break;                                                          \
+        case 2: LN_BWD_LAUNCH(TT, 2, 1); break;                                                          \
+        case 4: LN_BWD_LAUNCH(TT, 4, 1); break;                                                          \
+        case 8: LN_BWD_LAUNCH(TT, 8, 1); break;                                                          \
+        case 16: LN_BWD_LAUNCH(TT, 16, 1); break;                                                        \
+        case 32: LN_BWD_LAUNCH(TT, 32, 1); break;                                                        \
+        default: if (npass == 1) LN_BWD_LAUNCH(TT, 64, 1); else LN_BWD_LAUNCH(TT, 64, 2); break;         \
+    }
     if (dtype == B4C_F32) {
-        LN_DISPATCH_G(add_ln_bwd_kernel, float, g, <<<grid, 256, shm, st>>>((const float *)dout, (const float *)z, stats, gamma, (float *)dz, (float *)dy, dgamma, dbeta, rows, d, dropout_rate, seed))
+        LN_BWD_DISPATCH(float)
     } else if (dtype == B4C_BF16) {
-        LN_DISPATCH_G(add_ln_bwd_kernel, bf16_t, g, <<<grid, 256, shm, st>>>((const bf16_t *)dout, (const bf16_t *)z, stats, gamma, (bf16_t *)dz, (bf16_t *)dy, dgamma, dbeta, rows, d, dropout_rate, seed))
+        LN_BWD_DISPATCH(bf16_t)
     } else
         B4C_REQUIRE(false, "add_ln_bwd: dtype %d", dtype);
     return b4c_check_launch("add_ln_bwd");
