@@ -88,6 +88,18 @@ def lib():
             'b4c_vocab_ce_dw': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i64, i64, i32, i32, vp]),
             'b4c_topk_rows': (i32, [vp, i32, i64, i32, i32, vp, vp, vp, vp, i32, vp]),
             'b4c_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
+            'b4c_dropout': (i32, [vp, vp, i64, f32, u64, i32, vp]),
+            'b4c_softmax_rows_bwd': (i32, [vp, i32, vp, i32, vp, i32, i64, i32, i32, vp]),
+            'b4c_sparse_ce_from_probs_bwd': (i32, [vp, i32, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
+            'b4c_sigmoid_fwd': (i32, [vp, vp, i64, i32, vp]),
+            'b4c_sigmoid_bwd': (i32, [vp, vp, vp, i64, i32, vp]),
+            'b4c_masked_bce': (i32, [vp, vp, f32, vp, vp, vp, i64, i32, vp]),
+            'b4c_binary_counts': (i32, [vp, vp, vp, i64, i32, vp]),
+            'b4c_compact_labels': (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp]),
+            'b4c_attn_weights': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+            'b4c_transpose_add': (i32, [vp, i32, vp, i32, i32, i32, vp]),
+            'b4c_rows_gather_f32': (i32, [vp, i32, vp, vp, i32, i64, i32, vp]),
+            'b4c_rows_scatter_add_f32': (i32, [vp, i32, vp, vp, i32, i64, i32, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

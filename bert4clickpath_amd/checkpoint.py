@@ -18,7 +18,8 @@ import torch
 from . import ops
 from .clickstream_transformer import transformer as _tr
 
-FORMAT = 'b4c-checkpoint-1'
+FORMAT = 'b4c-checkpoint-2'       # 2: Adam moments stored per parameter NAME (1 stored the flat arena: order-dependent)
+FORMAT_V1 = 'b4c-checkpoint-1'
 
 
 def save_checkpoint(path, model, optimizer=None, epoch=0, metrics=None):
@@ -34,15 +35,26 @@ def save_checkpoint(path, model, optimizer=None, epoch=0, metrics=None):
         'dropout_seed': {'base': int(_tr.dropout_seeds.base), 'counter': int(_tr.dropout_seeds.counter)},
     }
     if optimizer is not None:
+        # The arena's layout depends on FlatArena(order=...) while its size does not (every slice is padded to 64
+        # elements on its own), so the moments are stored per parameter name and re-mapped on load.
+        names = _param_names(model)
+        m, v = {}, {}
+        for p, o in zip(optimizer.arena.params, optimizer.arena.offsets):
+            if id(p) not in names:
+                raise KeyError('optimizer holds a parameter that is not one of model.named_parameters()')
+            m[names[id(p)]] = optimizer.m[o:o + p.numel()].detach().to('cpu', copy=True).view(p.shape)
+            v[names[id(p)]] = optimizer.v[o:o + p.numel()].detach().to('cpu', copy=True).view(p.shape)
         blob['optimizer'] = {'iterations': int(optimizer.iterations), 'lr': float(optimizer.lr),
                              'beta_1': float(optimizer.beta_1), 'beta_2': float(optimizer.beta_2),
-                             'epsilon': float(optimizer.epsilon),
-                             'numel': int(optimizer.arena.numel),
-                             'm': optimizer.m.detach().to('cpu', copy=True), 'v': optimizer.v.detach().to('cpu', copy=True)}
+                             'epsilon': float(optimizer.epsilon), 'm': m, 'v': v}
     tmp = path + '.tmp'
     torch.save(blob, tmp)
     os.replace(tmp, path)          # a crash never leaves a half-written "latest" checkpoint
     return path
+
+
+def _param_names(model):
+    return {id(p): n for n, p in model.named_parameters()}
 
 
 def latest_checkpoint(ckpt_dir):
@@ -55,7 +67,7 @@ def load_checkpoint(path, model, optimizer=None, strict=True):
     """Restore `model` (and `optimizer` if given and present in the file).  Returns the checkpoint's
     {'epoch', 'metrics'}.  The packed bf16 / fp32 compute copies of the weights are refreshed on next use."""
     blob = torch.load(path, map_location='cpu', weights_only=True)
-    if blob.get('format') != FORMAT:
+    if blob.get('format') not in (FORMAT, FORMAT_V1):
         raise ValueError('%s is not a %s file' % (path, FORMAT))
     own = model.state_dict()
     missing = [k for k in own if k not in blob['model']]
@@ -71,10 +83,20 @@ def load_checkpoint(path, model, optimizer=None, strict=True):
     ops.bump_weights_epoch()
     if optimizer is not None and 'optimizer' in blob:
         o = blob['optimizer']
-        if int(o['numel']) != int(optimizer.arena.numel):
-            raise ValueError('optimizer arena has %d elements, checkpoint %d (different model or parameter order)'
-                             % (optimizer.arena.numel, o['numel']))
-        optimizer.load_state_dict(o)
+        if blob['format'] == FORMAT_V1:
+            raise ValueError('%s stores the Adam moments as one flat arena without its layout (format 1): they cannot be '
+                             'mapped onto parameters safely; load the weights with optimizer=None and re-save' % path)
+        names = _param_names(model)
+        with torch.no_grad():
+            for p, off in zip(optimizer.arena.params, optimizer.arena.offsets):
+                n = names.get(id(p))
+                if n is None or n not in o['m'] or n not in o['v']:
+                    raise KeyError('checkpoint has no Adam moments for parameter %r' % n)
+                if tuple(o['m'][n].shape) != tuple(p.shape):
+                    raise ValueError('%s: moment shape %s, parameter shape %s' % (n, tuple(o['m'][n].shape), tuple(p.shape)))
+                optimizer.m[off:off + p.numel()].view(p.shape).copy_(o['m'][n])
+                optimizer.v[off:off + p.numel()].view(p.shape).copy_(o['v'][n])
+        optimizer.iterations, optimizer.lr = int(o['iterations']), float(o['lr'])
         optimizer.beta_1, optimizer.beta_2, optimizer.epsilon = o['beta_1'], o['beta_2'], o['epsilon']
     ds = blob.get('dropout_seed')
     if ds:

@@ -1,6 +1,8 @@
 from .clickstream_transformer import ClickstreamTransformer, TransformerInputPrep   # noqa: F401
-from .head import SoftMaxHead                                                       # noqa: F401
-from .losses import MaskedLoss, sparse_categorical_crossentropy                     # noqa: F401
+from .head import (BinaryClassificationHead, ClozeMaskedItemPrediction,             # noqa: F401
+                   MultiLabel_MultiClass_classification, SoftMaxHead)
+from .losses import MaskedLoss, binary_crossentropy, sparse_categorical_crossentropy  # noqa: F401
+from .metrics import F1Score, MaskedMetric, PositiveRate, PredictedPositives          # noqa: F401
 from .transformer import (Encoder, EncoderLayer, MultiHeadAttention, Transformer,   # noqa: F401
                           create_padding_mask, point_wise_feed_forward_network, positional_encoding,
                           scaled_dot_product_attention)

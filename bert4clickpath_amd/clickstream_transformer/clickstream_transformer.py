@@ -99,6 +99,10 @@ class ClickstreamTransformer(nn.Module):
             embedding_dims=self.embedding_dims, num_layers=num_encoder_layers,
             num_attention_heads=num_attention_heads, encoder_ff_dim=100,   # hard-coded in the reference (:225)
             dropout_rate=dropout_rate, compute_dtype=compute_dtype)
+        if hasattr(self.head, 'tie') and getattr(self.head, '_table', None) is None:
+            # tied-weight head: project back onto the FIRST embedded feature's table (the items)
+            first = list(self.embedding_dims.keys())[0]
+            self.head.tie(self.transformer.embedding_layers[first].weight)
         if hasattr(self.head, 'build'):
             self.head.build(self.transformer.d_model)
 
@@ -196,27 +200,45 @@ class ClickstreamTransformer(nn.Module):
         return logits
 
     # ---- fused MI355X entry points ----------------------------------------------------------------
-    def _masked_rows(self, inputs, training, flat_idx=None):
+    def _masked_rows(self, inputs, training, flat_idx=None, cap=None, labels_padded=None):
+        """Encoder output rows at the [MASK] positions, row-major.
+        flat_idx given: used as is.  cap given: the sync-free form -- index generation and label compaction stay on
+        the device, exactly `cap` rows come back (those beyond the real count R are zero rows whose label is -1) together
+        with the compact int32 labels.  Neither: R is read back from the device (one host sync)."""
         enc, ids_first, raw_first, _, _ = self._encode(inputs, training)
         B, S, d = enc.shape
-        if flat_idx is None:
+        lab = None
+        if flat_idx is None and cap is not None:
+            counts, offsets, flat, _ = self._match_positions(ids_first, raw_first, cap)
+            lab = ops.compact_labels(labels_padded, counts, offsets, cap, flat)     # also sets flat[R:] = -1
+            flat_idx = flat
+        elif flat_idx is None:
             _, offsets, flat, _ = self._match_positions(ids_first, raw_first)
             R = int(offsets[-1].item())
             flat_idx = flat[:R]
         rows = ops.GatherRowsFn.apply(enc.reshape(B * S, d), flat_idx, flat_idx.shape[0])
-        return rows
+        return rows, lab
 
-    def cloze_loss(self, inputs, labels, training=True, flat_idx=None, variant='tf', unit_grad=True):
+    def cloze_loss(self, inputs, labels, training=True, flat_idx=None, variant='tf', unit_grad=False, max_masked_per_row=None):
         """Masked-item training loss == ClozeMaskedLoss(sparse_categorical_crossentropy)(labels, self(inputs)).
-        labels: (B, M) float32 padded with -1 (reference format) or compact (R,) int ids in row-major
-        mask order.  flat_idx (R,) int32 skips the device-side index generation + host sync."""
-        rows = self._masked_rows(inputs, training, flat_idx)
-        lab = torch.as_tensor(labels, device=rows.device)
-        if lab.dim() == 2:
-            lab = lab[lab != -1.0]
-        lab = lab.to(torch.int32).contiguous()
-        if lab.shape[0] != rows.shape[0]:
-            raise ValueError('%d labels for %d masked positions' % (lab.shape[0], rows.shape[0]))
+        labels: (B, M) float32 padded with -1 (reference format) or compact (R,) int ids in row-major mask order.
+        flat_idx (R,) int32 skips the device-side index generation.  max_masked_per_row=M (the pipeline's
+        MAX_MASKED_ITEMS, cloze_constants.py:1) selects the sync-free form: [MASK] positions and the labels of the padded
+        (B, Mlab) tensor are compacted on the device, the head runs on B*M rows (the unused ones are ignored rows), and no
+        value is read back to the host."""
+        lab = torch.as_tensor(labels, device=self.transformer.pos_encoding.device)
+        if max_masked_per_row is not None and flat_idx is None:
+            if lab.dim() != 2:
+                raise ValueError('the sync-free form needs the padded (B, M) labels')
+            rows, lab = self._masked_rows(inputs, training, None, cap=int(lab.shape[0]) * int(max_masked_per_row),
+                                          labels_padded=lab)
+        else:
+            rows, _ = self._masked_rows(inputs, training, flat_idx)
+            if lab.dim() == 2:
+                lab = lab[lab != -1.0]
+            lab = lab.to(torch.int32).contiguous()
+            if lab.shape[0] != rows.shape[0]:
+                raise ValueError('%d labels for %d masked positions' % (lab.shape[0], rows.shape[0]))
         code = CE_TF if variant == 'tf' else CE_PLAIN
         if hasattr(self.head, 'cloze_ce'):
             return self.head.cloze_ce(rows, lab, code, unit_grad)
@@ -227,7 +249,7 @@ class ClickstreamTransformer(nn.Module):
         """Top-k item ids (label space) at every masked position, ranked over all V items.  Ranks the
         logits (softmax is monotone); returns (topk_idx (R,k) int32, hit (R,), ndcg (R,)) -- the
         latter two when labels are given."""
-        rows = self._masked_rows(inputs, False, flat_idx)
+        rows, _ = self._masked_rows(inputs, False, flat_idx)
         logits = self.head.logits(rows, out_fp32=True)
         lab = None
         if labels is not None:

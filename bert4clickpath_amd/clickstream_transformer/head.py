@@ -1,23 +1,14 @@
-"""Heads.  ``SoftMaxHead`` is the BERT4Rec masked-item head of the reference
-(clickstream_transformer/head.py:29-47; dims from examples/BERT4Rec/source/main.py:262-263):
-relu(Dense) x n, then Dense(V) + softmax, untied from the item embedding."""
+"""Heads (reference clickstream_transformer/head.py:4-69).  ``SoftMaxHead`` is the BERT4Rec masked-item head
+(head.py:29-47; dims from examples/BERT4Rec/source/main.py:262-263): relu(Dense) x n, then Dense(V) + softmax,
+untied from the item embedding.  ``BinaryClassificationHead`` (head.py:4-26) and
+``MultiLabel_MultiClass_classification`` (head.py:50-69) are the reference's other two heads.
+``ClozeMaskedItemPrediction`` is the tied-weight masked-item head BASELINE.json's north_star names; the reference
+has no such class: it is an extension behind the same head_unit contract, with no reference oracle."""
 import torch
 from torch import nn
 
 from .. import ops
 from .transformer import Dense
-
-
-class _SoftmaxRows(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, logits, V):
-        return ops.softmax_rows(logits, V)
-
-    @staticmethod
-    def backward(ctx, g):
-        raise NotImplementedError('materialised-probability backward is not part of the MI355X training path: '
-                                  'train through ClickstreamTransformer.cloze_loss / FusedSoftmaxCE (same loss, '
-                                  'no (B*M) x V tensor)')
 
 
 class SoftMaxHead(nn.Module):
@@ -50,9 +41,16 @@ class SoftMaxHead(nn.Module):
             out += [l.kernel, l.bias]
         return out
 
+    def _built(self):
+        return self.output_layer is not None
+
+    def _proj(self):
+        """(input width, kernel parameter, bias parameter) of the vocabulary projection."""
+        return int(self.output_layer.kernel.shape[0]), self.output_layer.kernel, self.output_layer.bias
+
     def logits(self, x2d, out_fp32=False):
         """x2d: [R, d] -> logits [R, round_up(V, 8)] (pad columns are 0 and must be ignored)."""
-        if self.output_layer is None:
+        if not self._built():
             self.build(x2d.shape[-1])
             self.to(x2d.device)
         need_tape = torch.is_grad_enabled()
@@ -60,29 +58,162 @@ class SoftMaxHead(nn.Module):
 
     def trunk(self, x2d):
         """relu(Dense) x n of head.py:35 alone: the input of the vocabulary projection."""
-        if self.output_layer is None:
+        if not self._built():
             self.build(x2d.shape[-1])
             self.to(x2d.device)
         if not self.intermediate_layers:
             return x2d
         return ops.MLPFn.apply(x2d, self._packs[:-1], torch.is_grad_enabled(), 'relu_last', *self._params()[:-2])
 
-    def cloze_ce(self, x2d, labels_i32, variant, unit_grad=True):
+    def cloze_ce(self, x2d, labels_i32, variant, unit_grad=False):
         """Mean over valid rows of the sparse CE of softmax(Dense(V)(trunk(x))) -- loss only, for training.
         bf16 with a 64 / 128-wide projection input: the logits are never materialised (ops.VocabCEFn);
         otherwise logits + fused softmax / CE (ops.FusedSoftmaxCEFn)."""
         V = self.output_vocab_size
         h = self.trunk(x2d)
-        K = self.output_layer.kernel.shape[0]
+        K, kernel, bias = self._proj()
         if ops.flash_ce and ops.vocab_ce_supported(h, K):
-            return ops.VocabCEFn.apply(h, self._packs[-1], labels_i32, V, variant, unit_grad,
-                                       self.output_layer.kernel, self.output_layer.bias)
-        return ops.FusedSoftmaxCEFn.apply(self.logits(x2d), labels_i32, V, variant, unit_grad)
+            return ops.VocabCEFn.apply(h, self._packs[-1], labels_i32, V, variant, unit_grad, kernel, bias)
+        return ops.FusedSoftmaxCEFn.apply(self._project(h), labels_i32, V, variant, unit_grad)
+
+    def _project(self, h, out_fp32=False):
+        """Vocabulary projection alone: trunk output [R, K] -> logits [R, round_up(V, 8)]."""
+        K, kernel, bias = self._proj()
+        return ops.MLPFn.apply(h, self._packs[-1:], torch.is_grad_enabled(), out_fp32, kernel, bias)
 
     def forward(self, inputs, **kwargs):
         """inputs (B, M, d) -> probabilities (B, M, V), materialised as the reference does."""
         shp = inputs.shape
         lg = self.logits(inputs.reshape(-1, shp[-1]))
         V = self.output_vocab_size
-        probs = _SoftmaxRows.apply(lg, V)
+        probs = ops.SoftmaxRowsFn.apply(lg, V)
         return probs.view(*shp[:-1], probs.shape[-1])[..., :V]
+
+
+class _DenseStackHead(nn.Module):
+    """relu(Dense) x n then one sigmoid Dense: the shared body of the reference's two sigmoid heads."""
+
+    def __init__(self, dense_layer_dims, out_units, input_dim=None):
+        super().__init__()
+        self.dense_layer_dims = list(dense_layer_dims)
+        self.out_units = int(out_units)
+        self.intermediate_layers = nn.ModuleList()
+        self.output_layer = None
+        self._packs = None
+        if input_dim is not None:
+            self.build(input_dim)
+
+    def build(self, input_dim):
+        if self.output_layer is not None:
+            return
+        prev = int(input_dim)
+        for h in self.dense_layer_dims:
+            self.intermediate_layers.append(Dense(prev, h))
+            prev = h
+        self.output_layer = Dense(prev, self.out_units)
+        self._packs = [ops.PackedLinear([l.kernel], [l.bias]) for l in list(self.intermediate_layers) + [self.output_layer]]
+
+    def _params(self):
+        out = []
+        for l in list(self.intermediate_layers) + [self.output_layer]:
+            out += [l.kernel, l.bias]
+        return out
+
+    def _probs(self, inputs):
+        """(.., d) -> sigmoid(Dense(relu(Dense(..)))) as (.., out_units)."""
+        shp = inputs.shape
+        x2d = inputs.reshape(-1, shp[-1])
+        if self.output_layer is None:
+            self.build(shp[-1])
+            self.to(x2d.device)
+        lg = ops.MLPFn.apply(x2d, self._packs, torch.is_grad_enabled(), False, *self._params())   # [R, rup8(units)]
+        p = ops.SigmoidFn.apply(lg)
+        return p[:, :self.out_units].reshape(*shp[:-1], self.out_units)
+
+
+class BinaryClassificationHead(_DenseStackHead):
+    """relu(Dense) x n -> Dense(1, sigmoid) -> squeeze(-1): (B, L, d) -> (B, L) probabilities (head.py:4-26)."""
+
+    def __init__(self, dense_layer_dims, input_dim=None, **kwargs):
+        super().__init__(dense_layer_dims, 1, input_dim)
+
+    def forward(self, inputs, **kwargs):
+        return self._probs(inputs).squeeze(-1)
+
+
+class MultiLabel_MultiClass_classification(_DenseStackHead):
+    """relu(Dense) x n -> Dense(V, sigmoid) -> squeeze(axis=1): (B, 1, d) -> (B, V) probabilities (head.py:50-69;
+    like tf.squeeze(axis=1) it insists on a length-1 axis 1 -- the [CLS] segment, segment_to_head=0)."""
+
+    def __init__(self, dense_layer_dims, output_vocab_size, input_dim=None, **kwargs):
+        super().__init__(dense_layer_dims, output_vocab_size, input_dim)
+        self.output_vocab_size = int(output_vocab_size)
+
+    def forward(self, inputs, **kwargs):
+        p = self._probs(inputs)
+        if p.shape[1] != 1:
+            raise ValueError('Can not squeeze dim[1], expected a dimension of 1, got %d' % p.shape[1])
+        return p.squeeze(1)
+
+
+class ClozeMaskedItemPrediction(SoftMaxHead):
+    """Tied-weight masked-item head (BERT4Rec paper / north_star; NOT in the reference, whose head is untied:
+    head.py:29-47): relu(Dense) x n, a last relu(Dense) back to the item-embedding width when the widths differ, then
+        logits = h . E[offset : offset + V]^T + bias,   probabilities = softmax(logits)
+    with E the item-embedding table of the model (input id = label id + 10, constants.py:14-24, so offset = 10).
+    Same head_unit contract and the same fused entry points as SoftMaxHead (cloze_ce / logits / forward); the
+    projection's gradient is added, transposed, into rows offset .. offset+V of the table's gradient.
+    No reference oracle: checked against the build's own fp64 restatement (oracle/numpy_ref.py)."""
+
+    def __init__(self, dense_layer_dims, output_vocab_size, item_embedding=None, id_offset=10, input_dim=None, **kwargs):
+        super().__init__(dense_layer_dims, output_vocab_size, None)
+        self.id_offset = int(id_offset)
+        self._table = None
+        if item_embedding is not None:
+            self.tie(item_embedding)
+        if input_dim is not None:
+            self.build(input_dim)
+
+    def tie(self, embedding_weight):
+        """embedding_weight: the (V + 11, d_item) Parameter of Transformer.embedding_layers[<items>]
+        (kept by reference, not registered a second time: the model owns it)."""
+        if embedding_weight.shape[0] < self.id_offset + self.output_vocab_size:
+            raise ValueError('embedding table has %d rows, need offset %d + V %d'
+                             % (embedding_weight.shape[0], self.id_offset, self.output_vocab_size))
+        object.__setattr__(self, '_table', embedding_weight)
+        return self
+
+    def build(self, input_dim):
+        if self._packs is not None:
+            return
+        if self._table is None:
+            raise ops.B4CError('ClozeMaskedItemPrediction: call tie(item_embedding_weight) before the first use')
+        d_item = int(self._table.shape[1])
+        prev = int(input_dim)
+        dims = list(self.dense_layer_dims)
+        if (dims[-1] if dims else prev) != d_item:
+            dims.append(d_item)
+        for h in dims:
+            self.intermediate_layers.append(Dense(prev, h))
+            prev = h
+        self.output_bias = nn.Parameter(torch.zeros(self.output_vocab_size))
+        self._packs = [ops.PackedLinear([l.kernel], [l.bias]) for l in self.intermediate_layers] + \
+                      [ops.TiedPackedLinear(self._table, self.id_offset, self.output_vocab_size, self.output_bias)]
+
+    def _built(self):
+        return self._packs is not None
+
+    def _params(self):
+        out = []
+        for l in self.intermediate_layers:
+            out += [l.kernel, l.bias]
+        return out + [self._table, self.output_bias]
+
+    def _proj(self):
+        return int(self._table.shape[1]), self._table, self.output_bias
+
+    def _project(self, h, out_fp32=False):
+        return ops.TiedLogitsFn.apply(h, self._table, self.output_bias, self._packs[-1], bool(out_fp32))
+
+    def logits(self, x2d, out_fp32=False):
+        return self._project(self.trunk(x2d), out_fp32)

@@ -83,15 +83,40 @@ def _mask_to_bytes(mask, B, S, device):
     return (m != 0).to(torch.uint8).contiguous()
 
 
-def scaled_dot_product_attention(q, k, v, mask=None):
-    """q, k, v: (B, H, S, depth) on the HIP device -> (output (B,H,S,depth), None).
-    The attention-weight matrix is never materialised (the reference returns it and discards it,
-    transformer.py:203), so the second result is None."""
+def _key_mask_bytes(mask, B, Sk, device):
+    """Key-side padding masks only: the reference's (B,1,1,Sk) float mask, a (B,Sk) byte / bool / float mask, or None.
+    (The reference's function also accepts any mask broadcastable to (..., Sq, Sk); the encoder never builds one.)"""
+    if mask is None:
+        return torch.zeros(B, Sk, dtype=torch.uint8, device=device)
+    if mask.numel() != B * Sk:
+        raise B4CError('MI355X build: attention masks are key-side padding masks of %d x %d elements, got shape %s'
+                       % (B, Sk, tuple(mask.shape)))
+    return (mask.reshape(B, Sk) != 0).to(torch.uint8).contiguous()
+
+
+def _pad_rows(x, S):
+    """(B, s, d) -> (B, S, d), zero rows appended."""
+    if x.shape[1] == S:
+        return x
+    return torch.nn.functional.pad(x, (0, 0, 0, S - x.shape[1]))
+
+
+def scaled_dot_product_attention(q, k, v, mask=None, return_weights=False):
+    """q: (B, H, Sq, depth), k / v: (B, H, Sk, depth) on the HIP device -> (output (B,H,Sq,depth), weights).
+    The attention-weight matrix (B,H,Sq,Sk) is materialised only with return_weights=True (the reference returns it
+    and its only caller discards it, transformer.py:203); otherwise the second result is None."""
     ops._cuda(q, k, v)
-    B, H, S, dh = q.shape
-    pack = torch.cat([t.permute(0, 2, 1, 3).reshape(B * S, H * dh) for t in (q, k, v)], dim=1).contiguous()
-    o, _ = ops.attn_fwd(pack, _mask_to_bytes(mask, B, S, q.device), B, S, H, dh)
-    return o.view(B, S, H, dh).permute(0, 2, 1, 3), None
+    B, H, Sq, dh = q.shape
+    Sk = k.shape[2]
+    S = max(Sq, Sk)
+    key_pad = _key_mask_bytes(mask, B, Sk, q.device)
+    if Sk < S:
+        key_pad = torch.nn.functional.pad(key_pad, (0, S - Sk), value=1)
+    pack = torch.cat([_pad_rows(t.permute(0, 2, 1, 3).reshape(B, -1, H * dh), S).reshape(B * S, H * dh) for t in (q, k, v)],
+                     dim=1).contiguous()
+    o, lse = ops.attn_fwd(pack, key_pad, B, S, H, dh)
+    w = ops.attn_weights(pack, key_pad, lse, B, S, H, dh)[:, :, :Sq, :Sk] if return_weights else None
+    return o.view(B, S, H, dh)[:, :Sq].permute(0, 2, 1, 3), w
 
 
 class Dense(nn.Module):
@@ -128,20 +153,29 @@ class MultiHeadAttention(nn.Module):
     def get_config(self):
         return {'d_model': self.d_model, 'num_heads': self.num_heads}
 
-    def forward(self, v, k, q, mask):
-        """Self-attention only (v is k is q), as the encoder uses it (reference :203).  Returns
-        (output (B,S,d), None)."""
-        if not (v is k and k is q):
-            raise NotImplementedError('MI355X build: MultiHeadAttention supports self-attention (v is k is q)')
-        B, S, d = q.shape
-        x = q.reshape(B * S, d)
-        wt, _, bias = self._pk_qkv.get(x.dtype, d, False)
-        wo, _, bo = self._pk_o.get(x.dtype, d, False)
-        with torch.no_grad():
-            qkv = ops.gemm_nt(x, wt, 3 * d, bias)
-            o, _ = ops.attn_fwd(qkv, _mask_to_bytes(mask, B, S, q.device), B, S, self.num_heads, self.depth)
-            out = ops.gemm_nt(o, wo, d, bo)
-        return out.view(B, S, d), None
+    def forward(self, v, k, q, mask, return_weights=False):
+        """call(v, k, q, mask) of the reference (:137-160): q (B, Sq, d), k / v (B, Sk, d), key-side padding mask
+        ((B,1,1,Sk) float, 1 = pad, or (B,Sk) bytes) -> (output (B, Sq, d), attention weights (B, H, Sq, Sk) or None).
+        Differentiable; the weights are materialised only on request (the encoder discards them, :203).
+        Sequences of different length are padded to the longer one (pad keys masked, pad queries dropped)."""
+        ops._cuda(v, k, q)
+        B, Sq, d = q.shape
+        Sk = k.shape[1]
+        if v.shape[1] != Sk:
+            raise ValueError('k and v must have the same length (%d vs %d)' % (Sk, v.shape[1]))
+        S = max(Sq, Sk)
+        same = (v is k and k is q)
+        key_pad = _key_mask_bytes(mask, B, Sk, q.device)
+        if Sk < S:
+            key_pad = torch.nn.functional.pad(key_pad, (0, S - Sk), value=1)
+        xq = _pad_rows(q, S).reshape(B * S, d)
+        xk = xq if same else _pad_rows(k, S).reshape(B * S, d)
+        xv = xq if same else (xk if v is k else _pad_rows(v, S).reshape(B * S, d))
+        out, w = ops.MHAFn.apply(xq, xk, xv, key_pad, self.wq.kernel, self.wq.bias, self.wk.kernel, self.wk.bias,
+                                 self.wv.kernel, self.wv.bias, self.dense.kernel, self.dense.bias, self._pk_qkv, self._pk_o,
+                                 B, S, self.num_heads, same, bool(return_weights))
+        out = out.view(B, S, d)[:, :Sq]
+        return out, (w[:, :, :Sq, :Sk] if return_weights else None)
 
 
 class _FeedForward(nn.ModuleList):
@@ -203,8 +237,8 @@ class EncoderLayer(nn.Module):
 
 class Encoder(nn.Module):
     """num_layers EncoderLayers; no final LayerNorm (reference :255-268).  The input dropout of the
-    reference's Encoder.call (:263) is fused into the embedding kernel by ``Transformer``; calling an
-    Encoder on its own with dropout in training mode is therefore not supported."""
+    reference's Encoder.call (:263) is fused into the embedding kernel when ``Transformer`` calls the Encoder;
+    an Encoder called on its own applies it with the stand-alone dropout kernel (same keep-mask generator)."""
 
     def __init__(self, num_layers, d_model, num_heads, dff, dropout_rate, **kwargs):
         super().__init__()
@@ -217,10 +251,9 @@ class Encoder(nn.Module):
                 'dropout_rate': self.dropout_rate}
 
     def forward(self, inputs, training=None, mask=None, _input_dropout_done=False):
-        if training and self.dropout_rate > 0 and not _input_dropout_done:
-            raise NotImplementedError('Encoder input dropout is fused into Transformer\'s embedding kernel; '
-                                      'call the Transformer, or use training=False / dropout_rate=0')
         x = inputs
+        if training and self.dropout_rate > 0 and not _input_dropout_done:
+            x = ops.DropoutFn.apply(x, float(self.dropout_rate), dropout_seeds.next())
         B, S, d = x.shape
         layers = [{'mha': l.mha, 'ffn': l.ffn, 'ln1': l.layernorm1, 'ln2': l.layernorm2} for l in self.enc_layers]
         if mask is not None and mask.dtype == torch.uint8 and mask.dim() == 2 and \

@@ -1,0 +1,470 @@
+// Small HBM-bound kernels around the hot path: stand-alone dropout (Encoder.call's input dropout when the
+// Encoder is used without the embedding stage), the backward of the materialised-probability route
+// (softmax rows, masked sparse CE on probabilities), the binary-task head pieces (sigmoid, masked binary CE,
+// PositiveRate / PredictedPositives / F1 counts), label compaction for the sync-free Cloze step, the
+// attention-weight matrix on request, a transposed accumulate for the tied-weight head, a row-sparse
+// gather / scatter-add pair for the embedding-gradient exchange and a per-row dot product.
+// gfx950, wave64, 16-byte accesses; one workgroup per row for the vocabulary-wide kernels.
+#include <math.h>
+
+#include "common.h"
+
+#define KERAS_EPS 1e-7f
+
+static inline int ew_grid(int64_t work_items, int block) {
+    int64_t g = ceil_div64(work_items, block);
+    const int64_t cap = 256 * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <int NW> __device__ __forceinline__ float ew_block_sum(float v, float *buf) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += buf[i];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// dropout: y[e] = keep(seed, e) ? x[e] / (1 - rate) : 0     (the same op is its own backward)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) dropout_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t n8, float rate, uint64_t seed) {
+    const float inv_keep = 1.0f / (1.0f - rate);
+    const uint32_t thr = b4c_keep_threshold(rate);
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        Vec8<T>::load(x + i * 8, v);
+        const uint32_t km = b4c_keep8(seed, (uint64_t)i * 8, thr);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = ((km >> k) & 1u) ? v[k] * inv_keep : 0.f;
+        Vec8<T>::store(y + i * 8, v);
+    }
+}
+
+extern "C" int b4c_dropout(const void *x, void *y, int64_t n, float rate, uint64_t seed, int dtype, void *stream) {
+    B4C_REQUIRE(x && y && n >= 0 && n % 8 == 0, "dropout: n must be a multiple of 8");
+    B4C_REQUIRE(rate > 0.f && rate < 1.f, "dropout: rate %f must be in (0, 1)", rate);
+    if (n == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(n / 8, 256);
+    if (dtype == B4C_F32) dropout_kernel<float><<<grid, 256, 0, st>>>((const float *)x, (float *)y, n / 8, rate, seed);
+    else if (dtype == B4C_BF16) dropout_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t *)x, (bf16_t *)y, n / 8, rate, seed);
+    else B4C_REQUIRE(false, "dropout: dtype %d", dtype);
+    return b4c_check_launch("dropout");
+}
+
+// ------------------------------------------------------------------------------------------
+// softmax backward on materialised probabilities: dx_j = p_j (g_j - sum_i g_i p_i)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_rows_bwd_kernel(const T *__restrict__ p, int ldp, const T *__restrict__ g, int ldg,
+                                                               T *__restrict__ dx, int ldx, int64_t R, int V) {
+    __shared__ float buf[4];
+    const int tid = threadIdx.x;
+    const int nch = (V + 7) >> 3;
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        const T *pr = p + row * ldp, *gr = g + row * ldg;
+        T *xr = dx + row * ldx;
+        float s = 0.f;
+        for (int c = tid; c < nch; c += 256) {
+            float a[8], b[8];
+            Vec8<T>::load(pr + c * 8, a);
+            Vec8<T>::load(gr + c * 8, b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c * 8 + k < V) s += a[k] * b[k];
+        }
+        s = ew_block_sum<4>(s, buf);
+        const int nch_out = ldx >> 3;
+        for (int c = tid; c < nch_out; c += 256) {
+            float a[8], b[8];
+            if (c < nch) { Vec8<T>::load(pr + c * 8, a); Vec8<T>::load(gr + c * 8, b); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = (c * 8 + k < V) ? a[k] * (b[k] - s) : 0.f;
+            Vec8<T>::store(xr + c * 8, a);
+        }
+    }
+}
+
+extern "C" int b4c_softmax_rows_bwd(const void *probs, int ldp, const void *dprobs, int ldg, void *dlogits, int ldx,
+                                    int64_t R, int V, int dtype, void *stream) {
+    B4C_REQUIRE(probs && dprobs && dlogits && R >= 0 && V > 0, "softmax_rows_bwd: bad argument");
+    B4C_REQUIRE(ldp % 8 == 0 && ldg % 8 == 0 && ldx % 8 == 0 && ldp >= V && ldg >= V && ldx >= V, "softmax_rows_bwd: pitches");
+    if (R == 0) return B4C_OK;
+    const int grid = (int)(R < 4096 ? R : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32)
+        softmax_rows_bwd_kernel<float><<<grid, 256, 0, st>>>((const float *)probs, ldp, (const float *)dprobs, ldg, (float *)dlogits, ldx, R, V);
+    else if (dtype == B4C_BF16)
+        softmax_rows_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t *)probs, ldp, (const bf16_t *)dprobs, ldg, (bf16_t *)dlogits, ldx, R, V);
+    else B4C_REQUIRE(false, "softmax_rows_bwd: dtype %d", dtype);
+    return b4c_check_launch("softmax_rows_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// backward of b4c_sparse_ce_from_probs:  loss_r = log sum_j clip(p_j) - log clip(p_y)   (TF variant)
+//   d loss_r / d p_j = u_j (1/S - [j = y] / clip(p_y)),  u_j = [eps <= p_j <= 1 - eps]
+//   plain variant: - [j = y] / p_y.       dprobs = gscale[0] * that for valid rows, 0 for pad rows.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) sparse_ce_probs_bwd_kernel(const T *__restrict__ p, int ld, const float *__restrict__ labels,
+                                                                  const float *__restrict__ gscale, T *__restrict__ dp, int ld_dp,
+                                                                  int64_t R, int V, int variant) {
+    __shared__ float buf[4];
+    const int tid = threadIdx.x;
+    const int nch = (V + 7) >> 3, nch_out = ld_dp >> 3;
+    const float gs = gscale[0];
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        const float lab = labels[row];
+        const T *pr = p + row * ld;
+        T *dr = dp + row * ld_dp;
+        const int y = (int)lab;
+        const bool pad = lab == -1.0f;
+        const bool bad = !pad && (y < 0 || y >= V);
+        if (pad || bad) {
+            for (int c = tid; c < nch_out; c += 256) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (bad && c * 8 + k < V) ? NAN : 0.f;
+                Vec8<T>::store(dr + c * 8, v);
+            }
+            continue;
+        }
+        float invS = 0.f;
+        if (variant == B4C_CE_TF) {
+            float s = 0.f;
+            for (int c = tid; c < nch; c += 256) {
+                float v[8];
+                Vec8<T>::load(pr + c * 8, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c * 8 + k < V) s += fminf(fmaxf(v[k], KERAS_EPS), 1.0f - KERAS_EPS);
+            }
+            invS = 1.0f / ew_block_sum<4>(s, buf);
+        }
+        const float py = (float)pr[y];
+        const float pyc = fminf(fmaxf(py, KERAS_EPS), 1.0f - KERAS_EPS);
+        for (int c = tid; c < nch_out; c += 256) {
+            float v[8];
+            if (c < nch) Vec8<T>::load(pr + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = c * 8 + k;
+                float g = 0.f;
+                if (j < V) {
+                    if (variant == B4C_CE_TF) {
+                        const float u = (v[k] >= KERAS_EPS && v[k] <= 1.0f - KERAS_EPS) ? 1.f : 0.f;
+                        g = u * (invS - (j == y ? 1.0f / pyc : 0.f));
+                    } else {
+                        g = (j == y) ? -1.0f / py : 0.f;
+                    }
+                }
+                v[k] = g * gs;
+            }
+            Vec8<T>::store(dr + c * 8, v);
+        }
+    }
+}
+
+extern "C" int b4c_sparse_ce_from_probs_bwd(const void *probs, int ld, const float *labels, const float *gscale, void *dprobs,
+                                            int ld_dp, int64_t R, int V, int variant, int dtype, void *stream) {
+    B4C_REQUIRE(probs && labels && gscale && dprobs && R >= 0 && V > 0, "sparse_ce_from_probs_bwd: bad argument");
+    B4C_REQUIRE(ld % 8 == 0 && ld >= V && ld_dp % 8 == 0 && ld_dp >= V, "sparse_ce_from_probs_bwd: pitch");
+    B4C_REQUIRE(variant == B4C_CE_TF || variant == B4C_CE_PLAIN, "sparse_ce_from_probs_bwd: variant %d", variant);
+    if (R == 0) return B4C_OK;
+    const int grid = (int)(R < 4096 ? R : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32)
+        sparse_ce_probs_bwd_kernel<float><<<grid, 256, 0, st>>>((const float *)probs, ld, labels, gscale, (float *)dprobs, ld_dp, R, V, variant);
+    else if (dtype == B4C_BF16)
+        sparse_ce_probs_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t *)probs, ld, labels, gscale, (bf16_t *)dprobs, ld_dp, R, V, variant);
+    else B4C_REQUIRE(false, "sparse_ce_from_probs_bwd: dtype %d", dtype);
+    return b4c_check_launch("sparse_ce_from_probs_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// sigmoid (Dense(activation='sigmoid') of the binary / multi-label heads, head.py:12,59) and its backward
+// ------------------------------------------------------------------------------------------
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) sigmoid_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ out, int64_t n8) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8], w[8];
+        Vec8<T>::load(a + i * 8, v);
+        if (BWD) {   // a = y (probabilities), b = dy  ->  dx = dy * y * (1 - y)
+            Vec8<T>::load(b + i * 8, w);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = w[k] * v[k] * (1.0f - v[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 1.0f / (1.0f + expf(-v[k]));
+        }
+        Vec8<T>::store(out + i * 8, v);
+    }
+}
+
+extern "C" int b4c_sigmoid_fwd(const void *x, void *y, int64_t n, int dtype, void *stream) {
+    B4C_REQUIRE(x && y && n >= 0 && n % 8 == 0, "sigmoid_fwd: n must be a multiple of 8");
+    if (n == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(n / 8, 256);
+    if (dtype == B4C_F32) sigmoid_kernel<float, false><<<grid, 256, 0, st>>>((const float *)x, nullptr, (float *)y, n / 8);
+    else if (dtype == B4C_BF16) sigmoid_kernel<bf16_t, false><<<grid, 256, 0, st>>>((const bf16_t *)x, nullptr, (bf16_t *)y, n / 8);
+    else B4C_REQUIRE(false, "sigmoid_fwd: dtype %d", dtype);
+    return b4c_check_launch("sigmoid_fwd");
+}
+
+extern "C" int b4c_sigmoid_bwd(const void *y, const void *dy, void *dx, int64_t n, int dtype, void *stream) {
+    B4C_REQUIRE(y && dy && dx && n >= 0 && n % 8 == 0, "sigmoid_bwd: n must be a multiple of 8");
+    if (n == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(n / 8, 256);
+    if (dtype == B4C_F32) sigmoid_kernel<float, true><<<grid, 256, 0, st>>>((const float *)y, (const float *)dy, (float *)dx, n / 8);
+    else if (dtype == B4C_BF16) sigmoid_kernel<bf16_t, true><<<grid, 256, 0, st>>>((const bf16_t *)y, (const bf16_t *)dy, (bf16_t *)dx, n / 8);
+    else B4C_REQUIRE(false, "sigmoid_bwd: dtype %d", dtype);
+    return b4c_check_launch("sigmoid_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// masked binary cross-entropy on probabilities (MaskedLoss with tf.keras.backend.binary_crossentropy,
+// losses.py:31-98): o = clip(p, eps, 1-eps); bce = -(t log(o + eps) + (1-t) log(1 - o + eps));
+// weight = pos_weight where t == 1 (if pos_weight > 0) else 1; pad labels (-1) give 0 and are not counted.
+// sums[0] += sum weight * bce, sums[1] += number of non-pad items.
+// dprobs (optional): weight * d bce / d p  (0 outside the clip range and at pads), unscaled.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) masked_bce_kernel(const T *__restrict__ p, const float *__restrict__ labels, float pos_weight,
+                                                         float *__restrict__ item_loss, float *__restrict__ sums,
+                                                         float *__restrict__ dprobs, int64_t n) {
+    __shared__ float buf[4];
+    float tot = 0.f, cnt = 0.f;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float t = labels[i];
+        float loss = 0.f, d = 0.f;
+        if (t != -1.0f) {
+            const float pv = (float)p[i];
+            const float o = fminf(fmaxf(pv, KERAS_EPS), 1.0f - KERAS_EPS);
+            const float w = (pos_weight > 0.f && t == 1.0f) ? pos_weight : 1.0f;
+            loss = -(t * logf(o + KERAS_EPS) + (1.0f - t) * logf(1.0f - o + KERAS_EPS)) * w;
+            if (pv >= KERAS_EPS && pv <= 1.0f - KERAS_EPS) d = -(t / (o + KERAS_EPS) - (1.0f - t) / (1.0f - o + KERAS_EPS)) * w;
+            cnt += 1.f;
+        }
+        tot += loss;
+        if (item_loss) item_loss[i] = loss;
+        if (dprobs) dprobs[i] = d;
+    }
+    tot = ew_block_sum<4>(tot, buf);
+    cnt = ew_block_sum<4>(cnt, buf);
+    if (threadIdx.x == 0) { atomicAdd(sums, tot); atomicAdd(sums + 1, cnt); }
+}
+
+extern "C" int b4c_masked_bce(const void *probs, const float *labels, float pos_weight, float *item_loss, float *sums,
+                              float *dprobs, int64_t n, int dtype, void *stream) {
+    B4C_REQUIRE(probs && labels && sums && n >= 0, "masked_bce: bad argument");
+    if (n == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(n, 256) > 512 ? 512 : ew_grid(n, 256);
+    if (dtype == B4C_F32) masked_bce_kernel<float><<<grid, 256, 0, st>>>((const float *)probs, labels, pos_weight, item_loss, sums, dprobs, n);
+    else if (dtype == B4C_BF16) masked_bce_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t *)probs, labels, pos_weight, item_loss, sums, dprobs, n);
+    else B4C_REQUIRE(false, "masked_bce: dtype %d", dtype);
+    return b4c_check_launch("masked_bce");
+}
+
+// ------------------------------------------------------------------------------------------
+// counts behind PositiveRate / PredictedPositives / F1Score (metrics.py:5-87), one pass:
+//   out[0] += sum mask * y_true      out[1] += sum mask            (mask = y_true != -1)
+//   out[2] += sum mask * round(y_pred)
+//   out[3] += #(int(y_true) == 1 and int(round(y_pred)) == 1)   out[4] += #(int(y_true) == 1)
+//   out[5] += #(int(round(y_pred)) == 1)            (tf.round: half to even; F1 counts are NOT masked, as the reference)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) binary_counts_kernel(const float *__restrict__ y_true, const T *__restrict__ y_pred,
+                                                            float *__restrict__ out, int64_t n) {
+    __shared__ float buf[4];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float t = y_true[i];
+        const float r = rintf((float)y_pred[i]);
+        const float m = (t != -1.0f) ? 1.f : 0.f;
+        acc[0] += m * t;
+        acc[1] += m;
+        acc[2] += m * r;
+        const bool ct = (int)t == 1, pt = (int)r == 1;
+        acc[3] += (ct && pt) ? 1.f : 0.f;
+        acc[4] += ct ? 1.f : 0.f;
+        acc[5] += pt ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float s = ew_block_sum<4>(acc[k], buf);
+        if (threadIdx.x == 0) atomicAdd(out + k, s);
+    }
+}
+
+extern "C" int b4c_binary_counts(const float *y_true, const void *y_pred, float *out6, int64_t n, int dtype, void *stream) {
+    B4C_REQUIRE(y_true && y_pred && out6 && n >= 0, "binary_counts: bad argument");
+    if (n == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int g0 = ew_grid(n, 256), grid = g0 > 512 ? 512 : g0;
+    if (dtype == B4C_F32) binary_counts_kernel<float><<<grid, 256, 0, st>>>(y_true, (const float *)y_pred, out6, n);
+    else if (dtype == B4C_BF16) binary_counts_kernel<bf16_t><<<grid, 256, 0, st>>>(y_true, (const bf16_t *)y_pred, out6, n);
+    else B4C_REQUIRE(false, "binary_counts: dtype %d", dtype);
+    return b4c_check_launch("binary_counts");
+}
+
+// ------------------------------------------------------------------------------------------
+// label compaction for the sync-free Cloze step: padded (B, M) float labels (-1 = pad, row b's labels are the
+// first counts[b] entries, in mask order) -> compact int32 [cap] in the row-major order of b4c_mask_positions;
+// entries >= R (= offsets[B]) become -1 (ignored rows) in `out`, and -1 (zero row) in flat_idx when given.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) compact_labels_kernel(const float *__restrict__ labels, int B, int M,
+                                                             const int32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
+                                                             int32_t *__restrict__ out, int32_t *__restrict__ flat_idx, int32_t cap) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= cap) return;
+    const int32_t R = offsets[B];
+    if (i >= R) {
+        out[i] = -1;
+        if (flat_idx) flat_idx[i] = -1;
+        return;
+    }
+    // destination i belongs to the row b with offsets[b] <= i < offsets[b + 1] (rows without a match are skipped)
+    int lo = 0, hi = B;            // invariant: offsets[lo] <= i < offsets[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= (int32_t)i) lo = mid; else hi = mid;
+    }
+    const int m = (int)i - offsets[lo];
+    float v = -1.0f;
+    if (m < M) v = labels[(int64_t)lo * M + m];
+    out[i] = (v == -1.0f) ? -1 : (int32_t)v;
+}
+
+extern "C" int b4c_compact_labels(const float *labels, int B, int M, const int32_t *counts, const int32_t *offsets,
+                                  int32_t *out, int32_t *flat_idx, int32_t cap, void *stream) {
+    B4C_REQUIRE(labels && counts && offsets && out && B > 0 && M > 0 && cap > 0, "compact_labels: bad argument");
+    compact_labels_kernel<<<(int)ceil_div64(cap, 256), 256, 0, (hipStream_t)stream>>>(labels, B, M, counts, offsets, out, flat_idx, cap);
+    return b4c_check_launch("compact_labels");
+}
+
+// ------------------------------------------------------------------------------------------
+// attention weights on request (MultiHeadAttention.call's second result, transformer.py:64-97):
+//   w[b][h][i][j] = exp(q_i . k_j / sqrt(dh) + pad_j * -1e9 - lse[b][h][i])          fp32 [B][H][S][S]
+// 64 x 64 tile per workgroup, q and k rows staged in LDS as fp32.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) attn_weights_kernel(const T *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
+                                                           const float *__restrict__ lse, float *__restrict__ w, int S, int H,
+                                                           int dh, float sqrt_dk) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // q tile [64][dh+1], k tile [64][dh+1]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z / H, h = blockIdx.z % H, dm = H * dh;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int64_t tok0 = (int64_t)b * S;
+    float *sq = sm, *sk = sm + 64 * (dh + 1);
+    for (int e = tid; e < 64 * dh; e += 256) {
+        const int r = e / dh, c = e % dh;
+        sq[r * (dh + 1) + c] = (i0 + r < S) ? (float)qkv[(tok0 + i0 + r) * ld + h * dh + c] : 0.f;
+        sk[r * (dh + 1) + c] = (j0 + r < S) ? (float)qkv[(tok0 + j0 + r) * ld + dm + h * dh + c] : 0.f;
+    }
+    __syncthreads();
+    const int j = tid & 63;
+    for (int i = tid >> 6; i < 64; i += 4) {
+        if (i0 + i >= S || j0 + j >= S) continue;
+        float s = 0.f;
+        for (int c = 0; c < dh; ++c) s += sq[i * (dh + 1) + c] * sk[j * (dh + 1) + c];
+        s /= sqrt_dk;
+        if (key_pad[tok0 + j0 + j]) s += -1e9f;
+        const float L = lse[((int64_t)b * H + h) * S + i0 + i];
+        w[(((int64_t)b * H + h) * S + i0 + i) * S + j0 + j] = expf(s - L);
+    }
+}
+
+extern "C" int b4c_attn_weights(const void *qkv, int ld_qkv, const uint8_t *key_pad, const float *lse, float *weights, int B,
+                                int S, int H, int dh, int dtype, void *stream) {
+    B4C_REQUIRE(qkv && key_pad && lse && weights && B > 0 && S > 0 && H > 0 && dh > 0, "attn_weights: bad argument");
+    B4C_REQUIRE(ld_qkv >= 3 * H * dh, "attn_weights: bad pitch");
+    B4C_REQUIRE((int64_t)B * H <= 65535, "attn_weights: B*H exceeds 65535");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((S + 63) / 64, (S + 63) / 64, B * H);
+    const size_t shm = (size_t)2 * 64 * (dh + 1) * sizeof(float);
+    const float sq = sqrtf((float)dh);
+    if (dtype == B4C_F32) attn_weights_kernel<float><<<grid, 256, shm, st>>>((const float *)qkv, ld_qkv, key_pad, lse, weights, S, H, dh, sq);
+    else if (dtype == B4C_BF16) attn_weights_kernel<bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, lse, weights, S, H, dh, sq);
+    else B4C_REQUIRE(false, "attn_weights: dtype %d", dtype);
+    return b4c_check_launch("attn_weights");
+}
+
+// ------------------------------------------------------------------------------------------
+// dst[n][k] += src[k][n]   (fp32; the tied-weight head's projection gradient [K][V] added into the
+// rows of the embedding-table gradient [V][K]); 32 x 32 LDS tile, both sides coalesced.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) transpose_add_kernel(const float *__restrict__ src, int lds_, float *__restrict__ dst, int ldd,
+                                                            int K, int N) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        tile[r][tx] = (k < K && n < N) ? src[(int64_t)k * lds_ + n] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < K) dst[(int64_t)n * ldd + k] += tile[tx][r];
+    }
+}
+
+extern "C" int b4c_transpose_add(const float *src, int ld_src, float *dst, int ld_dst, int K, int N, void *stream) {
+    B4C_REQUIRE(src && dst && K > 0 && N > 0 && ld_src >= N && ld_dst >= K, "transpose_add: bad argument");
+    dim3 grid((N + 31) / 32, (K + 31) / 32);
+    transpose_add_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, ld_src, dst, ld_dst, K, N);
+    return b4c_check_launch("transpose_add");
+}
+
+// ------------------------------------------------------------------------------------------
+// row-sparse gradient exchange (config 5: a 2 GB embedding gradient of which <= B*S rows are touched):
+//   b4c_rows_gather_f32:      out[r][:] = src[idx[r]][:]                         (idx < 0 -> zeros)
+//   b4c_rows_scatter_add_f32: dst[idx[r]][:] += src[r][:]  with float atomics    (idx < 0 skipped)
+// width % 4 == 0; one thread = 4 columns.
+// ------------------------------------------------------------------------------------------
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) rows_f32_kernel(const float *__restrict__ src, int ld_src, const int64_t *__restrict__ idx,
+                                                       float *__restrict__ dst, int ld_dst, int64_t n, int width) {
+    const int cpr = width >> 2;
+    const int64_t total = n * cpr;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr) << 2;
+        const int64_t j = idx[r];
+        if (SCATTER) {
+            if (j < 0) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * ld_src + c);
+            float *d = dst + j * ld_dst + c;
+            atomicAdd(d, v[0]); atomicAdd(d + 1, v[1]); atomicAdd(d + 2, v[2]); atomicAdd(d + 3, v[3]);
+        } else {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j >= 0) v = *reinterpret_cast<const f32x4 *>(src + j * ld_src + c);
+            *reinterpret_cast<f32x4 *>(dst + r * ld_dst + c) = v;
+        }
+    }
+}
+
+extern "C" int b4c_rows_gather_f32(const float *src, int ld_src, const int64_t *idx, float *out, int ld_out, int64_t n,
+                                   int width, void *stream) {
+    B4C_REQUIRE(src && idx && out && n >= 0 && width > 0 && width % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0, "rows_gather_f32: bad shape");
+    if (n == 0) return B4C_OK;
+    rows_f32_kernel<false><<<ew_grid(n * (width / 4), 256), 256, 0, (hipStream_t)stream>>>(src, ld_src, idx, out, ld_out, n, width);
+    return b4c_check_launch("rows_gather_f32");
+}
+
+extern "C" int b4c_rows_scatter_add_f32(const float *src, int ld_src, const int64_t *idx, float *dst, int ld_dst, int64_t n,
+                                        int width, void *stream) {
+    B4C_REQUIRE(src && idx && dst && n >= 0 && width > 0 && width % 4 == 0 && ld_src % 4 == 0, "rows_scatter_add_f32: bad shape");
+    if (n == 0) return B4C_OK;
+    rows_f32_kernel<true><<<ew_grid(n * (width / 4), 256), 256, 0, (hipStream_t)stream>>>(src, ld_src, idx, dst, ld_dst, n, width);
+    return b4c_check_launch("rows_scatter_add_f32");
+}

@@ -196,18 +196,21 @@ def embed_concat_pe_bwd(ids_list, tables, dout, scale, rate, seed, into=None, or
     return dtabs
 
 
-def gemm_nt(a, bt, n, bias=None, act=L.ACT_NONE, gate=None, residual=None, out_dtype=None):
-    """a: [M, Kp], bt: [>=n, Kp] -> [M, n]"""
+def gemm_nt(a, bt, n, bias=None, act=L.ACT_NONE, gate=None, residual=None, out_dtype=None, out=None):
+    """a: [M, Kp], bt: [>=n, Kp] -> [M, n] (written into `out`, a row-pitched [M, n] view, when given)"""
     M, K = a.shape
     out_dtype = out_dtype or a.dtype
-    out = torch.empty(M, n, dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty(M, n, dtype=out_dtype, device=a.device)
+    elif out.dtype != out_dtype or tuple(out.shape) != (M, n) or out.stride(1) != 1:
+        raise B4CError('gemm_nt: out must be a [%d, %d] %s view with unit column stride' % (M, n, out_dtype))
     if M == 0:
         return out
     es = a.element_size()
     nbytes = M * K * es + n * K * es + M * n * out.element_size() + (M * n * es if gate is not None else 0) + \
         (M * n * es if residual is not None else 0)
     with _record('gemm_nt', nbytes, 2 * M * n * K):
-        L.check(L.lib().b4c_gemm_nt(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), n, M, n, K, _p(bias), act,
+        L.check(L.lib().b4c_gemm_nt(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), out.stride(0), M, n, K, _p(bias), act,
                                     _p(gate), gate.stride(0) if gate is not None else 0,
                                     _p(residual), residual.stride(0) if residual is not None else 0,
                                     dt_code(a.dtype), dt_code(out_dtype), _st()), 'gemm_nt')
@@ -1039,11 +1042,23 @@ class VocabCEFn(torch.autograd.Function):
     def backward(ctx, g):
         h, dh, rowscal, labels_i32 = ctx.saved_tensors
         kernel, bias = ctx.params
-        if not ctx.unit_grad:
+        if not ctx.unit_grad:       # the kernels ran at scale 1/valid in forward: fold the upstream gradient in now
             dh = dh * g.to(dh.dtype)
             rowscal = rowscal.clone()
             rowscal[:, 1:5] *= g.to(torch.float32)      # c, +-a, b, yd are linear in the upstream gradient
         wt, _, b = ctx.pack.get(h.dtype, h.shape[1], False)
+        off = getattr(ctx.pack, 'tied_offset', None)
+        if off is not None:     # tied head: `kernel` is the (rows, K) embedding table; dW [K, V] is added transposed
+            dWt = torch.zeros(h.shape[1], ctx.V, dtype=torch.float32, device=h.device)
+            inplace = _inplace_ok(kernel, bias)
+            db = bias.grad if inplace else torch.zeros(bias.shape, dtype=torch.float32, device=h.device)
+            vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, dWt, db)
+            dtab = kernel.grad if inplace else torch.zeros(kernel.shape, dtype=torch.float32, device=h.device)
+            transpose_add_(dtab[off:off + ctx.V], dWt)
+            if inplace:
+                _ready(bias)        # the table is announced by the embedding backward, which runs last
+                return dh, None, None, None, None, None, None, None
+            return dh, None, None, None, None, None, dtab, db
         if _inplace_ok(kernel, bias):
             vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel.grad, bias.grad)
             _ready(kernel, bias)
@@ -1091,3 +1106,300 @@ class FusedSoftmaxCEFn(torch.autograd.Function):
         if not ctx.unit_grad:
             dlogits = dlogits * g.to(dlogits.dtype)
         return dlogits, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------
+# round 2: the reference's own composition loss(y, model(x)) is differentiable; other heads; MHA in general
+# --------------------------------------------------------------------------------------
+def dropout(x, rate, seed):
+    """keep(seed, e) ? x / (1 - rate) : 0 over the flat element index (its own backward)."""
+    _cuda(x)
+    x = x.contiguous()
+    if x.numel() % 8:
+        raise B4CError('dropout: element count %d must be a multiple of 8' % x.numel())
+    y = torch.empty_like(x)
+    L.check(L.lib().b4c_dropout(_p(x), _p(y), x.numel(), rate, seed, dt_code(x.dtype), _st()), 'dropout')
+    return y
+
+
+class DropoutFn(torch.autograd.Function):
+    """Encoder.call's input dropout (transformer.py:263) for an Encoder used on its own."""
+
+    @staticmethod
+    def forward(ctx, x, rate, seed):
+        ctx.rate, ctx.seed = rate, seed
+        return dropout(x, rate, seed)
+
+    @staticmethod
+    def backward(ctx, g):
+        return dropout(g, ctx.rate, ctx.seed), None, None
+
+
+def softmax_rows_bwd(probs, g, V):
+    R, ld = probs.shape[0], probs.stride(0)
+    dx = torch.empty(R, ld, dtype=probs.dtype, device=probs.device)
+    if R == 0:
+        return dx
+    L.check(L.lib().b4c_softmax_rows_bwd(_p(probs), ld, _p(g), g.stride(0), _p(dx), ld, R, V, dt_code(probs.dtype), _st()),
+            'softmax_rows_bwd')
+    return dx
+
+
+class SoftmaxRowsFn(torch.autograd.Function):
+    """Dense(V, softmax)'s activation on materialised logits [R, ld] (head.py:36) with its Jacobian."""
+
+    @staticmethod
+    def forward(ctx, logits, V):
+        probs = softmax_rows(logits, V)
+        ctx.save_for_backward(probs)
+        ctx.V = V
+        return probs
+
+    @staticmethod
+    def backward(ctx, g):
+        (probs,) = ctx.saved_tensors
+        g = g.to(probs.dtype)
+        if g.stride(1) != 1 or g.stride(0) % 8:
+            g = g.contiguous()
+        return softmax_rows_bwd(probs, g, ctx.V), None
+
+
+class MaskedSparseCEFn(torch.autograd.Function):
+    """MaskedLoss(sparse_categorical_crossentropy)(y_true, y_pred) on PROBABILITIES (losses.py:31-98, main.py:89):
+    mean over non-pad rows of the TF-backend sparse CE; differentiable w.r.t. the probabilities.
+    apply(probs [R, >=V] with 8-aligned row pitch, labels fp32 [R] (-1 = pad), V, variant)"""
+
+    @staticmethod
+    def forward(ctx, probs, labels_f32, V, variant):
+        item, nval = sparse_ce_from_probs(probs, labels_f32, V, variant)
+        ctx.save_for_backward(probs, labels_f32, nval)
+        ctx.V, ctx.variant = V, variant
+        return item.sum() / nval[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        probs, labels_f32, nval = ctx.saved_tensors
+        R, ld = probs.shape[0], probs.stride(0)
+        gscale = (g.to(torch.float32) / nval[0]).reshape(1).contiguous()
+        dp = torch.empty(R, ld, dtype=probs.dtype, device=probs.device)
+        if R:
+            L.check(L.lib().b4c_sparse_ce_from_probs_bwd(_p(probs), ld, _p(labels_f32), _p(gscale), _p(dp), ld, R, ctx.V,
+                                                         ctx.variant, dt_code(probs.dtype), _st()), 'sparse_ce_from_probs_bwd')
+        return dp[:, :probs.shape[1]], None, None, None
+
+
+def sigmoid(x):
+    _cuda(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    L.check(L.lib().b4c_sigmoid_fwd(_p(x), _p(y), x.numel(), dt_code(x.dtype), _st()), 'sigmoid_fwd')
+    return y
+
+
+class SigmoidFn(torch.autograd.Function):
+    """Dense(activation='sigmoid') of BinaryClassificationHead / MultiLabel_MultiClass_classification (head.py:12,59)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = sigmoid(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.to(y.dtype).contiguous()
+        dx = torch.empty_like(y)
+        L.check(L.lib().b4c_sigmoid_bwd(_p(y), _p(g), _p(dx), y.numel(), dt_code(y.dtype), _st()), 'sigmoid_bwd')
+        return dx
+
+
+def masked_bce(probs, labels_f32, pos_weight=None, want_grad=False):
+    """-> (item_loss fp32 [n], sums fp32 [2] = (sum of weighted losses, non-pad count), dprobs fp32 [n] or None)"""
+    _cuda(probs)
+    n = probs.numel()
+    item = torch.empty(n, dtype=torch.float32, device=probs.device)
+    sums = torch.zeros(2, dtype=torch.float32, device=probs.device)
+    dp = torch.empty(n, dtype=torch.float32, device=probs.device) if want_grad else None
+    L.check(L.lib().b4c_masked_bce(_p(probs), _p(labels_f32), float(pos_weight) if pos_weight is not None else 0.0, _p(item),
+                                   _p(sums), _p(dp), n, dt_code(probs.dtype), _st()), 'masked_bce')
+    return item, sums, dp
+
+
+class MaskedBCEFn(torch.autograd.Function):
+    """MaskedLoss(binary_crossentropy, pos_weight)(y_true, y_pred) (losses.py:31-98): weighted mean over non-pad items,
+    divided by (pos_weight + 1) / 2 when a pos_weight is given.  apply(probs (any shape), labels fp32 same count, pos_weight)"""
+
+    @staticmethod
+    def forward(ctx, probs, labels_f32, pos_weight):
+        p = probs.contiguous()
+        _, sums, dp = masked_bce(p, labels_f32, pos_weight, want_grad=True)
+        norm = (float(pos_weight) + 1.0) / 2.0 if pos_weight is not None else 1.0
+        ctx.save_for_backward(dp, sums)
+        ctx.norm, ctx.shape, ctx.dtype = norm, probs.shape, probs.dtype
+        return sums[0] / sums[1] / norm
+
+    @staticmethod
+    def backward(ctx, g):
+        dp, sums = ctx.saved_tensors
+        return (dp * (g.to(torch.float32) / sums[1] / ctx.norm)).to(ctx.dtype).view(ctx.shape), None, None
+
+
+def binary_counts(y_true_f32, y_pred):
+    _cuda(y_pred)
+    out = torch.zeros(6, dtype=torch.float32, device=y_pred.device)
+    yp = y_pred.contiguous()
+    L.check(L.lib().b4c_binary_counts(_p(y_true_f32), _p(yp), _p(out), yp.numel(), dt_code(yp.dtype), _st()), 'binary_counts')
+    return out
+
+
+def compact_labels(labels_padded, counts, offsets, cap, flat_idx=None):
+    """(B, M) fp32 labels padded with -1 -> int32 [cap] in mask order; entries >= R are -1 (and flat_idx[>= R] = -1)."""
+    _cuda(labels_padded)
+    B, M = labels_padded.shape
+    lab = labels_padded.to(torch.float32).contiguous()
+    out = torch.empty(cap, dtype=torch.int32, device=lab.device)
+    L.check(L.lib().b4c_compact_labels(_p(lab), B, M, _p(counts), _p(offsets), _p(out), _p(flat_idx), cap, _st()),
+            'compact_labels')
+    return out
+
+
+def attn_weights(qkv, key_pad, lse, B, S, H, dh):
+    w = torch.empty(B, H, S, S, dtype=torch.float32, device=qkv.device)
+    L.check(L.lib().b4c_attn_weights(_p(qkv), qkv.stride(0), _p(key_pad), _p(lse), _p(w), B, S, H, dh, dt_code(qkv.dtype),
+                                     _st()), 'attn_weights')
+    return w
+
+
+def transpose_add_(dst, src):
+    """dst [N, K] += src [K, N]^T (fp32)."""
+    K, N = src.shape
+    L.check(L.lib().b4c_transpose_add(_p(src), src.stride(0), _p(dst), dst.stride(0), K, N, _st()), 'transpose_add')
+
+
+def rows_gather_f32(src, idx):
+    out = torch.empty(idx.shape[0], src.shape[1], dtype=torch.float32, device=src.device)
+    L.check(L.lib().b4c_rows_gather_f32(_p(src), src.stride(0), _p(idx), _p(out), out.stride(0), idx.shape[0], src.shape[1],
+                                        _st()), 'rows_gather_f32')
+    return out
+
+
+def rows_scatter_add_f32_(dst, idx, src):
+    L.check(L.lib().b4c_rows_scatter_add_f32(_p(src), src.stride(0), _p(idx), _p(dst), dst.stride(0), idx.shape[0],
+                                             src.shape[1], _st()), 'rows_scatter_add_f32')
+
+
+class MHAFn(torch.autograd.Function):
+    """MultiHeadAttention.call(v, k, q, mask) in general (transformer.py:137-160): distinct value / key / query inputs
+    of one padded length S, key-side padding mask, attention weights on request.  Differentiable in the three inputs
+    and all eight parameters.  apply(xq, xk, xv, key_pad, wq, bq, wk, bk, wv, bv, wo, bo, pk_qkv, pk_o, B, S, H, same, want_w)"""
+
+    @staticmethod
+    def forward(ctx, xq, xk, xv, key_pad, wq, bq, wk, bk, wv, bv, wo, bo, pk_qkv, pk_o, B, S, H, same, want_w):
+        T_tok, d = xq.shape
+        dh = d // H
+        wt_qkv, _, b_qkv = pk_qkv.get(xq.dtype, d, True)
+        wt_o, _, b_o = pk_o.get(xq.dtype, d, True)
+        if same:
+            qkv = gemm_nt(xq, wt_qkv, 3 * d, b_qkv)
+        else:
+            qkv = torch.empty(T_tok, 3 * d, dtype=xq.dtype, device=xq.device)
+            for i, x in enumerate((xq, xk, xv)):
+                gemm_nt(x, wt_qkv[i * d:(i + 1) * d], d, b_qkv[i * d:(i + 1) * d], out=qkv[:, i * d:(i + 1) * d])
+        o, lse = attn_fwd(qkv, key_pad, B, S, H, dh)
+        out = gemm_nt(o, wt_o, d, b_o)
+        w = attn_weights(qkv, key_pad, lse, B, S, H, dh) if want_w else None
+        ctx.save_for_backward(xq, xk, xv, key_pad, qkv, o, lse)
+        ctx.pk, ctx.dims, ctx.same = (pk_qkv, pk_o), (B, S, H, dh), same
+        if w is None:
+            w = torch.empty(0, device=xq.device)
+        ctx.mark_non_differentiable(w)
+        return out, w
+
+    @staticmethod
+    def backward(ctx, dout, _):
+        xq, xk, xv, key_pad, qkv, o, lse = ctx.saved_tensors
+        pk_qkv, pk_o = ctx.pk
+        B, S, H, dh = ctx.dims
+        d = H * dh
+        _, wc_o, _ = pk_o.get(xq.dtype, d, True)
+        _, wc_qkv, _ = pk_qkv.get(xq.dtype, d, True)
+        dy = dout.contiguous()
+        dWo, dbo = gemm_tn(o, dy, d, d)
+        d_o = gemm_nt(dy, wc_o, d)
+        dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh)
+        if ctx.same:
+            dW, db = gemm_tn(xq, dqkv, d, 3 * d)
+            (gq, gk, gv), (gbq, gbk, gbv) = pk_qkv.split_grads(dW, db)
+            dx = gemm_nt(dqkv, wc_qkv, d)
+            return (dx, None, None, None, gq, gbq, gk, gbk, gv, gbv, dWo, dbo) + (None,) * 7
+        gw, gb, gx = [], [], []
+        for i, x in enumerate((xq, xk, xv)):
+            g = dqkv[:, i * d:(i + 1) * d]
+            dW, db = gemm_tn(x, g, d, d)
+            gw.append(dW)
+            gb.append(db)
+            gx.append(gemm_nt(g, wc_qkv[:, i * d:(i + 1) * d], d))
+        return (gx[0], gx[1], gx[2], None, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], dWo, dbo) + (None,) * 7
+
+
+class TiedPackedLinear(PackedLinear):
+    """Compute copies of a projection whose weights are rows off .. off+V of an embedding table (rows, K) fp32,
+    vocabulary-major: ``wt`` [Vp][Kp] is a straight copy of those rows, ``wc`` [Kp][Vp] their transpose, ``bias``
+    the head's own fp32 [V].  Re-packed with the dense layers (same batched launch: the table slice is handed to
+    b4c_pack_weights_batched as a "[V][K] kernel" with the two outputs swapped)."""
+
+    def __init__(self, table, off, V, bias):
+        import weakref
+        self.table, self.tied_offset, self.bias_p = table, int(off), bias
+        self.kernels, self.biases = [table], [bias]
+        self.K = int(table.shape[1])
+        self.Ns = [int(V)]
+        self.N = int(V)
+        self.Np = rup8(self.N)
+        self._cache = {}
+        _pack_registry.append(weakref.ref(self))
+
+    def _descs(self, ent, Kp):
+        t = self.table.detach()
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise B4CError('embedding tables must be contiguous float32')
+        rows = t[self.tied_offset:self.tied_offset + self.N]
+        ent['bias'][:self.N].copy_(self.bias_p.detach())
+        # as a Keras kernel [K' = V][N' = K]:  wt'[n'][k'] = src[k'][n'] is our wc [K][V],  wc'[k'][n'] is our wt [V][K]
+        return [L.PackDesc(rows.data_ptr(), None, ent['wc'].data_ptr() if ent['wc'] is not None else None,
+                           ent['wt'].data_ptr(), None, self.N, self.K, self.Np, Kp, 0, 0)]
+
+    def split_grads(self, dW, db):
+        return [dW], [db]
+
+
+class TiedLogitsFn(torch.autograd.Function):
+    """logits [R, Vp] = h . E[off : off + V]^T + bias for the tied-weight head (materialised route)."""
+
+    @staticmethod
+    def forward(ctx, h, table, bias, pack, out_fp32):
+        h = h.contiguous()
+        wt, _, b = pack.get(h.dtype, h.shape[1], True)
+        ctx.save_for_backward(h)
+        ctx.pack, ctx.params = pack, (table, bias)
+        return gemm_nt(h, wt, pack.Np, b, out_dtype=torch.float32 if out_fp32 else None)
+
+    @staticmethod
+    def backward(ctx, g):
+        (h,) = ctx.saved_tensors
+        pack = ctx.pack
+        table, bias = ctx.params
+        g = g.to(h.dtype).contiguous()
+        _, wc, _ = pack.get(h.dtype, h.shape[1], True)
+        dWt, db = gemm_tn(h, g, pack.K, pack.N)                 # [K, V] fp32, [V]
+        dh = gemm_nt(g, wc, h.shape[1])
+        off = pack.tied_offset
+        if _inplace_ok(table, bias):
+            transpose_add_(table.grad[off:off + pack.N], dWt)
+            bias.grad += db
+            _ready(bias)
+            return dh, None, None, None, None
+        dtab = torch.zeros(table.shape, dtype=torch.float32, device=h.device)
+        transpose_add_(dtab[off:off + pack.N], dWt)
+        return dh, dtab, db, None, None

@@ -261,6 +261,65 @@ int b4c_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float
  * returns 1 if element e is kept under (seed, rate). */
 int b4c_keep(uint64_t seed, uint64_t e, float rate);
 
+/* ==== round-2 additions (ABI version 3) ================================================== */
+
+/* ---- stand-alone dropout: Encoder.call's input dropout (transformer.py:263) when the Encoder is used
+ * without the embedding stage that normally fuses it.  y[e] = keep(seed, e) ? x[e] / (1 - rate) : 0, e = flat
+ * element index; applied to a gradient it is its own backward.  n % 8 == 0. */
+int b4c_dropout(const void *x, void *y, int64_t n, float rate, uint64_t seed, int dtype, void *stream);
+
+/* ---- backward of the materialised-probability route: the reference trains through
+ * loss(y, model(x)) with model(x) = (B, M, V) probabilities (main.py:159-165, head.py:36-47, losses.py:31-98).
+ * softmax:  dlogits_j = p_j (g_j - sum_i g_i p_i); pad columns V..ldx of dlogits are written 0.
+ * sparse CE on probabilities (b4c_sparse_ce_from_probs): dprobs = gscale[0] * d item_loss / d probs for rows
+ * whose label is not the pad (-1), 0 for pad rows; gscale is a DEVICE scalar (upstream gradient / n_valid). */
+int b4c_softmax_rows_bwd(const void *probs, int ldp, const void *dprobs, int ldg, void *dlogits, int ldx,
+                         int64_t R, int V, int dtype, void *stream);
+int b4c_sparse_ce_from_probs_bwd(const void *probs, int ld, const float *labels, const float *gscale, void *dprobs,
+                                 int ld_dp, int64_t R, int V, int variant, int dtype, void *stream);
+
+/* ---- the other heads (head.py:4-26, 50-69): Dense(activation='sigmoid') and its backward
+ * (dx = dy * y * (1 - y), y = the forward's output).  n % 8 == 0. */
+int b4c_sigmoid_fwd(const void *x, void *y, int64_t n, int dtype, void *stream);
+int b4c_sigmoid_bwd(const void *y, const void *dy, void *dx, int64_t n, int dtype, void *stream);
+
+/* MaskedLoss with tf.keras.backend.binary_crossentropy on probabilities and the optional pos_weight
+ * (losses.py:31-98): o = clip(p, 1e-7, 1 - 1e-7); bce = -(t log(o + 1e-7) + (1 - t) log(1 - o + 1e-7));
+ * weight = pos_weight where t == 1 (pos_weight <= 0: none).  labels fp32, -1 = pad (loss 0, not counted).
+ * sums[0] += sum of weighted item losses, sums[1] += number of non-pad items (caller zeroes);
+ * item_loss [n] and dprobs [n] (fp32, = weight * d bce / d p, unscaled) may be NULL. */
+int b4c_masked_bce(const void *probs, const float *labels, float pos_weight, float *item_loss, float *sums,
+                   float *dprobs, int64_t n, int dtype, void *stream);
+
+/* counts behind PositiveRate, PredictedPositives and F1Score (metrics.py:5-87) in one pass; out6 += :
+ * [0] sum mask*y_true  [1] sum mask  [2] sum mask*round(y_pred)  [3] tp  [4] condition_true  [5] predicted_true
+ * (mask = y_true != -1; tf.round = half to even; the F1 counts are not masked, as in the reference). */
+int b4c_binary_counts(const float *y_true, const void *y_pred, float *out6, int64_t n, int dtype, void *stream);
+
+/* ---- labels of the sync-free Cloze step: padded (B, M) fp32 labels (-1 pad; row b's labels are its first
+ * counts[b] entries, input_pipeline.py:198-214) -> compact int32 [cap] in the row-major order of
+ * b4c_mask_positions; entries at and beyond R = offsets[B] are set to -1 in `out` (ignored rows) and, when
+ * flat_idx is given, to -1 there too (b4c_gather_rows then yields zero rows). */
+int b4c_compact_labels(const float *labels, int B, int M, const int32_t *counts, const int32_t *offsets,
+                       int32_t *out, int32_t *flat_idx, int32_t cap, void *stream);
+
+/* ---- attention weights on request: the second result of MultiHeadAttention.call /
+ * scaled_dot_product_attention (transformer.py:64-97, 137-160), which the encoder discards (:203).
+ * weights fp32 [B][H][S][S] = exp(q k^T / sqrt(dh) + pad * -1e9 - lse). */
+int b4c_attn_weights(const void *qkv, int ld_qkv, const uint8_t *key_pad, const float *lse, float *weights, int B,
+                     int S, int H, int dh, int dtype, void *stream);
+
+/* ---- tied-weight head (north-star extension, no reference counterpart): dst[n][k] += src[k][n], fp32 --
+ * the projection gradient [K][V] added into rows of the embedding-table gradient [V][K]. */
+int b4c_transpose_add(const float *src, int ld_src, float *dst, int ld_dst, int K, int N, void *stream);
+
+/* ---- row-sparse gradient exchange: gather the touched rows of an fp32 gradient table
+ * (idx int64, < 0 -> zero row) and add received rows back (float atomics; idx < 0 skipped).  width % 4 == 0. */
+int b4c_rows_gather_f32(const float *src, int ld_src, const int64_t *idx, float *out, int ld_out, int64_t n,
+                        int width, void *stream);
+int b4c_rows_scatter_add_f32(const float *src, int ld_src, const int64_t *idx, float *dst, int ld_dst, int64_t n,
+                             int width, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

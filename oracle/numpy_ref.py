@@ -267,6 +267,23 @@ def transformer_forward(ids_by_feature, params, num_layers, num_heads, dtype=np.
     return outs if return_all else x
 
 
+def multi_head_attention_general(v_in, k_in, q_in, p, num_heads, mask):
+    """transformer.py:137-160 as written: call(v, k, q, mask) with three inputs; q_in (B, Sq, d), k_in / v_in
+    (B, Sk, d); mask broadcastable to (B, H, Sq, Sk).  Returns (output (B, Sq, d), attention_weights (B, H, Sq, Sk))."""
+    B, Sq, d = q_in.shape
+    Sk = k_in.shape[1]
+    depth = d // num_heads
+
+    def split(t, S):
+        return t.reshape(B, S, num_heads, depth).transpose(0, 2, 1, 3)
+    q = split(dense(q_in, p['wq.kernel'], p['wq.bias']), Sq)
+    k = split(dense(k_in, p['wk.kernel'], p['wk.bias']), Sk)
+    v = split(dense(v_in, p['wv.kernel'], p['wv.bias']), Sk)
+    o, w = scaled_dot_product_attention(q, k, v, mask)
+    o = o.transpose(0, 2, 1, 3).reshape(B, Sq, d)
+    return dense(o, p['dense.kernel'], p['dense.bias']), w
+
+
 # ----------------------------------------------------------------------------
 # R11  [MASK]-position gather  (clickstream_transformer.py:260-297)
 # ----------------------------------------------------------------------------
@@ -300,6 +317,38 @@ def softmax_head(x, params, n_hidden, return_logits=False):
     for i in range(n_hidden):
         x = dense(x, params['intermediate_layers.%d.kernel' % i], params['intermediate_layers.%d.bias' % i], 'relu')
     logits = dense(x, params['output_layer.kernel'], params['output_layer.bias'])
+    probs = softmax(logits, axis=-1)
+    return (probs, logits) if return_logits else probs
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def binary_classification_head(x, params, n_hidden):
+    """head.py:4-26: relu(Dense) x n, Dense(1, sigmoid), squeeze(-1): (B, L, d) -> (B, L)."""
+    for i in range(n_hidden):
+        x = dense(x, params['intermediate_layers.%d.kernel' % i], params['intermediate_layers.%d.bias' % i], 'relu')
+    return sigmoid(dense(x, params['output_layer.kernel'], params['output_layer.bias']))[..., 0]
+
+
+def multilabel_multiclass_head(x, params, n_hidden):
+    """head.py:50-69: relu(Dense) x n, Dense(V, sigmoid), squeeze(axis=1): (B, 1, d) -> (B, V)."""
+    for i in range(n_hidden):
+        x = dense(x, params['intermediate_layers.%d.kernel' % i], params['intermediate_layers.%d.bias' % i], 'relu')
+    p = sigmoid(dense(x, params['output_layer.kernel'], params['output_layer.bias']))
+    assert p.shape[1] == 1
+    return p[:, 0]
+
+
+def tied_item_head(x, params, n_hidden, table, id_offset=10, out_vocab=None, return_logits=False):
+    """Tied-weight masked-item head (north_star extension; NO reference counterpart):
+    relu(Dense) x n_hidden, logits = h . E[offset : offset + V]^T + output_bias, softmax."""
+    for i in range(n_hidden):
+        x = dense(x, params['intermediate_layers.%d.kernel' % i], params['intermediate_layers.%d.bias' % i], 'relu')
+    V = out_vocab if out_vocab is not None else table.shape[0] - id_offset - 1
+    W = np.asarray(table, dtype=x.dtype)[id_offset:id_offset + V]
+    logits = x @ W.T + params['output_bias']
     probs = softmax(logits, axis=-1)
     return (probs, logits) if return_logits else probs
 
@@ -350,6 +399,48 @@ def masked_loss(y_true, y_pred, item_wise_loss_fn=sparse_categorical_crossentrop
     item = item_wise_loss_fn(yt, y_pred).reshape(y_true.shape)
     item = item * mask
     return dt(np.sum(item) / np.sum(mask))
+
+
+def binary_crossentropy(y_true, y_pred):
+    """tf.keras.backend.binary_crossentropy(from_logits=False), TF 2.3.1 keras/backend.py (restated from the published
+    source; unpinned): output = clip(output, eps, 1 - eps); -(t log(output + eps) + (1 - t) log(1 - output + eps))."""
+    dt = y_pred.dtype.type
+    eps = dt(KERAS_EPSILON)
+    o = np.clip(y_pred, eps, dt(1.0) - eps)
+    t = np.asarray(y_true, dtype=y_pred.dtype)
+    return -(t * np.log(o + eps) + (1 - t) * np.log(1 - o + eps))
+
+
+def masked_loss_weighted(y_true, y_pred, item_wise_loss_fn=binary_crossentropy, pos_weight=None, label_pad=LABEL_PAD):
+    """losses.py:31-98 including the pos_weight branch (:71-73, :93-96): item losses at y_true == 1 are multiplied by
+    pos_weight, the masked mean is divided by (pos_weight + 1) / 2."""
+    y_true = np.asarray(y_true)
+    dt = y_pred.dtype.type
+    if y_true.size == 0:
+        return dt(0.0)
+    mask = (y_true != np.asarray(label_pad, dtype=y_true.dtype)).astype(y_pred.dtype)
+    yt = y_true - (1 - mask.astype(y_true.dtype)) * np.asarray(label_pad, dtype=y_true.dtype)
+    item = item_wise_loss_fn(yt, y_pred).reshape(y_true.shape) * mask
+    if pos_weight is not None:
+        item = np.where(yt == 1, dt(pos_weight), dt(1.0)) * item
+    out = np.sum(item) / np.sum(mask)
+    if pos_weight is not None:
+        out = out / ((dt(pos_weight) + dt(1.0)) / 2)
+    return dt(out)
+
+
+def binary_metrics(y_true, y_pred, label_pad=LABEL_PAD):
+    """metrics.py:5-87: PositiveRate, PredictedPositives (both masked by y_true != pad), F1Score (not masked; tf.round
+    = half to even; casts to int32 before comparing with 1)."""
+    yt = np.asarray(y_true, dtype=np.float64).reshape(-1)
+    yp = np.asarray(y_pred, dtype=np.float64).reshape(-1)
+    mask = (yt != label_pad).astype(np.float64)
+    r = np.round(yp)            # numpy rounds half to even, like tf.round
+    tp = np.sum((yt.astype(np.int32) == 1) & (r.astype(np.int32) == 1))
+    ct = np.sum(yt.astype(np.int32) == 1)
+    pt = np.sum(r.astype(np.int32) == 1)
+    return {'positive_rate': np.sum(yt * mask) / np.sum(mask), 'pred_positives': np.sum(r * mask) / np.sum(mask),
+            'f1': 2.0 * tp / (ct + pt)}
 
 
 def cloze_masked_loss(y_true, y_pred, variant='tf'):

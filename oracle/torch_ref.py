@@ -115,3 +115,66 @@ def adam_step(p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-9):
     v.mul_(b2).addcmul_(g, g, value=1 - b2)
     lr_t = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
     p.sub_(lr_t * m / (v.sqrt() + eps))
+
+
+# ---- round 2: restatements of the reference's other heads / losses and of the general MHA call (differentiable) ----
+def mha_general(v_in, k_in, q_in, P, num_heads, key_pad=None):
+    """transformer.py:137-160: call(v, k, q, mask) with a key-side padding mask (B, Sk) of 0 / 1.
+    P: 'wq.kernel', 'wq.bias', ... 'dense.kernel', 'dense.bias'.  -> (out (B, Sq, d), weights (B, H, Sq, Sk))"""
+    B, Sq, d = q_in.shape
+    Sk = k_in.shape[1]
+    depth = d // num_heads
+
+    def split(t, S):
+        return t.reshape(B, S, num_heads, depth).permute(0, 2, 1, 3)
+    q = split(q_in @ P['wq.kernel'] + P['wq.bias'], Sq)
+    k = split(k_in @ P['wk.kernel'] + P['wk.bias'], Sk)
+    v = split(v_in @ P['wv.kernel'] + P['wv.bias'], Sk)
+    logits = q @ k.transpose(-1, -2) / float(np.sqrt(np.float32(depth)))
+    if key_pad is not None:
+        logits = logits + key_pad.to(logits.dtype)[:, None, None, :] * -1e9
+    w = torch.softmax(logits, dim=-1)
+    o = (w @ v).permute(0, 2, 1, 3).reshape(B, Sq, d)
+    return o @ P['dense.kernel'] + P['dense.bias'], w
+
+
+def dense_stack(x, P, n_hidden):
+    for i in range(n_hidden):
+        x = torch.relu(x @ P['intermediate_layers.%d.kernel' % i] + P['intermediate_layers.%d.bias' % i])
+    return x
+
+
+def binary_head(x, P, n_hidden):
+    """head.py:4-26 -> (B, L) probabilities."""
+    return torch.sigmoid(dense_stack(x, P, n_hidden) @ P['output_layer.kernel'] + P['output_layer.bias'])[..., 0]
+
+
+def multilabel_head(x, P, n_hidden):
+    """head.py:50-69 -> (B, V) probabilities (axis 1 must have length 1)."""
+    return torch.sigmoid(dense_stack(x, P, n_hidden) @ P['output_layer.kernel'] + P['output_layer.bias'])[:, 0]
+
+
+def binary_ce_tf(y_true, y_pred):
+    """TF 2.3.1 backend binary_crossentropy on probabilities (see numpy_ref.binary_crossentropy)."""
+    eps = nr.KERAS_EPSILON
+    o = torch.clamp(y_pred, eps, 1.0 - eps)
+    return -(y_true * torch.log(o + eps) + (1 - y_true) * torch.log(1 - o + eps))
+
+
+def masked_loss(y_true, y_pred, item_fn, pos_weight=None):
+    """losses.py:31-98 with the pos_weight branch."""
+    mask = (y_true != nr.LABEL_PAD).to(y_pred.dtype)
+    yt = y_true - (1 - mask) * nr.LABEL_PAD
+    item = item_fn(yt, y_pred).reshape(y_true.shape) * mask
+    if pos_weight is not None:
+        item = torch.where(yt == 1, torch.full_like(item, pos_weight), torch.ones_like(item)) * item
+    out = item.sum() / mask.sum()
+    if pos_weight is not None:
+        out = out / ((pos_weight + 1.0) / 2)
+    return out
+
+
+def tied_head_logits(x, P, n_hidden, table, id_offset, V):
+    """Tied-weight head (extension, no reference counterpart): h . E[off : off + V]^T + output_bias."""
+    h = dense_stack(x, P, n_hidden)
+    return h @ table[id_offset:id_offset + V].t() + P['output_bias']

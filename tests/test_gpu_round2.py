@@ -1,0 +1,507 @@
+"""Round-2 GPU parity tests: the reference's own training composition loss(y, model(x)).backward(), upstream-gradient
+scaling of the fused losses, MultiHeadAttention.call(v, k, q, mask) in general + attention weights, stand-alone Encoder
+dropout, the other heads / losses / metrics (head.py:4-26,50-69; losses.py:71-96; metrics.py:5-107), the tied-weight
+head (extension, no reference oracle), label compaction for the sync-free step, checkpoint layout re-mapping."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import numpy_ref as nr  # noqa: E402
+from oracle import torch_ref as tr  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs the MI355X')
+    return torch.device('cuda')
+
+
+def _model(V=61, d=32, L=2, H=2, head_dims=(24, 16), dropout=0.0, dtype=torch.float32, seed=7, head=None, features=None):
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    torch.manual_seed(seed)
+    head = head if head is not None else SoftMaxHead(list(head_dims), V)
+    model = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': d}, head,
+                                   value_to_head='[MASK]', num_encoder_layers=L, num_attention_heads=H, dropout_rate=dropout,
+                                   compute_dtype=dtype)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('bias') or n.endswith('beta'):
+                p.normal_(0, 0.05)
+    return model.cuda()
+
+
+def _batch(B, S, V, seed):
+    from bert4clickpath_amd import input_pipeline
+    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=seed, min_len=4)
+    ids = torch.from_numpy(b['ids'])
+    return b, ids[:, 2:S - 1].contiguous().cuda(), torch.from_numpy(b['labels_padded']).cuda()
+
+
+def _grads(model):
+    return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the reference's training route: ClozeMaskedLoss(sparse_categorical_crossentropy)(y, model(x)).backward()
+# (main.py:159-165, 277; head.py:36-47; losses.py:31-98) must train and agree with the fused cloze_loss
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('V', [61, 64])
+def test_reference_composition_backward_matches_fused_loss_and_oracle(gpu, V):
+    from bert4clickpath_amd.clickstream_transformer.losses import sparse_categorical_crossentropy
+    from bert4clickpath_amd.cloze import ClozeMaskedLoss
+    model = _model(V=V)
+    b, items, labels = _batch(5, 17, V, seed=11)
+    loss_fn = ClozeMaskedLoss(sparse_categorical_crossentropy)
+    probs = model({'asin': items}, training=True)             # (B, M, V) probabilities, on the tape
+    loss = loss_fn(labels, probs)
+    loss.backward()
+    g_ref_route = _grads(model)
+    model.zero_grad()
+    fused = model.cloze_loss({'asin': items}, labels, training=True)
+    fused.backward()
+    g_fused = _grads(model)
+    assert abs(float(loss) - float(fused)) < 1e-5
+    # fp64 oracle of the same composition
+    P = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in model.state_dict().items() if 'pos_encoding' not in k}
+    ref_loss, _ = tr.model_loss(torch.from_numpy(b['ids']), torch.from_numpy(b['labels']).long(), P, 2, 2, 2)
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    assert set(g_ref_route) == set(g_fused)
+    for n in g_fused:
+        gr = P[n].grad
+        scale = float(gr.abs().max())
+        if scale < 1e-9:
+            continue
+        e1 = float((g_ref_route[n].cpu().double() - gr).abs().max()) / scale
+        e2 = float((g_fused[n].cpu().double() - gr).abs().max()) / scale
+        assert e1 < 2e-4 and e2 < 2e-4, (n, e1, e2)
+
+
+def test_materialised_route_clip_branch_gradients(gpu):
+    """probabilities below TF's clip bound 1e-7 (both MaskedLoss backward branches) against the fp64 oracle."""
+    from bert4clickpath_amd.clickstream_transformer.losses import MaskedLoss, sparse_categorical_crossentropy, \
+        sparse_categorical_crossentropy_plain
+    torch.manual_seed(3)
+    R, V = 9, 45
+    logits = torch.randn(R, V, dtype=torch.float64) * 9.0        # spread: many probabilities < 1e-7
+    labels = torch.randint(0, V, (R,)).double()
+    labels[2] = -1.0
+    logits[4, int(labels[4])] = 40.0                              # label probability above 1 - 1e-7
+    for fn, variant in ((sparse_categorical_crossentropy, 'tf'), (sparse_categorical_crossentropy_plain, 'plain')):
+        lg = logits.clone().float().cuda().requires_grad_(True)
+        probs = torch.softmax(lg, dim=-1)                         # torch softmax here: the loss backward is under test
+        loss = MaskedLoss(fn)(labels.float().cuda(), probs)
+        (3.0 * loss).backward()
+        lr = logits.clone().requires_grad_(True)
+        pr = torch.softmax(lr, dim=-1)
+        keep = labels >= 0
+        if variant == 'tf':
+            item = tr.sparse_ce_tf(pr[keep], labels[keep].long())
+        else:
+            item = -torch.log(pr[keep].gather(1, labels[keep].long()[:, None])[:, 0])
+        ref = item.sum() / keep.sum()
+        (3.0 * ref).backward()
+        assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+        err = float((lg.grad.cpu().double() - lr.grad).abs().max()) / float(lr.grad.abs().max())
+        assert err < 1e-4, (variant, err)
+
+
+def test_softmax_rows_backward_kernel(gpu):
+    from bert4clickpath_amd import ops
+    torch.manual_seed(5)
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+        R, V = 7, 93
+        ld = ops.rup8(V)
+        lg = torch.zeros(R, ld, device='cuda', dtype=dtype)
+        lg[:, :V] = torch.randn(R, V, device='cuda').to(dtype)
+        x = lg.clone().requires_grad_(True)
+        p = ops.SoftmaxRowsFn.apply(x, V)
+        w = torch.randn(R, ld, device='cuda').to(dtype)
+        (p[:, :V].float() * w[:, :V].float()).sum().backward()
+        xr = lg[:, :V].double().cpu().requires_grad_(True)
+        (torch.softmax(xr, -1) * w[:, :V].double().cpu()).sum().backward()
+        assert float((x.grad[:, :V].double().cpu() - xr.grad).abs().max()) < tol
+        assert float(x.grad[:, V:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_upstream_gradient_scales_fused_losses(gpu, dtype):
+    """(0.5 * loss).backward() gives exactly half the gradient on the VocabCE and the FusedSoftmaxCE routes
+    (unit_grad used to ignore the upstream gradient by default)."""
+    from bert4clickpath_amd import ops
+    V = 200
+    # head ends 64-wide so that bf16 takes the logits-free route
+    model = _model(V=V, d=32, head_dims=(48, 64), dtype=dtype)
+    b, items, labels = _batch(6, 21, V, seed=4)
+    outs = []
+    for mul in (1.0, 0.5):
+        model.zero_grad()
+        loss = model.cloze_loss({'asin': items}, labels, training=True)
+        (mul * loss).backward()
+        outs.append(_grads(model))
+    for n in outs[0]:
+        a, h = outs[0][n].float(), outs[1][n].float()
+        tol = 0.0 if dtype == torch.float32 else 1e-2 * float(a.abs().max()) + 1e-12
+        assert float((0.5 * a - h).abs().max()) <= tol + 1e-7 * float(a.abs().max()), n
+    if dtype == torch.bfloat16:
+        assert ops.vocab_ce_supported(torch.empty(1, 64, dtype=dtype, device='cuda'), 64)
+        prev = ops.flash_ce
+        ops.flash_ce = False                                   # the materialised-logits route
+        try:
+            outs2 = []
+            for mul in (1.0, 0.5):
+                model.zero_grad()
+                (mul * model.cloze_loss({'asin': items}, labels, training=True)).backward()
+                outs2.append(_grads(model))
+        finally:
+            ops.flash_ce = prev
+        for n in outs2[0]:
+            a, h = outs2[0][n].float(), outs2[1][n].float()
+            assert float((0.5 * a - h).abs().max()) <= 1e-2 * float(a.abs().max()) + 1e-12, n
+
+
+# ------------------------------------------------------------------------------------------------------------
+# MultiHeadAttention.call(v, k, q, mask) -> (output, attention_weights)   (transformer.py:137-160)
+# ------------------------------------------------------------------------------------------------------------
+def _mha_params(mha):
+    return {n: p.detach().cpu().double().clone().requires_grad_(True) for n, p in mha.named_parameters()}
+
+
+@pytest.mark.parametrize('Sq,Sk', [(13, 13), (9, 21), (21, 9)])
+def test_mha_distinct_inputs_weights_and_gradients(gpu, Sq, Sk):
+    from bert4clickpath_amd.clickstream_transformer.transformer import MultiHeadAttention
+    torch.manual_seed(Sq * 31 + Sk)
+    B, d, H = 3, 32, 2
+    mha = MultiHeadAttention(d, H).cuda()
+    with torch.no_grad():
+        for p in mha.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    q = torch.randn(B, Sq, d, device='cuda', requires_grad=True)
+    k = torch.randn(B, Sk, d, device='cuda', requires_grad=True)
+    v = torch.randn(B, Sk, d, device='cuda', requires_grad=True)
+    pad = torch.zeros(B, Sk)
+    pad[0, Sk - 3:] = 1
+    pad[2, 1] = 1
+    mask = pad[:, None, None, :].cuda()                       # the reference's (B,1,1,Sk) float mask
+    out, w = mha(v, k, q, mask, return_weights=True)
+    assert out.shape == (B, Sq, d) and w.shape == (B, H, Sq, Sk)
+    wgt = torch.randn(B, Sq, d, device='cuda')
+    (out * wgt).sum().backward()
+    P = _mha_params(mha)
+    qr, kr, vr = (t.detach().cpu().double().requires_grad_(True) for t in (q, k, v))
+    ro, rw = tr.mha_general(vr, kr, qr, P, H, pad.double())
+    (ro * wgt.cpu().double()).sum().backward()
+    assert float((out.detach().cpu().double() - ro).abs().max()) < 1e-4
+    assert float((w.cpu().double() - rw).abs().max()) < 1e-6
+    # numpy restatement of the reference lines agrees too
+    no, nw = nr.multi_head_attention_general(vr.detach().numpy(), kr.detach().numpy(), qr.detach().numpy(),
+                                             {n: t.detach().numpy() for n, t in P.items()}, H, pad.double().numpy()[:, None, None, :])
+    assert float(np.abs(no - ro.detach().numpy()).max()) < 1e-9 and float(np.abs(nw - rw.detach().numpy()).max()) < 1e-9
+    for got, ref, name in ((q.grad, qr.grad, 'dq'), (k.grad, kr.grad, 'dk'), (v.grad, vr.grad, 'dv')):
+        assert float((got.cpu().double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), name
+    for n, p in mha.named_parameters():
+        ref = P[n].grad
+        if float(ref.abs().max()) < 1e-9:
+            continue
+        assert float((p.grad.cpu().double() - ref).abs().max()) < 2e-4 * float(ref.abs().max()), n
+    # default call: weights are not materialised
+    out2, w2 = mha(v, k, q, mask)
+    assert w2 is None and torch.equal(out2, out)
+
+
+def test_mha_self_attention_and_free_function(gpu):
+    from bert4clickpath_amd.clickstream_transformer.transformer import MultiHeadAttention, scaled_dot_product_attention
+    torch.manual_seed(2)
+    B, S, d, H = 2, 11, 32, 2
+    mha = MultiHeadAttention(d, H).cuda()
+    x = torch.randn(B, S, d, device='cuda', requires_grad=True)
+    out, w = mha(x, x, x, None, return_weights=True)
+    out.sum().backward()
+    P = _mha_params(mha)
+    xr = x.detach().cpu().double().requires_grad_(True)
+    ro, rw = tr.mha_general(xr, xr, xr, P, H, None)
+    ro.sum().backward()
+    assert float((out.detach().cpu().double() - ro).abs().max()) < 1e-4
+    assert float((x.grad.cpu().double() - xr.grad).abs().max()) < 2e-4 * float(xr.grad.abs().max())
+    assert float((w.sum(-1) - 1).abs().max()) < 1e-5
+    q = torch.randn(B, H, 7, 16, device='cuda')
+    k = torch.randn(B, H, 12, 16, device='cuda')
+    v = torch.randn(B, H, 12, 16, device='cuda')
+    o, ww = scaled_dot_product_attention(q, k, v, None, return_weights=True)
+    ro, rw = nr.scaled_dot_product_attention(q.cpu().double().numpy(), k.cpu().double().numpy(), v.cpu().double().numpy())
+    assert float(np.abs(o.cpu().numpy() - ro).max()) < 1e-5 and float(np.abs(ww.cpu().numpy() - rw).max()) < 1e-6
+    assert scaled_dot_product_attention(q, k, v)[1] is None
+
+
+def test_encoder_standalone_applies_input_dropout(gpu):
+    """Encoder.call's own input dropout (transformer.py:263) when the Encoder is used without the embedding stage."""
+    from bert4clickpath_amd import ops
+    from bert4clickpath_amd.clickstream_transformer import transformer as T
+    torch.manual_seed(1)
+    B, S, d, rate = 3, 10, 32, 0.25
+    enc = T.Encoder(1, d, 2, 100, rate).cuda()
+    x = torch.randn(B, S, d, device='cuda', requires_grad=True)
+    T.set_dropout_seed(77)
+    seed0 = T._SeedStream(77).next()
+    y = ops.DropoutFn.apply(x, rate, seed0)
+    keep = torch.from_numpy(ops.keep_mask(seed0, B * S * d, rate)).view(B, S, d).cuda()
+    assert torch.allclose(y, torch.where(keep, x / (1 - rate), torch.zeros_like(x)), rtol=1e-6, atol=0)
+    assert 0.6 < float(keep.float().mean()) < 0.9
+    y.sum().backward()
+    assert torch.allclose(x.grad, keep.float() / (1 - rate), rtol=1e-6)
+    out = enc(x, training=True, mask=None)                    # used to raise NotImplementedError
+    assert out.shape == (B, S, d) and torch.isfinite(out).all()
+    out_eval = enc(x, training=False, mask=None)
+    assert not torch.equal(out, out_eval)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the other heads, MaskedLoss(binary_crossentropy, pos_weight), metrics.py
+# ------------------------------------------------------------------------------------------------------------
+def _head_params(head):
+    return {n: p.detach().cpu().double().clone().requires_grad_(True) for n, p in head.named_parameters()}
+
+
+@pytest.mark.parametrize('pos_weight', [None, 3.0])
+def test_binary_head_masked_bce_and_gradients(gpu, pos_weight):
+    from bert4clickpath_amd.clickstream_transformer import BinaryClassificationHead, MaskedLoss, binary_crossentropy
+    torch.manual_seed(13)
+    B, Lq, d = 4, 6, 32
+    head = BinaryClassificationHead([24, 16], input_dim=d).cuda()
+    with torch.no_grad():
+        head.output_layer.bias.fill_(0.3)
+    x = torch.randn(B, Lq, d, device='cuda', requires_grad=True)
+    y = torch.randint(0, 2, (B, Lq)).float()
+    y[1, 3:] = -1.0
+    y[3, 5] = -1.0
+    probs = head(x)
+    assert probs.shape == (B, Lq)
+    loss = MaskedLoss(binary_crossentropy, pos_weight=pos_weight)(y.cuda(), probs)
+    (2.0 * loss).backward()
+    P = _head_params(head)
+    xr = x.detach().cpu().double().requires_grad_(True)
+    pr = tr.binary_head(xr, P, 2)
+    ref = tr.masked_loss(y.double(), pr, tr.binary_ce_tf, pos_weight)
+    (2.0 * ref).backward()
+    assert float((probs.detach().cpu().double() - pr).abs().max()) < 1e-6
+    assert abs(float(loss) - float(ref)) < 1e-6
+    npv = nr.masked_loss_weighted(y.double().numpy(), pr.detach().numpy(), nr.binary_crossentropy, pos_weight)
+    assert abs(float(npv) - float(ref)) < 1e-12
+    assert float((x.grad.cpu().double() - xr.grad).abs().max()) < 2e-4 * float(xr.grad.abs().max())
+    for n, p in head.named_parameters():
+        assert float((p.grad.cpu().double() - P[n].grad).abs().max()) < 2e-4 * float(P[n].grad.abs().max()) + 1e-12, n
+
+
+def test_binary_ce_clip_range_and_empty_batch(gpu):
+    from bert4clickpath_amd.clickstream_transformer import MaskedLoss, binary_crossentropy
+    p = torch.tensor([0.0, 1.0, 5e-8, 1 - 5e-8, 0.3, 0.9, 0.5, 0.2], device='cuda', requires_grad=True)
+    y = torch.tensor([1.0, 0.0, 0.0, 1.0, 1.0, 0.0, -1.0, 1.0], device='cuda')
+    loss = MaskedLoss(binary_crossentropy)(y, p)
+    loss.backward()
+    # fp32 restatement: at the clip bounds the fp32 arithmetic itself (1 - 1e-7 rounds to 1 - 1.19e-7) decides the value,
+    # as it does in the reference, which runs this loss in fp32
+    pr = p.detach().cpu().requires_grad_(True)
+    ref = tr.masked_loss(y.cpu(), pr, tr.binary_ce_tf)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * float(ref)
+    # inside the clip range the gradients agree; at / beyond the bounds TF's clip passes the boundary value only
+    inside = (pr.detach() > 1e-7) & (pr.detach() < 1 - 1e-7)
+    assert float((p.grad.cpu() - pr.grad)[inside].abs().max()) < 1e-5 * float(pr.grad[inside].abs().max())
+    assert float(p.grad[6]) == 0.0
+    assert float(MaskedLoss(binary_crossentropy)(torch.zeros(0, device='cuda'), torch.zeros(0, device='cuda'))) == 0.0
+    with pytest.raises(ValueError):
+        from bert4clickpath_amd.clickstream_transformer.losses import sparse_categorical_crossentropy
+        MaskedLoss(sparse_categorical_crossentropy, pos_weight=2.0)
+
+
+def test_multilabel_head_on_cls_segment(gpu):
+    """MultiLabel_MultiClass_classification on the [CLS] segment (segment_to_head=0): (B, 1, d) -> (B, V) sigmoid
+    probabilities (head.py:50-69) and the multi-hot masked BCE, against the fp64 restatement."""
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, MaskedLoss, \
+        MultiLabel_MultiClass_classification, binary_crossentropy
+    torch.manual_seed(21)
+    V, d, NL = 50, 32, 12
+    head = MultiLabel_MultiClass_classification([16], NL)
+    model = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': d}, head,
+                                   segment_to_head=0, num_encoder_layers=1, num_attention_heads=2, dropout_rate=0.0).cuda()
+    items = torch.randint(10, 10 + V, (5, 9), device='cuda')
+    items[2, 6:] = 0
+    probs = model({'asin': items}, training=True)
+    assert probs.shape == (5, NL)
+    y = torch.randint(0, 2, (5, NL)).float()
+    y[4] = -1.0
+    loss = MaskedLoss(binary_crossentropy)(y.cuda(), probs)
+    loss.backward()
+    ids = torch.cat([torch.full((5, 1), 3), torch.full((5, 1), 4), items.cpu(), torch.full((5, 1), 4)], dim=1)
+    tP = {k[len('transformer.'):]: v.detach().cpu().double() for k, v in model.state_dict().items()
+          if k.startswith('transformer.') and 'pos_encoding' not in k}
+    hP = {k[len('head.'):]: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items() if k.startswith('head.')}
+    enc = tr.transformer_forward({'items': ids}, tP, 1, 2)
+    pr = tr.multilabel_head(enc[:, 0:1, :], hP, 1)            # segment 0 = the [CLS] position only
+    ref = tr.masked_loss(y.double(), pr, tr.binary_ce_tf)
+    ref.backward()
+    assert float((probs.detach().cpu().double() - pr).abs().max()) < 1e-5
+    assert abs(float(loss) - float(ref)) < 1e-5
+    for n, p in model.head.named_parameters():
+        assert float((p.grad.cpu().double() - hP[n].grad).abs().max()) < 2e-4 * float(hP[n].grad.abs().max()) + 1e-12, n
+    with pytest.raises(ValueError):
+        head(torch.zeros(2, 3, d, device='cuda'))            # tf.squeeze(axis=1) needs a length-1 axis
+
+
+def test_binary_metrics_match_restatement(gpu):
+    from bert4clickpath_amd.clickstream_transformer import F1Score, MaskedMetric, PositiveRate, PredictedPositives
+    torch.manual_seed(9)
+    y = torch.randint(0, 2, (6, 9)).float()
+    y[0, 4:] = -1.0
+    y[5, 8] = -1.0
+    p = torch.rand(6, 9)
+    p[1, 1] = 0.5          # tf.round(0.5) = 0 (half to even)
+    p[1, 2] = 1.5          # rounds to 2: not a predicted positive for F1
+    ref = nr.binary_metrics(y.numpy(), p.numpy())
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-6)):
+        pp = p.to(dtype)
+        refd = nr.binary_metrics(y.numpy(), pp.float().numpy())
+        ms = [PositiveRate(), PredictedPositives(), MaskedMetric(F1Score(), name='f1')]
+        for m in ms:
+            m.update_state(y.cuda(), pp.cuda())
+            m.update_state(y.cuda(), pp.cuda())             # accumulates: ratios unchanged
+        assert abs(float(ms[0].result()) - refd['positive_rate']) < tol
+        assert abs(float(ms[1].result()) - refd['pred_positives']) < tol
+        assert abs(float(ms[2].result()) - refd['f1']) < tol
+        ms[2].reset_states()
+        ms[2].update_state(y.cuda(), pp.cuda())
+        assert abs(float(ms[2].result()) - refd['f1']) < tol
+    with pytest.raises(ValueError):
+        MaskedMetric(F1Score(), name='x').update_state(y.cuda(), p.cuda(), sample_weight=1)
+    assert abs(ref['f1'] - nr.binary_metrics(y.numpy(), p.numpy())['f1']) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------
+# tied-weight masked-item head: north_star extension, NO reference oracle (build's own fp64 restatement)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_tied_head_forward_loss_and_gradients(gpu, dtype):
+    from bert4clickpath_amd import optim
+    from bert4clickpath_amd.clickstream_transformer import ClozeMaskedItemPrediction
+    V, d = 150, 64
+    head = ClozeMaskedItemPrediction([48], V)
+    model = _model(V=V, d=d, L=1, H=2, dtype=dtype, head=head, seed=17)
+    assert sorted(n for n, _ in model.head.named_parameters()) == ['intermediate_layers.0.bias', 'intermediate_layers.0.kernel',
+                                                                   'intermediate_layers.1.bias', 'intermediate_layers.1.kernel',
+                                                                   'output_bias']       # the table is the model's, not the head's
+    b, items, labels = _batch(6, 19, V, seed=23)
+    table = model.transformer.embedding_layers['items'].weight
+    P = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in model.state_dict().items() if 'pos_encoding' not in k}
+    ids = torch.from_numpy(b['ids'])
+
+    def oracle_loss():
+        tP = {k[len('transformer.'):]: v for k, v in P.items() if k.startswith('transformer.')}
+        hP = {k[len('head.'):]: v for k, v in P.items() if k.startswith('head.')}
+        enc = tr.transformer_forward({'items': ids}, tP, 1, 2)
+        rows, _ = tr.gather_masked_rows(enc, ids)
+        logits = tr.tied_head_logits(rows, hP, 2, tP['embedding_layers.items.weight'], 10, V)
+        probs = torch.softmax(logits, -1)
+        return tr.sparse_ce_tf(probs, torch.from_numpy(b['labels']).long()).mean(), probs, rows
+    ref, rprobs, rrows = oracle_loss()
+    ref.backward()
+    probs = model({'asin': items}, training=False)
+    assert probs.shape[-1] == V
+    # numpy restatement == torch restatement (the oracle checks itself)
+    hPn = {k[len('head.'):]: v.detach().numpy() for k, v in P.items() if k.startswith('head.')}
+    npp = nr.tied_item_head(rrows.detach().numpy(), hPn, 2, P['transformer.embedding_layers.items.weight'].detach().numpy(), 10, V)
+    assert float(np.abs(npp - rprobs.detach().numpy()).max()) < 1e-12
+    loss = model.cloze_loss({'asin': items}, labels, training=True)
+    loss.backward()
+    if dtype == torch.float32:
+        assert abs(float(loss) - float(ref)) < 1e-5
+        flat = probs.reshape(-1, V)[(labels.reshape(-1) != -1)]
+        assert float((flat.cpu().double() - rprobs.detach()).abs().max()) < 1e-6
+        tol = 2e-4
+    else:
+        assert abs(float(loss) - float(ref)) < 3e-2 * float(ref)
+        tol = 0.2      # bf16 weights / activations carry 8 significant bits; q / k projections of a 1-layer toy model are the noisiest
+    for n, p in model.named_parameters():
+        gr = P[n].grad
+        if float(gr.abs().max()) < 1e-9:
+            continue
+        err = float((p.grad.cpu().double() - gr).norm() / gr.norm())
+        assert err < tol, (n, err)
+    # the table receives BOTH gradients: rows of items that only occur as labels are touched through the head alone
+    lab = torch.from_numpy(b['labels']).long() + 10
+    assert float(table.grad[lab].abs().sum()) > 0
+    # arena mode (in-place gradients) gives the same result
+    g_plain = _grads(model)
+    opt = optim.Adam(model.parameters())
+    opt.zero_grad()
+    model.cloze_loss({'asin': items}, labels, training=True).backward()
+    for n, p in model.named_parameters():
+        a = g_plain[n].float()
+        assert float((p.grad.float() - a).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2) * float(a.abs().max()) + 1e-9, n
+    opt.step()
+    assert torch.isfinite(opt.arena.flat).all()
+    top, hit, nd = model.predict_topk({'asin': items}, 5, labels)
+    assert top.shape == (b['labels'].shape[0], 5)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# sync-free Cloze step: device-side label compaction
+# ------------------------------------------------------------------------------------------------------------
+def test_compact_labels_and_syncfree_cloze_loss(gpu):
+    from bert4clickpath_amd import ops
+    V = 80
+    model = _model(V=V)
+    b, items, labels = _batch(7, 23, V, seed=31)
+    ids = torch.from_numpy(b['ids']).cuda()
+    counts, offsets, flat, mx = ops.mask_positions(ids, 1, cap=7 * 10)
+    lab = ops.compact_labels(labels, counts, offsets, 70, flat)
+    R = int(offsets[-1])
+    assert R == b['labels'].shape[0]
+    assert np.array_equal(lab[:R].cpu().numpy(), b['labels']) and bool((lab[R:] == -1).all()) and bool((flat[R:] == -1).all())
+    assert np.array_equal(flat[:R].cpu().numpy(), b['flat_idx'])
+    ref = model.cloze_loss({'asin': items}, labels, training=False, flat_idx=torch.from_numpy(b['flat_idx']).cuda())
+    got = model.cloze_loss({'asin': items}, labels, training=False, max_masked_per_row=10)
+    assert abs(float(ref) - float(got)) < 1e-6 * float(ref)     # the ignored tail rows only change the summation tree
+    model.zero_grad()
+    model.cloze_loss({'asin': items}, labels, training=True, flat_idx=torch.from_numpy(b['flat_idx']).cuda()).backward()
+    g0 = _grads(model)
+    model.zero_grad()
+    model.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10).backward()
+    for n, g in _grads(model).items():
+        assert float((g - g0[n]).abs().max()) <= 1e-6 * float(g0[n].abs().max()) + 1e-12, n
+
+
+def test_checkpoint_remaps_adam_moments_across_arena_orders(gpu, tmp_path):
+    """a checkpoint saved under one FlatArena order must load under another (moments are stored by name)."""
+    from bert4clickpath_amd import checkpoint as ck, optim
+    V = 40
+    m1 = _model(V=V, seed=3)
+    names = {id(p): n for n, p in m1.named_parameters()}
+    o1 = optim.Adam(m1.parameters(), order=lambda p: names[id(p)][::-1])     # some other order
+    b, items, labels = _batch(4, 15, V, seed=8)
+    for _ in range(2):
+        o1.zero_grad()
+        m1.cloze_loss({'asin': items}, labels, training=True).backward()
+        o1.step()
+    path = ck.save_checkpoint(str(tmp_path / 'ckpt-x'), m1, o1, epoch=1)
+    m2 = _model(V=V, seed=4)
+    o2 = optim.Adam(m2.parameters())                                          # default order
+    assert [names[id(p)] for p in o1.arena.params] != [n for n, _ in m2.named_parameters()]
+    ck.load_checkpoint(path, m2, o2)
+    n2 = {id(p): n for n, p in m2.named_parameters()}
+    for p, off in zip(o2.arena.params, o2.arena.offsets):
+        q = dict(m1.named_parameters())[n2[id(p)]]
+        lo, hi = o1.arena.slice_of(q)
+        assert torch.equal(o2.m[off:off + p.numel()], o1.m[lo:hi]) and torch.equal(o2.v[off:off + p.numel()], o1.v[lo:hi])
+        assert torch.equal(p.data, q.data)
+    for o, m in ((o1, m1), (o2, m2)):
+        o.zero_grad()
+        m.cloze_loss({'asin': items}, labels, training=True).backward()
+        o.step()
+    for (n, p), (_, q) in zip(sorted(m1.named_parameters()), sorted(m2.named_parameters())):
+        if n.endswith('mha.wk.bias'):
+            continue
+        assert float((p - q).abs().max()) <= 1e-5 * float(p.abs().max()) + 1e-7, n
