@@ -38,24 +38,41 @@ def _batch(rank):
     return ids[:, 2:S - 1].contiguous().cuda(), torch.from_numpy(b['labels']).cuda(), torch.from_numpy(b['flat_idx']).cuda()
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, sparse):
+    # one device per rank over RCCL ("nccl") whenever the box has them; both ranks on cuda:0 over gloo otherwise
+    multi = torch.cuda.device_count() >= world
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0', B4C_DIST_BACKEND='gloo')
+                      LOCAL_RANK=str(rank if multi else 0), B4C_DIST_BACKEND='nccl' if multi else 'gloo',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
     from bert4clickpath_amd import optim, parallel
     parallel.init_distributed()
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(rank if multi else 0)
     model = _model()
     opt = optim.Adam(model.parameters())
     head_end = max(opt.arena.slice_of(p)[1] for n, p in model.named_parameters() if n.startswith('head.'))
-    red = parallel.GradReducer(opt.arena, bucket_bounds=[head_end], reduce='sum')
+    table = model.transformer.embedding_layers['items'].weight
+    red = parallel.GradReducer(opt.arena, bucket_bounds=[head_end], reduce='sum', sparse_params=[table] if sparse else (),
+                               sparse_max_fill=8.0)
     assert red.overlap and len(red.buckets) == 2
     items, labels, flat = _batch(rank)
-    for _ in range(STEPS):
+    for step in range(STEPS):
         opt.zero_grad()
         red.begin_backward()
-        loss = model.cloze_loss({'asin': items}, labels, training=True, flat_idx=flat)
+        if step == 1 and rank == 1:
+            # a replica without a single masked row (losses.py:89-91 guard): zero loss, most gradients never produced
+            # on this rank -- the bucket order must still match rank 0's
+            loss = model.cloze_loss({'asin': items}, labels[:0], training=True, flat_idx=flat[:0])
+        else:
+            loss = model.cloze_loss({'asin': items}, labels, training=True, flat_idx=flat)
         loss.backward()
+        if sparse:
+            ids = torch.cat([torch.full((items.shape[0], 2), 3, device=items.device), items,
+                             torch.full((items.shape[0], 1), 4, device=items.device)], dim=1)    # [CLS] [SEP] items [SEP]
+            ids[:, 1] = 4
+            red.set_touched_rows(table, ids)
         red.finish()
+        if sparse:
+            assert red.last_exchange[id(table)] == 'sparse'
         opt.step(red.grad_mul)
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, 'rank%d.npy' % rank), opt.arena.flat.cpu().numpy())
@@ -63,12 +80,13 @@ def _worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_step_matches_single_process(tmp_path):
+@pytest.mark.parametrize('sparse', [False, True])
+def test_two_rank_step_matches_single_process(tmp_path, sparse):
     if not torch.cuda.is_available():
         pytest.skip('needs the MI355X')
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), sparse)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -82,9 +100,11 @@ def test_two_rank_step_matches_single_process(tmp_path):
     model = _model()
     opt = optim.Adam(model.parameters())
     shards = [_batch(r) for r in range(world)]
-    for _ in range(STEPS):
+    for step in range(STEPS):
         opt.zero_grad()
-        for items, labels, flat in shards:
+        for r, (items, labels, flat) in enumerate(shards):
+            if step == 1 and r == 1:
+                continue          # that replica had no masked row in this step: its loss is 0
             model.cloze_loss({'asin': items}, labels, training=True, flat_idx=flat).backward()
         opt.step()
     ref = opt.arena.flat.cpu().numpy()

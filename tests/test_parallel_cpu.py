@@ -42,6 +42,45 @@ def _worker(rank, world, port, q):
             assert torch.allclose(p.grad, torch.full_like(p, tot * (i + 1.0))), (overlap, i)
         assert p.grad.data_ptr() >= arena.grad.data_ptr()          # still a view into the arena
         out['overlap%d' % overlap] = True
+    # a parameter without gradient on ONE rank (a replica with no masked row): the collectives must still be issued in
+    # the same order on both ranks -- three buckets, rank 1 never produces the gradient of the middle one
+    red3 = parallel.GradReducer(arena, bucket_bounds=[arena.offsets[1], arena.offsets[2]], reduce='sum', overlap=True)
+    assert len(red3.buckets) == 3
+    arena.zero_grad()
+    red3.begin_backward()
+    use = params if rank == 0 else [params[0], params[2], params[3]]
+    sum((i + 1.0) * p.sum() for i, p in enumerate(use)).backward()
+    red3.finish()
+    assert torch.allclose(params[1].grad, torch.full_like(params[1], 2.0))            # rank 0 only
+    assert torch.allclose(params[0].grad, torch.full_like(params[0], 2.0))            # 1 + 1
+    assert torch.allclose(params[3].grad, torch.full_like(params[3], 4.0 + 3.0))      # i+1 = 4 on rank 0, 3 on rank 1
+    out['ragged'] = True
+    # row-sparse exchange of an embedding-table gradient against the dense all-reduce
+    torch.manual_seed(10 + rank)
+    dense_p = torch.nn.Parameter(torch.randn(70))
+    table = torch.nn.Parameter(torch.randn(40, 8))
+    ar2 = optim.FlatArena([dense_p, table])
+    ids = torch.tensor([[3, 5, 5, 9], [0, 39, 3, 17]]) if rank == 0 else torch.tensor([[5, 6, 7, 39], [21, 21, 21, 2]])
+    for fill, expect in ((1.0, 'sparse'), (0.01, 'dense')):
+        red_s = parallel.GradReducer(ar2, reduce='sum', overlap=False, sparse_params=[table], sparse_max_fill=fill)
+        assert red_s.dense_end == ar2.slice_of(table)[0] and len(red_s.buckets) == 1
+        ar2.zero_grad()
+        red_s.begin_backward()
+        ((rank + 2.0) * table[ids.reshape(-1)].sum() + (rank + 1.0) * dense_p.sum()).backward()
+        local = table.grad.clone()
+        red_s.set_touched_rows(table, ids)
+        red_s.finish()
+        assert red_s.last_exchange[id(table)] == expect
+        both = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(both, local)
+        assert torch.equal(table.grad, both[0] + both[1]), expect
+        assert torch.allclose(dense_p.grad, torch.full_like(dense_p, 3.0))
+    try:
+        parallel.GradReducer(ar2, sparse_params=[dense_p])
+        raise AssertionError('a sparse parameter that is not last in the arena must be refused')
+    except ValueError:
+        pass
+    out['sparse'] = True
     red_mean = parallel.GradReducer(arena, reduce='mean', overlap=False)
     assert red_mean.grad_mul == 1.0 / world and parallel.GradReducer(arena, overlap=False).grad_mul == 1.0
     # shards partition the rows
@@ -71,6 +110,7 @@ def test_two_rank_gloo_gradient_reduce_and_metrics():
     assert res[0]['shard'] == (0, 5) and res[1]['shard'] == (5, 10)
     assert res[0]['recall'] == res[1]['recall'] == pytest.approx(3.0 / 8.0)
     assert res[0]['overlap1'] and res[1]['overlap1']
+    assert all(res[r]['ragged'] and res[r]['sparse'] for r in (0, 1))
 
 
 def test_shard_rows_partition():
