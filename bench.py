@@ -2,8 +2,12 @@
 """bench.py -- masked-items/sec of the BERT4Rec Cloze training step on MI355X.
 
 A step = one pass of the hot path over one synthetic batch already resident in HBM:
-embedding stage -> 4 encoder layers -> [MASK]-row gather -> SoftMaxHead trunk + 50k-way projection ->
-fused softmax / masked sparse CE -> full backward -> gradient all-reduce (N > 1) -> Adam.
+embedding stage -> 4 encoder layers -> device-side [MASK] index generation + label compaction -> [MASK]-row gather ->
+SoftMaxHead trunk + 50k-way projection -> fused softmax / masked sparse CE -> full backward -> gradient all-reduce
+(N > 1) -> Adam.  Nothing is read back to the host inside the timed region.
+After the timed training region rank 0 also times the SCORING leg on the same batches (forward -> materialised
+(B, M, V) probabilities, as the reference's head returns them -> HitRate@10 / NDCG@10 update) and reports it under
+"eval" with the roofline of the vocabulary projection.
 Workload (BASELINE.json configs[1]): vocab 50,000, encoder length 200 (197 items + 3 specials),
 d_model 128, 4 layers, 2 heads, dff 100 (reference-hard-coded), head [1024,512,256,128] -> V,
 batch 4096 sequences per GPU (weak scaling), 10 masked items per sequence, dropout 0.1, bf16
@@ -44,9 +48,11 @@ def parse():
     ap.add_argument('--heads', type=int, default=2)
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--n_batches', type=int, default=2, help='distinct resident batches cycled through')
+    ap.add_argument('--n_batches', type=int, default=8, help='distinct resident batches cycled through')
     ap.add_argument('--no_cpu_baseline', action='store_true')
-    ap.add_argument('--cpu_rows', type=int, default=48, help='sequences in the bounded CPU-baseline sample')
+    ap.add_argument('--cpu_rows', type=int, default=256, help='sequences in the bounded CPU-baseline sample (SURVEY 8d: B=256)')
+    ap.add_argument('--eval_steps', type=int, default=6, help='timed scoring batches (0 = skip the scoring leg)')
+    ap.add_argument('--host_flat_idx', action='store_true', help='A/B: hand the step host-precomputed [MASK] indices (round-1 bench)')
     ap.add_argument('--record_steps', type=int, default=5,
                     help='timed steps (the first N of the timed region) whose launches are bracketed by HIP events for the roofline; '
                          '-1 = all (costs ~0.4 ms/step of event overhead), 0 = none')
@@ -94,6 +100,7 @@ def make_batches(a, rank, device):
         out.append({'items': ids[:, 2:a.seq - 1].contiguous().to(device),
                     'flat_idx': torch.from_numpy(b['flat_idx']).to(device),
                     'labels': torch.from_numpy(b['labels']).to(device),
+                    'labels_padded': torch.from_numpy(b['labels_padded']).to(device),      # (B, 10) float32, -1 = pad
                     'R': int(b['labels'].shape[0])})
     return out
 
@@ -125,7 +132,7 @@ def cpu_baseline(a):
                 tr.adam_step(P[k], P[k].grad, m[k], vv[k], t)
     step(1)
     t0, n = time.perf_counter(), 0
-    while time.perf_counter() - t0 < 12.0 and n < 50:
+    while (time.perf_counter() - t0 < 15.0 and n < 50) or n < 2:
         step(n + 2)
         n += 1
     dt = (time.perf_counter() - t0) / max(n, 1)
@@ -141,18 +148,20 @@ KERNEL_OF = {   # launch family (ops recorder) -> kernel symbol(s) in the rocpro
     'add_ln_fwd': 'add_ln_fwd_kernel', 'gemm_nt_ln': 'gemm_nt_ln_kernel (out-proj / FFN2 GEMM + residual + dropout + LayerNorm)', 'add_ln_bwd': 'add_ln_bwd_kernel', 'embed_fwd': 'embed_fwd_kernel',
     'embed_bwd': 'embed_bwd_kernel', 'adam': 'adam_kernel',
     'vocab_ce_fwd': 'vce_token_kernel<128,0|1|2> + vce_combine_kernel (projection + softmax CE + dX, logits in registers)',
-    'vocab_ce_dw': 'vce_dw_kernel + vce_label_kernel (projection dW / db, logits recomputed)'}
+    'vocab_ce_dw': 'vce_dw_kernel + vce_label_kernel (projection dW / db, logits recomputed)',
+    'vocab_proj': 'gemm_nt_wide_kernel (materialised vocabulary projection, R x V out)',
+    'softmax_rows': 'softmax_rows_bf16_kernel (row in registers: one read, one write)', 'topk_rows': 'topk_rows_kernel'}
 
 
-def roofline_from(fams, steps, peak_tf):
-    """Dominant launch family of the timed region (largest summed HIP-event time) against the HBM roofline:
-    achieved = sum of the launches' ALGORITHMIC bytes / summed duration."""
+def roofline_from(fams, steps, peak_tf, dom=None):
+    """Dominant launch family of the timed region (largest summed HIP-event time; or the named one) against the HBM
+    roofline: achieved = sum of the launches' ALGORITHMIC bytes / summed duration."""
     table = {}
     for fam, v in fams.items():
         ms = max(v['ms'], 1e-9)
         table[fam] = {'ms_per_step': v['ms'] / steps, 'launches_per_step': v['launches'] / steps,
                       'GB_per_s': v['bytes'] / ms / 1e6, 'TFLOP_per_s': v['flops'] / ms / 1e9}
-    dom = max(fams, key=lambda f: fams[f]['ms'])
+    dom = dom or max(fams, key=lambda f: fams[f]['ms'])
     v = fams[dom]
     ach = v['bytes'] / v['ms'] / 1e6
     return {'bound': 'hbm', 'kernel': KERNEL_OF.get(dom, dom), 'family': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -160,6 +169,42 @@ def roofline_from(fams, steps, peak_tf):
             'algorithmic_bytes_per_launch': v['bytes'] / v['launches'],
             'mfma_frac_of_%g_TF' % peak_tf: v['flops'] / v['ms'] / 1e9 / peak_tf, 'traffic': None,
             'families': table}
+
+
+def eval_leg(model, batches, a, peak_tf):
+    """Scoring leg (reference: evaluate / predict): forward without dropout -> (B, M, V) probabilities materialised as
+    SoftMaxHead returns them (head.py:36-47) -> ClozeMaskedRecall(10) / ClozeMaskedNDCG(10) update (utils.py:161-190,
+    225-255).  Timed on the device timeline; the vocabulary projection's own roofline is reported (north_star: >= 60 %
+    of HBM peak on the vocab-projection at batch 4096 x seq 200)."""
+    from bert4clickpath_amd import ops
+    from bert4clickpath_amd.cloze import ClozeMaskedNDCG, ClozeMaskedRecall
+    rec, ndcg = ClozeMaskedRecall(10), ClozeMaskedNDCG(10)
+
+    def score(i):
+        b = batches[i % len(batches)]
+        with torch.no_grad():
+            probs = model({'asin': b['items']}, training=False, max_matches=10)       # (B, 10, V), no host sync
+            rec.update_state(b['labels_padded'], probs)
+            ndcg.update_state(b['labels_padded'], probs)
+    for i in range(2):
+        score(i)
+    rec.reset_states()
+    ndcg.reset_states()
+    torch.cuda.synchronize()
+    ops.start_recording()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.eval_steps + 1)]
+    ev[0].record()
+    for i in range(a.eval_steps):
+        score(i)
+        ev[i + 1].record()
+    fams = ops.stop_recording()
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.eval_steps))
+    R = sum(batches[i % len(batches)]['R'] for i in range(a.eval_steps))
+    roof = roofline_from(fams, a.eval_steps, peak_tf, dom='vocab_proj' if 'vocab_proj' in fams else None)
+    return {'what': 'forward -> materialised (B, 10, V) probabilities -> HitRate@10 + NDCG@10 update, batch %d' % a.batch,
+            'batches': a.eval_steps, 'ms_per_batch': sum(ms) / len(ms), 'ms_median': ms[len(ms) // 2],
+            'masked_items_per_s': R / (sum(ms) / 1e3), 'hit_rate_at_10': float(rec.result()), 'ndcg_at_10': float(ndcg.result()),
+            'roofline': roof}
 
 
 def main():
@@ -192,7 +237,10 @@ def main():
         b = batches[i % len(batches)]
         opt.zero_grad()
         reducer.begin_backward()
-        loss = model.cloze_loss({'asin': b['items']}, b['labels'], training=True, flat_idx=b['flat_idx'])
+        if a.host_flat_idx:
+            loss = model.cloze_loss({'asin': b['items']}, b['labels'], training=True, flat_idx=b['flat_idx'])
+        else:       # device-side index generation + label compaction, cap = 10 rows per sequence, no host sync
+            loss = model.cloze_loss({'asin': b['items']}, b['labels_padded'], training=True, max_masked_per_row=10)
         loss.backward()
         reducer.finish()
         opt.step(reducer.grad_mul)
@@ -203,15 +251,18 @@ def main():
     nrec = a.steps if a.record_steps < 0 else min(a.record_steps, a.steps)
     if rank == 0 and nrec > 0:
         ops.start_recording()      # HIP events around every hot-path launch of the first nrec timed steps (rank 0)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # one event per step boundary
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fams = None
+    marks[0].record()
     for i in range(a.steps):
         if i == nrec and rank == 0 and nrec > 0:
             fams = ops.pause_recording()
         loss = step(a.warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -225,26 +276,41 @@ def main():
 
     if rank == 0:
         fams = ops.stop_recording(fams)
-        roof = roofline_from(fams, max(nrec, 1), MFMA_BF16_PEAK_TF if a.dtype == 'bf16' else 157.3) if fams else None
+        peak_tf = MFMA_BF16_PEAK_TF if a.dtype == 'bf16' else 157.3
+        roof = roofline_from(fams, max(nrec, 1), peak_tf) if fams else None
         tj = a.traffic_json or os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tj):      # rocprofv3 PMC passes (separate runs), HBM bytes per launch of each family
+        if roof and os.path.exists(tj):      # rocprofv3 PMC passes (separate runs), HBM bytes per launch of each family
             with open(tj) as f:
-                if roof:
-                    roof['traffic'] = json.load(f).get(roof['family'])
+                traffic = json.load(f)
+            cfg = traffic.get('_config', {})
+            mine = {'vocab': a.vocab, 'batch': a.batch, 'seq': a.seq, 'd_model': a.d_model, 'layers': a.layers, 'dtype': a.dtype}
+            if a.traffic_json or all(cfg.get(k) == v for k, v in mine.items()):     # counters are valid for that config only
+                roof['traffic'] = traffic.get(roof['family'])
+        # per-step durations on the device timeline (events at the step boundaries; steps with the launch recorder on are
+        # ~0.4 ms longer): SURVEY 8d asks for the median and p10 / p90
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+
+        def pct(q):
+            return step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))]
         out = {
             'metric': 'masked-items/sec (whole node)', 'value': items / dt, 'unit': 'masked-items/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if a.dtype == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BERT4Rec Cloze training step: vocab=%d seq_len=%d d_model=%d layers=%d heads=%d dff=100 '
-                                   'head=[1024,512,256,128]->V batch=%d seq/GPU x %d GPU, 10 masked/seq, dropout=%.2f, Zipf(1.1) ids'
-                                   % (a.vocab, a.seq, a.d_model, a.layers, a.heads, a.batch, world, a.dropout),
+                                   'head=[1024,512,256,128]->V batch=%d seq/GPU x %d GPU, 10 masked/seq, dropout=%.2f, Zipf(1.1) ids, '
+                                   '%d resident batches, [MASK] indices %s'
+                                   % (a.vocab, a.seq, a.d_model, a.layers, a.heads, a.batch, world, a.dropout, len(batches),
+                                      'precomputed on the host' if a.host_flat_idx else 'generated on the device inside the step'),
                        'global_batch': a.batch * world, 'seq_len': a.seq, 'parallelism': 'dp%d' % world,
                        'grad_reduce': 'sum (reference semantics)'},
             'tokens_per_s': a.batch * world * a.seq * a.steps / dt,
+            'step_ms': {'median': pct(0.5), 'p10': pct(0.1), 'p90': pct(0.9), 'min': step_ms[0], 'max': step_ms[-1]},
             'final_loss': float(loss.detach()),
             'roofline': roof,
         }
+        if world == 1 and a.eval_steps > 0:
+            out['eval'] = eval_leg(model, batches, a, peak_tf)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a)
         print(json.dumps(out))

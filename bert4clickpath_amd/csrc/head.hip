@@ -72,6 +72,72 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const T *__restrict__
     }
 }
 
+// bf16, V <= 65536: the row stays in registers as raw bf16 pairs (NCH x 16 B per thread, 512 threads), so HBM sees
+// every logit once in and every probability once out (the streaming kernel above reads the row three times).
+template <int NCH>
+__global__ void __launch_bounds__(512, 4) softmax_rows_bf16_kernel(const bf16_t *__restrict__ x, int ld_in, bf16_t *__restrict__ y,
+                                                                   int ld_out, int64_t R, int V) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    __shared__ float buf[8];
+    const int tid = threadIdx.x;
+    const int nch_in = (V + 7) >> 3, nch_out = ld_out >> 3;
+    const float LOG2E = 1.4426950408889634f;
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        const bf16_t *xr = x + row * ld_in;
+        bf16_t *yr = y + row * ld_out;
+        u32x4 raw[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 512 + tid;
+            raw[i] = (c < nch_in) ? *reinterpret_cast<const u32x4 *>(xr + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+#define SM_ELEM(i, k) __uint_as_float((k & 1) ? (raw[i][k >> 1] & 0xFFFF0000u) : (raw[i][k >> 1] << 16))
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int base = (i * 512 + tid) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (base + k < V) mx = fmaxf(mx, SM_ELEM(i, k));
+        }
+        mx = wave_max(mx);
+        __syncthreads();
+        if ((tid & 63) == 0) buf[tid >> 6] = mx;
+        __syncthreads();
+        mx = buf[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) mx = fmaxf(mx, buf[w]);
+        const float mb = mx * LOG2E;
+        float z = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int base = (i * 512 + tid) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (base + k < V) z += __builtin_amdgcn_exp2f(SM_ELEM(i, k) * LOG2E - mb);
+        }
+        z = wave_sum(z);
+        __syncthreads();
+        if ((tid & 63) == 0) buf[tid >> 6] = z;
+        __syncthreads();
+        z = buf[0] + buf[1] + buf[2] + buf[3] + buf[4] + buf[5] + buf[6] + buf[7];
+        const float invz = 1.0f / z;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 512 + tid;
+            const int base = c * 8;
+            if (c < nch_out) {
+                float p[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p[k] = (base + k < V) ? __builtin_amdgcn_exp2f(SM_ELEM(i, k) * LOG2E - mb) * invz : 0.f;
+                Vec8<bf16_t>::store_nt(yr + base, p);
+            }
+        }
+#undef SM_ELEM
+        __syncthreads();
+    }
+}
+
 extern "C" int b4c_softmax_rows(const void *logits, int ld_in, void *probs, int ld_out, int64_t R, int V, int dtype,
                                 void *stream) {
     B4C_REQUIRE(logits && probs && R >= 0 && V > 0, "softmax_rows: bad argument");
@@ -79,6 +145,19 @@ extern "C" int b4c_softmax_rows(const void *logits, int ld_in, void *probs, int 
     if (R == 0) return B4C_OK;
     const int grid = (int)(R < 4096 ? R : 4096);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_BF16 && ld_out <= 8 * 16 * 512) {
+        const int nch = (int)ceil_div64(ld_out / 8, 512);
+        const int g5 = (int)(R < 3072 ? R : 3072);
+#define SM16_LAUNCH(N) softmax_rows_bf16_kernel<N><<<g5, 512, 0, st>>>((const bf16_t *)logits, ld_in, (bf16_t *)probs, ld_out, R, V)
+        if (nch <= 1) SM16_LAUNCH(1);
+        else if (nch <= 2) SM16_LAUNCH(2);
+        else if (nch <= 4) SM16_LAUNCH(4);
+        else if (nch <= 8) SM16_LAUNCH(8);
+        else if (nch <= 13) SM16_LAUNCH(13);
+        else SM16_LAUNCH(16);
+#undef SM16_LAUNCH
+        return b4c_check_launch("softmax_rows_bf16");
+    }
     if (dtype == B4C_F32) softmax_rows_kernel<float><<<grid, 256, 0, st>>>((const float *)logits, ld_in, (float *)probs, ld_out, R, V);
     else if (dtype == B4C_BF16) softmax_rows_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t *)logits, ld_in, (bf16_t *)probs, ld_out, R, V);
     else B4C_REQUIRE(false, "softmax_rows: dtype %d", dtype);
@@ -449,9 +528,10 @@ extern "C" int b4c_softmax_ce_fwd_bwd(void *logits, int ld, const int32_t *label
 __device__ __forceinline__ bool better(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
 
 template <typename T, int KM>
-__global__ void __launch_bounds__(256) topk_rows_kernel(const T *__restrict__ x, int ld, int64_t R, int V, int k,
+__global__ void __launch_bounds__(256) topk_rows_lists_kernel(const T *__restrict__ x, int ld, int64_t R, int V, int k,
                                                         int32_t *__restrict__ topk_idx, const int32_t *__restrict__ labels,
-                                                        float *__restrict__ hit, float *__restrict__ ndcg) {
+                                                        float *__restrict__ hit, float *__restrict__ ndcg,
+                                                        const int32_t *__restrict__ redo) {
     __shared__ float lv[256][KM + 1];
     __shared__ int li[256][KM + 1];
     __shared__ float wv[4];
@@ -460,6 +540,7 @@ __global__ void __launch_bounds__(256) topk_rows_kernel(const T *__restrict__ x,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nch = (V + 7) >> 3;
     for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        if (redo && !redo[row]) continue;       // block-uniform: the threshold kernel has done this row
         const T *xr = x + row * ld;
         float tv[KM];
         int ti[KM];
@@ -525,15 +606,180 @@ __global__ void __launch_bounds__(256) topk_rows_kernel(const T *__restrict__ x,
     }
 }
 
+// Fast path: threshold selection.  Pass 1 finds every thread's best element; k rounds of block arg-max over those 256
+// values give T = the k-th best of them, a lower bound of the row's k-th best (at least k elements are >= T).  Pass 2
+// re-reads the row (it is 100 - 260 KB and was just read: served by L2) and collects the elements that are not worse than T
+// into LDS -- about k of them for continuous data -- and wave 0 picks the k best in order.  HBM sees the row once; the
+// per-thread sorted lists of the kernel above cost ~5,000 instructions per thread and row at k = 10 (562 GB/s).
+// Rows with more than TOPK_CAP candidates (massive ties) are flagged in `redo` and handled by the list kernel.
+#define TOPK_CAP 1024
+#define TOPK_THREADS 512
+// lane-strided arg-max over n (value, index) pairs in LDS by ONE wave; taken entries carry the sentinel index
+__device__ __forceinline__ void wave_argmax_lds(const float *v, const int *ix, int n, int lane, float &bv, int &bi, int &bp) {
+    bv = -INFINITY; bi = 0x7fffffff; bp = -1;
+    for (int q = lane; q < n; q += 64) {
+        const float a = v[q];
+        const int j = ix[q];
+        if (j != 0x7fffffff && better(a, j, bv, bi)) { bv = a; bi = j; bp = q; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o), op = __shfl_xor(bp, o);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; bp = op; }
+    }
+}
+
+// rank of lane's (v, j) among the first n lanes' pairs = number of pairs that are better (one wave, no LDS)
+__device__ __forceinline__ int wave_rank(float v, int j, int n) {
+    int rank = 0;
+    for (int q = 0; q < n; ++q) {
+        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), q));
+        const int oj = __builtin_amdgcn_readlane(j, q);
+        rank += better(ov, oj, v, j) ? 1 : 0;
+    }
+    return rank;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const T *__restrict__ x, int ld, int64_t R, int V, int k,
+                                                                 int32_t *__restrict__ topk_idx, const int32_t *__restrict__ labels,
+                                                                 float *__restrict__ hit, float *__restrict__ ndcg,
+                                                                 int32_t *__restrict__ redo) {
+    __shared__ float cv[TOPK_CAP];
+    __shared__ int ci[TOPK_CAP];
+    __shared__ float mv[TOPK_THREADS];
+    __shared__ int s_cnt;
+    __shared__ float s_tv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = (V + 7) >> 3;
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        const T *xr = x + row * ld;
+        // pass 1: per-thread maximum (values only; fmaxf drops NaNs).  Four loads in flight per thread.
+        float m = -INFINITY;
+        for (int c0 = tid; c0 < nch; c0 += 4 * TOPK_THREADS) {
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * TOPK_THREADS;
+                Vec8<T>::load(xr + (c < nch ? c : c0) * 8, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * TOPK_THREADS;
+                if (c + 1 < nch) {           // whole chunk inside the row (the last chunk may hold pad columns)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m = fmaxf(m, v[u][e]);
+                } else if (c < nch) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (c * 8 + e < V) m = fmaxf(m, v[u][e]);
+                }
+            }
+        }
+        mv[tid] = m;
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        if (wave == 0) {
+            // 64 maxima of disjoint element sets (lane l: threads l, l + 64, ...); the k-th largest of them is a lower
+            // bound of the row's k-th largest value: at least k elements are >= it
+            float g = mv[lane];
+#pragma unroll
+            for (int w = 1; w < TOPK_THREADS / 64; ++w) g = fmaxf(g, mv[lane + 64 * w]);
+            const int rank = wave_rank(g, lane, 64);
+            if (rank == k - 1) s_tv = g;      // ranks are a permutation of 0..63 (ties broken by lane)
+        }
+        __syncthreads();
+        const float tv = s_tv;
+        for (int c0 = tid; c0 < nch; c0 += 4 * TOPK_THREADS) {      // second read of the row: L2 / Infinity Cache
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * TOPK_THREADS;
+                Vec8<T>::load(xr + (c < nch ? c : c0) * 8, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * TOPK_THREADS;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = c * 8 + e;
+                    if (c < nch && j < V && v[u][e] >= tv) {
+                        const int pos = atomicAdd(&s_cnt, 1);
+                        if (pos < TOPK_CAP) { cv[pos] = v[u][e]; ci[pos] = j; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        if (cnt > TOPK_CAP) {
+            if (tid == 0) redo[row] = 1;
+        } else if (wave == 0) {
+            if (lane == 0) redo[row] = 0;
+            const int lab = labels ? labels[row] : -1;
+            if (cnt <= 64) {        // the usual case: one candidate per lane, ordered by rank counting
+                const float v = lane < cnt ? cv[lane] : -INFINITY;
+                const int j = lane < cnt ? ci[lane] : 0x7fffffff;
+                const int rank = wave_rank(v, j, cnt);
+                if (lane < cnt && rank < k) topk_idx[row * k + rank] = j;
+                if (lane >= cnt && lane < k) topk_idx[row * k + lane] = -1;          // fewer than k candidates (NaN rows)
+                const bool found = labels && lane < cnt && rank < k && j == lab;
+                const unsigned long long fb = __ballot(found);
+                if (found) {
+                    if (hit) hit[row] = 1.f;
+                    if (ndcg) ndcg[row] = 1.0f / (logf((float)(rank + 2)) / logf(2.0f));
+                } else if (fb == 0ull && lane == 0) {
+                    if (hit) hit[row] = 0.f;
+                    if (ndcg) ndcg[row] = 0.f;
+                }
+            } else {
+                float h_acc = 0.f, n_acc = 0.f;
+                for (int kk = 0; kk < k; ++kk) {
+                    float bv; int bi, bp;
+                    wave_argmax_lds(cv, ci, cnt, lane, bv, bi, bp);
+                    if (lane == 0) {
+                        if (bp >= 0) ci[bp] = 0x7fffffff;
+                        topk_idx[row * k + kk] = bi == 0x7fffffff ? -1 : bi;
+                        if (labels && bi == lab) {
+                            h_acc += 1.f;
+                            n_acc += 1.0f / (logf((float)(kk + 2)) / logf(2.0f));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (lane == 0) {
+                    if (hit) hit[row] = h_acc;
+                    if (ndcg) ndcg[row] = n_acc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int b4c_topk_rows(const void *scores, int ld, int64_t R, int V, int k, int32_t *topk_idx,
                              const int32_t *labels, float *hit, float *ndcg, int dtype, void *stream) {
+    return b4c_topk_rows_ws(scores, ld, R, V, k, topk_idx, labels, hit, ndcg, nullptr, dtype, stream);
+}
+
+// `redo` (int32 [R], scratch) enables the threshold kernel; rows it could not finish (more than TOPK_CAP candidates:
+// massive ties) are redone by the per-thread-list kernel.  redo == NULL: list kernel for every row.
+extern "C" int b4c_topk_rows_ws(const void *scores, int ld, int64_t R, int V, int k, int32_t *topk_idx,
+                                const int32_t *labels, float *hit, float *ndcg, int32_t *redo, int dtype, void *stream) {
     B4C_REQUIRE(scores && topk_idx && R >= 0 && V > 0, "topk_rows: bad argument");
     B4C_REQUIRE(k >= 1 && k <= B4C_MAX_TOPK && k <= V, "topk_rows: k=%d must be in [1, min(%d, V)]", k, B4C_MAX_TOPK);
     B4C_REQUIRE(ld % 8 == 0 && ld >= V, "topk_rows: pitch");
     if (R == 0) return B4C_OK;
     const int grid = (int)(R < 4096 ? R : 4096);
     hipStream_t st = (hipStream_t)stream;
-#define TOPK_LAUNCH(T, KM) topk_rows_kernel<T, KM><<<grid, 256, 0, st>>>((const T *)scores, ld, R, V, k, topk_idx, labels, hit, ndcg)
+    if (redo) {
+        const int g2 = (int)(R < 2048 ? R : 2048);
+        if (dtype == B4C_F32) topk_rows_kernel<float><<<g2, TOPK_THREADS, 0, st>>>((const float *)scores, ld, R, V, k, topk_idx, labels, hit, ndcg, redo);
+        else if (dtype == B4C_BF16) topk_rows_kernel<bf16_t><<<g2, TOPK_THREADS, 0, st>>>((const bf16_t *)scores, ld, R, V, k, topk_idx, labels, hit, ndcg, redo);
+        else B4C_REQUIRE(false, "topk_rows: dtype %d", dtype);
+    }
+#define TOPK_LAUNCH(T, KM) topk_rows_lists_kernel<T, KM><<<grid, 256, 0, st>>>((const T *)scores, ld, R, V, k, topk_idx, labels, hit, ndcg, redo)
 #define TOPK_DISPATCH(T)                  \
     if (k <= 1) TOPK_LAUNCH(T, 1);        \
     else if (k <= 4) TOPK_LAUNCH(T, 4);   \

@@ -209,7 +209,10 @@ def gemm_nt(a, bt, n, bias=None, act=L.ACT_NONE, gate=None, residual=None, out_d
     es = a.element_size()
     nbytes = M * K * es + n * K * es + M * n * out.element_size() + (M * n * es if gate is not None else 0) + \
         (M * n * es if residual is not None else 0)
-    with _record('gemm_nt', nbytes, 2 * M * n * K):
+    # the materialised vocabulary projection (wide kernel: bf16, K <= 128, N >= 2048, plain epilogue) is its own family
+    fam = 'vocab_proj' if (n >= 2048 and K <= 128 and a.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and
+                           act == L.ACT_NONE and gate is None and residual is None) else 'gemm_nt'
+    with _record(fam, nbytes, 2 * M * n * K):
         L.check(L.lib().b4c_gemm_nt(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), out.stride(0), M, n, K, _p(bias), act,
                                     _p(gate), gate.stride(0) if gate is not None else 0,
                                     _p(residual), residual.stride(0) if residual is not None else 0,
@@ -488,7 +491,8 @@ def softmax_rows(logits, V):
     probs = torch.empty(R, ld, dtype=logits.dtype, device=logits.device)
     if R == 0:
         return probs
-    L.check(L.lib().b4c_softmax_rows(_p(logits), ld, _p(probs), ld, R, V, dt_code(logits.dtype), _st()), 'softmax_rows')
+    with _record('softmax_rows', 2 * R * ld * logits.element_size()):
+        L.check(L.lib().b4c_softmax_rows(_p(logits), ld, _p(probs), ld, R, V, dt_code(logits.dtype), _st()), 'softmax_rows')
     return probs
 
 
@@ -562,6 +566,9 @@ def vocab_ce_dw(h, wt, bias, labels_i32, rowscal, V, dW, db):
                                         _p(dW), dW.stride(0), _p(db), ws.data_ptr(), ws.numel(), R, V, K, _st()), 'vocab_ce_dw')
 
 
+topk_threshold = True     # threshold-selection kernel (one HBM read per row); False: per-thread sorted lists only
+
+
 def topk_rows(scores, V, k, labels_i32=None):
     _cuda(scores)
     R, ld = scores.shape[0], scores.stride(0)
@@ -570,8 +577,10 @@ def topk_rows(scores, V, k, labels_i32=None):
     ndcg = torch.empty(R, dtype=torch.float32, device=scores.device) if labels_i32 is not None else None
     if R == 0:
         return idx, hit, ndcg
-    L.check(L.lib().b4c_topk_rows(_p(scores), ld, R, V, k, _p(idx), _p(labels_i32), _p(hit), _p(ndcg),
-                                  dt_code(scores.dtype), _st()), 'topk_rows')
+    redo = torch.empty(R, dtype=torch.int32, device=scores.device) if topk_threshold else None
+    with _record('topk_rows', R * ld * scores.element_size()):
+        L.check(L.lib().b4c_topk_rows_ws(_p(scores), ld, R, V, k, _p(idx), _p(labels_i32), _p(hit), _p(ndcg), _p(redo),
+                                         dt_code(scores.dtype), _st()), 'topk_rows')
     return idx, hit, ndcg
 
 

@@ -250,6 +250,12 @@ int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const flo
 int b4c_topk_rows(const void *scores, int ld, int64_t R, int V, int k, int32_t *topk_idx,
                   const int32_t *labels, float *hit, float *ndcg, int dtype, void *stream);
 
+/* same with a scratch int32 [R] (`redo`): rows are first handled by a threshold-selection kernel that reads each row
+ * from HBM once (per-thread maxima -> k-th best of them -> the ~k candidates not worse than it -> ordered pick);
+ * rows with more than 1024 candidates (massive ties) are flagged there and redone by the list kernel.  Same results. */
+int b4c_topk_rows_ws(const void *scores, int ld, int64_t R, int V, int k, int32_t *topk_idx,
+                     const int32_t *labels, float *hit, float *ndcg, int32_t *redo, int dtype, void *stream);
+
 /* ---- R16: Adam (Keras semantics, eps outside the sqrt) ------------------------------------
  * replaces tf.keras.optimizers.Adam(1e-3, .9, .999, 1e-9) (main.py:87), dense update over a flat
  * fp32 arena: m,v EMA; p -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (host).

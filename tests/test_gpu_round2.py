@@ -144,8 +144,9 @@ def test_upstream_gradient_scales_fused_losses(gpu, dtype):
         outs.append(_grads(model))
     for n in outs[0]:
         a, h = outs[0][n].float(), outs[1][n].float()
-        tol = 0.0 if dtype == torch.float32 else 1e-2 * float(a.abs().max()) + 1e-12
-        assert float((0.5 * a - h).abs().max()) <= tol + 1e-7 * float(a.abs().max()), n
+        # fp32: float atomics (LayerNorm dgamma / dbeta, embedding rows) reorder sums between the two runs
+        tol = (1e-5 if dtype == torch.float32 else 1e-2) * float(a.abs().max()) + 1e-12
+        assert float((0.5 * a - h).abs().max()) <= tol, n
     if dtype == torch.bfloat16:
         assert ops.vocab_ce_supported(torch.empty(1, 64, dtype=dtype, device='cuda'), 64)
         prev = ops.flash_ce
@@ -505,3 +506,34 @@ def test_checkpoint_remaps_adam_moments_across_arena_orders(gpu, tmp_path):
         if n.endswith('mha.wk.bias'):
             continue
         assert float((p - q).abs().max()) <= 1e-5 * float(p.abs().max()) + 1e-7, n
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_topk_threshold_kernel_equals_list_kernel(gpu, dtype):
+    """The one-read threshold-selection top-k against the per-thread-list kernel and the stable-argsort restatement:
+    bf16 ties, -inf / NaN entries, rows with more than 1024 candidates (fallback), k up to 16."""
+    from bert4clickpath_amd import ops
+    g = torch.Generator().manual_seed(123)
+    R, V = 40, 50000
+    s = torch.randn(R, V, generator=g)
+    s[3] = torch.randint(0, 3, (V,), generator=g).float()          # > 1024 candidates -> list kernel redoes the row
+    s[4, ::2] = float('-inf')
+    s[5, 100:200] = float('nan')
+    s[6] = torch.softmax(s[6] * 3, -1)                             # a probability row
+    s[7, :] = s[7, 0]                                              # all equal
+    sd = s.to(dtype).cuda()
+    labels = torch.randint(0, V, (R,), generator=g).int().cuda()
+    for k in (1, 10, 16):
+        ops.topk_threshold = True
+        i1, h1, n1 = ops.topk_rows(sd, V, k, labels)
+        ops.topk_threshold = False
+        try:
+            i0, h0, n0 = ops.topk_rows(sd, V, k, labels)
+        finally:
+            ops.topk_threshold = True
+        assert torch.equal(i1, i0) and torch.equal(h1, h0) and torch.equal(n1, n0), k
+        ref = sd.float().cpu().numpy()
+        ref = np.where(np.isnan(ref), -np.inf, ref)
+        _, want = nr.top_k(ref, k)
+        rows = [r for r in range(R) if r != 5]                     # NaNs never enter a list; the restatement has no NaN rule
+        assert np.array_equal(i1.cpu().numpy()[rows], want[rows])
