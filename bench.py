@@ -59,8 +59,15 @@ def parse():
     ap.add_argument('--ops_flags', default='', help='A/B switches of bert4clickpath_amd.ops, e.g. "fused_ln=0,sorted_embed_bwd=0"')
     ap.add_argument('--materialised_logits', action='store_true',
                     help='A/B: vocabulary projection writes the (R x V) logits and the CE reads them (ops.flash_ce = False)')
+    ap.add_argument('--config', default='c2', choices=['c2', 'c4'], help='c2 = BASELINE.json configs[1] (default, the metric\'s workload); '
+                    'c4 = configs[3]: items(192) + actions(64) concatenated -> d_model 256, 4 heads, 6 layers, vocab 100,000')
+    ap.add_argument('--action_dim', type=int, default=0, help='second feature (actions) embedding dim, part of d_model; 0 = single feature')
+    ap.add_argument('--action_vocab', type=int, default=1000)
     ap.add_argument('--traffic_json', default=None, help='optional JSON with PMC-derived HBM bytes per launch')
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config == 'c4':
+        a.vocab, a.d_model, a.layers, a.heads, a.action_dim = 100000, 256, 6, 4, 64
+    return a
 
 
 def build_model(a, device):
@@ -68,7 +75,10 @@ def build_model(a, device):
     torch.manual_seed(1234)
     vocab = ['i%d' % i for i in range(a.vocab)]
     head = SoftMaxHead([1024, 512, 256, 128], a.vocab)
-    model = ClickstreamTransformer({'items': ['asin']}, {'items': vocab}, {'items': a.d_model}, head,
+    chains, vocabs, dims = {'items': ['asin']}, {'items': vocab}, {'items': a.d_model - a.action_dim}
+    if a.action_dim > 0:      # second feature, concatenated on the last axis (reference transformer.py:384-388)
+        chains['actions'], vocabs['actions'], dims['actions'] = ['act'], ['a%d' % i for i in range(a.action_vocab)], a.action_dim
+    model = ClickstreamTransformer(chains, vocabs, dims, head,
                                    value_to_head='[MASK]', num_encoder_layers=a.layers, num_attention_heads=a.heads,
                                    dropout_rate=a.dropout,
                                    compute_dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
@@ -95,9 +105,13 @@ def make_batches(a, rank, device):
     from bert4clickpath_amd import input_pipeline
     out = []
     for j in range(a.n_batches):
-        b = input_pipeline.synthetic_cloze_batch(a.batch, a.seq, a.vocab, seed=4321 + rank + 1000 * j)
+        b = input_pipeline.synthetic_cloze_batch(a.batch, a.seq, a.vocab, seed=4321 + rank + 1000 * j,
+                                                 n_extra_features=1 if a.action_dim > 0 else 0, extra_vocab=a.action_vocab)
         ids = torch.from_numpy(b['ids'])
-        out.append({'items': ids[:, 2:a.seq - 1].contiguous().to(device),
+        feats = {'asin': ids[:, 2:a.seq - 1].contiguous().to(device)}
+        if a.action_dim > 0:
+            feats['act'] = torch.from_numpy(b['extra'][0])[:, 2:a.seq - 1].contiguous().to(device)
+        out.append({'feats': feats, 'items': feats['asin'],
                     'flat_idx': torch.from_numpy(b['flat_idx']).to(device),
                     'labels': torch.from_numpy(b['labels']).to(device),
                     'labels_padded': torch.from_numpy(b['labels_padded']).to(device),      # (B, 10) float32, -1 = pad
@@ -183,7 +197,7 @@ def eval_leg(model, batches, a, peak_tf):
     def score(i):
         b = batches[i % len(batches)]
         with torch.no_grad():
-            probs = model({'asin': b['items']}, training=False, max_matches=10)       # (B, 10, V), no host sync
+            probs = model(b['feats'], training=False, max_matches=10)       # (B, 10, V), no host sync
             rec.update_state(b['labels_padded'], probs)
             ndcg.update_state(b['labels_padded'], probs)
     for i in range(2):
@@ -238,9 +252,9 @@ def main():
         opt.zero_grad()
         reducer.begin_backward()
         if a.host_flat_idx:
-            loss = model.cloze_loss({'asin': b['items']}, b['labels'], training=True, flat_idx=b['flat_idx'])
+            loss = model.cloze_loss(b['feats'], b['labels'], training=True, flat_idx=b['flat_idx'])
         else:       # device-side index generation + label compaction, cap = 10 rows per sequence, no host sync
-            loss = model.cloze_loss({'asin': b['items']}, b['labels_padded'], training=True, max_masked_per_row=10)
+            loss = model.cloze_loss(b['feats'], b['labels_padded'], training=True, max_masked_per_row=10)
         loss.backward()
         reducer.finish()
         opt.step(reducer.grad_mul)
@@ -299,9 +313,11 @@ def main():
             'dtype': 'bf16' if a.dtype == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BERT4Rec Cloze training step: vocab=%d seq_len=%d d_model=%d layers=%d heads=%d dff=100 '
                                    'head=[1024,512,256,128]->V batch=%d seq/GPU x %d GPU, 10 masked/seq, dropout=%.2f, Zipf(1.1) ids, '
-                                   '%d resident batches, [MASK] indices %s'
+                                   '%d resident batches, [MASK] indices %s%s'
                                    % (a.vocab, a.seq, a.d_model, a.layers, a.heads, a.batch, world, a.dropout, len(batches),
-                                      'precomputed on the host' if a.host_flat_idx else 'generated on the device inside the step'),
+                                      'precomputed on the host' if a.host_flat_idx else 'generated on the device inside the step',
+                                      '; two concatenated features items(%d)+actions(%d, vocab %d)' % (a.d_model - a.action_dim, a.action_dim, a.action_vocab)
+                                      if a.action_dim > 0 else ''),
                        'global_batch': a.batch * world, 'seq_len': a.seq, 'parallelism': 'dp%d' % world,
                        'grad_reduce': 'sum (reference semantics)'},
             'tokens_per_s': a.batch * world * a.seq * a.steps / dt,
@@ -311,7 +327,7 @@ def main():
         }
         if world == 1 and a.eval_steps > 0:
             out['eval'] = eval_leg(model, batches, a, peak_tf)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.action_dim == 0:
             out['cpu_baseline'] = cpu_baseline(a)
         print(json.dumps(out))
     if world > 1:

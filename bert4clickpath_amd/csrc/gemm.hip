@@ -445,16 +445,178 @@ __global__ void __launch_bounds__(256, 3) gemm_nt_ln_kernel(const bf16_t *__rest
     }
 }
 
+// The same for 128 < N <= 256 (config 4: d_model = 256): a workgroup owns 64 whole rows x 256 columns (4 waves side by
+// side along N, each 64 x 64), the B tile is 256 weight rows per K stage.  32 consecutive lanes own one row in the
+// epilogue (8 columns each): the lane layout and summation order of add_ln_fwd_kernel<bf16, 32>, so z / out / stats
+// are again bit-identical to gemm_nt followed by add_ln_fwd.
+#define LN2_TM 64
+#define LN2_TN 256
+#define LN2_STAGE_BYTES ((LN2_TM + LN2_TN) * LDS_STRIDE)     // 46,080: three workgroups per CU
+#define LN2_OUT_STRIDE 520                                   // bytes per staged output row: 512 + 8
+
+__device__ __forceinline__ void ln2_load_a(const bf16_t *__restrict__ P, int ld, int row0, int nrows, int k0, int K, int tid, u32x4 (&reg)[2]) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(P + (int64_t)row0 * ld, (int64_t)nrows - row0, LN2_TM, (int64_t)ld * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * 256;
+        const int row = c >> 3, gk = k0 + (c & 7) * 8;
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((row * ld + gk) * 2) | oob_if(gk >= K), 0, 0);
+    }
+}
+__device__ __forceinline__ void ln2_load_b(const bf16_t *__restrict__ P, int ld, int nrows, int k0, int K, int tid, u32x4 (&reg)[8]) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(P, (int64_t)nrows, LN2_TN, (int64_t)ld * 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + i * 256;
+        const int row = c >> 3, gk = k0 + (c & 7) * 8;
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((row * ld + gk) * 2) | oob_if(gk >= K), 0, 0);
+    }
+}
+template <int NR> __device__ __forceinline__ void ln2_store(char *s, int tid, const u32x4 (&reg)[NR]) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int c = tid + i * 256;
+        *reinterpret_cast<u32x4 *>(s + (c >> 3) * LDS_STRIDE + (c & 7) * 16) = reg[i];
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_nt_ln256_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ Bt, int ldb,
+                                                            const float *__restrict__ bias, const bf16_t *__restrict__ x, int ldx,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            bf16_t *__restrict__ z, bf16_t *__restrict__ out, float *__restrict__ stats,
+                                                            int M, int N, int K, float eps, float rate, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sA = smem, *sB = smem + LN2_TM * LDS_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * LN2_TM;
+    f32x16 acc[2][2];     // acc[j][i]: rows = n (tile j of the wave's 64 columns), col = m (tile i of the 64 rows)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+    const int nk = (K + 63) / 64;
+    u32x4 xa[2], xb[8];
+    ln2_load_a(A, lda, m0, M, 0, K, tid, xa);
+    ln2_load_b(Bt, ldb, N, 0, K, tid, xb);
+    // epilogue chunk q of this thread: row (tid >> 5) + 8 q of the tile, columns 8 (tid & 31) ...
+    const int part = tid & 31, col = part * 8;
+    float bv[8], gv[8], be[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { bv[k] = 0.f; gv[k] = 0.f; be[k] = 0.f; }
+    if (col < N) {
+        if (bias) Vec8<float>::load(bias + col, bv);
+        Vec8<float>::load(gamma + col, gv);
+        Vec8<float>::load(beta + col, be);
+    }
+    ln2_store<2>(sA, tid, xa);
+    ln2_store<8>(sB, tid, xb);
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t xrs = tile_rsrc(x + (int64_t)m0 * ldx, (int64_t)M - m0, LN2_TM, (int64_t)ldx * 2);
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            ln2_load_a(A, lda, m0, M, (kt + 1) * 64, K, tid, xa);
+            ln2_load_b(Bt, ldb, N, (kt + 1) * 64, K, tid, xb);
+        } else {
+            // the eight residual chunks of this thread ride under the last stage's MFMAs (xb is idle by now)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                xb[q] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ((((tid >> 5) + 8 * q) * ldx + col) * 2) | oob_if(col >= N), 0, 0);
+        }
+        mma_stage<bf16_t>(sB, sA, wave, 0, r, h, acc);
+        __syncthreads();
+        if (more) {
+            ln2_store<2>(sA, tid, xa);
+            ln2_store<8>(sB, tid, xb);
+            __syncthreads();
+        }
+    }
+    // acc[j][i] register t: n = wave*64 + j*32 + (t&3) + 8*(t>>2) + 4*h, m = i*32 + r  ->  LDS [m][n] bf16
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+                bf16x4_t w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = (bf16_t)acc[j][i][4 * tq + k];
+                *reinterpret_cast<bf16x4_t *>(smem + (i * 32 + r) * LN2_OUT_STRIDE + (wave * 64 + j * 32 + 8 * tq + 4 * h) * 2) = w;
+            }
+    __syncthreads();
+    const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
+    const float inv_d = 1.0f / (float)N;
+#pragma unroll 2
+    for (int q = 0; q < 8; ++q) {
+        const int row = (tid >> 5) + 8 * q;
+        const int64_t grow = m0 + row;
+        const bool on = grow < M && col < N;     // rows are uniform over their 32 lanes
+        float v[8];
+        float sum = 0.f;
+        if (on) {
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(smem + row * LN2_OUT_STRIDE + part * 16);
+            const u32x2 hi = *reinterpret_cast<const u32x2 *>(smem + row * LN2_OUT_STRIDE + part * 16 + 8);
+            const u32x4 w4 = {lo[0], lo[1], hi[0], hi[1]};
+            const bf16x8 cv = __builtin_bit_cast(bf16x8, w4);
+            const bf16x8 xv = __builtin_bit_cast(bf16x8, xb[q]);
+            const uint32_t km = rate > 0.f ? b4c_keep8(seed, (uint64_t)(grow * N + col), b4c_keep_threshold(rate)) : 0xFFu;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float yy = (float)(bf16_t)((float)cv[k] + bv[k]);      // the bf16 y that gemm_nt would have stored
+                if (rate > 0.f) yy = ((km >> k) & 1u) ? yy * inv_keep : 0.f;
+                v[k] = (float)xv[k] + yy;
+                sum += v[k];
+            }
+            if (z) Vec8<bf16_t>::store_sel<B4C_NT(B4C_NT_GEMMLN_Z)>(z + grow * N + col, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+        const float mean = group_sum<32>(sum) * inv_d;
+        float sq = 0.f;
+        if (on) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float dlt = v[k] - mean;
+                sq += dlt * dlt;
+            }
+        }
+        const float var = group_sum<32>(sq) * inv_d;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (on) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (v[k] - mean) * rstd * gv[k] + be[k];
+            Vec8<bf16_t>::store_sel<B4C_NT(B4C_NT_GEMMLN_OUT)>(out + grow * N + col, o);
+            if (part == 0 && stats) {
+                stats[grow * 2] = mean;
+                stats[grow * 2 + 1] = rstd;
+            }
+        }
+    }
+}
+
 extern "C" int b4c_gemm_nt_add_ln(const void *A, int lda, const void *Bt, int ldb, const float *bias, const void *x, int ldx,
                                   const float *gamma, const float *beta, void *z, void *out, float *stats, int M, int N, int K,
                                   float eps, float dropout_rate, uint64_t seed, int dtype, void *stream) {
     B4C_REQUIRE(A && Bt && x && gamma && beta && out, "gemm_nt_add_ln: null pointer");     // z / stats may be NULL (inference)
     B4C_REQUIRE(dtype == B4C_BF16, "gemm_nt_add_ln: bf16 only (dtype %d)", dtype);
-    B4C_REQUIRE(M > 0 && N > 0 && N <= TILE && N % 8 == 0 && K > 0 && K % 8 == 0, "gemm_nt_add_ln: M=%d N=%d K=%d (N <= 128, N, K %% 8 == 0)", M, N, K);
+    B4C_REQUIRE(M > 0 && N > 0 && N <= LN2_TN && N % 8 == 0 && K > 0 && K % 8 == 0, "gemm_nt_add_ln: M=%d N=%d K=%d (N <= 256, N, K %% 8 == 0)", M, N, K);
     B4C_REQUIRE(lda >= K && ldb >= K && ldx >= N && lda % 8 == 0 && ldb % 8 == 0 && ldx % 8 == 0, "gemm_nt_add_ln: pitches");
     B4C_REQUIRE(((((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)x | (uintptr_t)z | (uintptr_t)out) & 15) == 0) &&
                 ((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)bias) & 15) == 0), "gemm_nt_add_ln: operands must be 16-byte aligned");
     B4C_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f, "gemm_nt_add_ln: dropout_rate %f", (double)dropout_rate);
+    if (N > TILE) {
+        const int grid2 = (M + LN2_TM - 1) / LN2_TM;
+        gemm_nt_ln256_kernel<<<grid2, 256, LN2_STAGE_BYTES, (hipStream_t)stream>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, bias,
+                                                                                   (const bf16_t *)x, ldx, gamma, beta, (bf16_t *)z,
+                                                                                   (bf16_t *)out, stats, M, N, K, eps, dropout_rate, seed);
+        return b4c_check_launch("gemm_nt_add_ln256");
+    }
     const int grid = (M + TILE - 1) / TILE;
     gemm_nt_ln_kernel<<<grid, 256, STAGE_BYTES, (hipStream_t)stream>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, bias,
                                                                        (const bf16_t *)x, ldx, gamma, beta, (bf16_t *)z,

@@ -111,7 +111,7 @@ int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void *C, int ld
                 const float *bias, int act, const void *gate, int ldg, const void *residual, int ldr,
                 int dtype, int out_dtype, void *stream);
 
-/* R9/R10 fused with the GEMM that feeds them (bf16, N <= 128):
+/* R9/R10 fused with the GEMM that feeds them (bf16, N <= 256; N > 128 runs 64-row x 256-column workgroups):
  *   y = A . Bt^T + bias;  z = x + dropout(y);  out = LayerNorm(z) * gamma + beta;  stats = (mean, rstd)
  * == b4c_gemm_nt followed by b4c_add_dropout_layernorm_fwd, bit for bit, without y in HBM.
  * z / out [M][N] bf16 (pitch N), stats [M][2] fp32, x pitch ldx. */

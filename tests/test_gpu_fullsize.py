@@ -153,3 +153,116 @@ def test_c2_logits_free_head_agrees_with_the_materialised_head(gpu):
     assert rel(dh, dh_m) < 2e-2 and rel(dW, dW_m) < 2e-2 and rel(db, db_m) < 2e-2
     ign = (y < 0)
     assert float(item[ign].abs().max()) == 0.0 and float(dh[ign].float().abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------
+# config 4 (BASELINE.json configs[3]): two features -- items (V = 100,000, dim 192) + actions (V = 1,000, dim 64) embedded
+# separately and CONCATENATED (reference transformer.py:384-388) -> d_model 256, 4 heads, 6 layers, S = 200
+# ------------------------------------------------------------------------------------------------------------
+def _c4_model(dtype, layers=6, Vi=100000, Va=1000, dropout=0.0, seed=1234):
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    torch.manual_seed(seed)
+    return ClickstreamTransformer({'items': ['asin'], 'actions': ['act']},
+                                  {'items': ['i%d' % i for i in range(Vi)], 'actions': ['a%d' % i for i in range(Va)]},
+                                  {'items': 192, 'actions': 64}, SoftMaxHead([1024, 512, 256, 128], Vi), value_to_head='[MASK]',
+                                  num_encoder_layers=layers, num_attention_heads=4, dropout_rate=dropout, compute_dtype=dtype).cuda()
+
+
+def _c4_batch(B, S, Vi, Va, seed):
+    from bert4clickpath_amd import input_pipeline
+    b = input_pipeline.synthetic_cloze_batch(B, S, Vi, seed=seed, n_extra_features=1, extra_vocab=Va)
+    ids = torch.from_numpy(b['ids']).cuda()
+    acts = torch.from_numpy(b['extra'][0]).cuda()
+    return b, ids, acts
+
+
+def test_c4_full_size_properties_bf16(gpu):
+    """Config 4 at its full size (B = 2048 sequences here: 409,600 tokens x d = 256, 6 layers, V = 100,000): properties that
+    do not need an oracle run -- pad independence, probabilities sum to 1, top-10 == stable argsort, fused GEMM + LayerNorm
+    (the 256-wide kernel) == the two-kernel route bit for bit inside the model, finite gradients, loss near log V."""
+    from bert4clickpath_amd import ops
+    Vi, Va, S, B = 100000, 1000, 200, 2048
+    model = _c4_model(torch.bfloat16)
+    assert model.transformer.d_model == 256
+    b, ids, acts = _c4_batch(B, S, Vi, Va, seed=77)
+    items, act_items = ids[:, 2:S - 1].contiguous(), acts[:, 2:S - 1].contiguous()
+    feats = {'items': ids, 'actions': acts}
+    with torch.no_grad():
+        enc, key_pad = model.transformer(feats, False, None, return_key_pad=True)
+        assert enc.shape == (B, S, 256) and bool(torch.isfinite(enc.float()).all())
+        assert torch.equal(key_pad.cpu(), (ids == 0).to(torch.uint8).cpu())     # the FIRST feature defines the mask (:377-381)
+        ops.fused_ln = False
+        try:
+            enc_two = model.transformer(feats, False, None)
+        finally:
+            ops.fused_ln = True
+        assert torch.equal(enc, enc_two)                                         # 256-wide fused kernel == gemm_nt + add_ln
+        emb = model.transformer.embedding_layers['items'].weight
+        saved = emb[0].clone()
+        emb[0] += 0.5
+        ops.bump_weights_epoch()
+        enc2 = model.transformer(feats, False, None)
+        emb[0] = saved
+        real = (ids != 0)
+        assert torch.equal(enc[real], enc2[real]) and not torch.equal(enc[~real], enc2[~real])
+        flat = torch.from_numpy(b['flat_idx']).cuda()
+        rows = ops.gather_rows(enc.reshape(B * S, 256), flat[:1024].contiguous(), 1024)
+        logits = model.head.logits(rows, out_fp32=True)
+        probs = ops.softmax_rows(logits, Vi)
+        assert float((probs[:, :Vi].sum(-1) - 1).abs().max()) < 1e-4
+        top, _, _ = ops.topk_rows(logits, Vi, 10)
+        _, want = nr.top_k(logits[:, :Vi].cpu().numpy(), 10)
+        assert np.array_equal(top.cpu().numpy(), want)
+    labels = torch.from_numpy(b['labels_padded']).cuda()
+    loss = model.cloze_loss({'asin': items, 'act': act_items}, labels, training=True, max_masked_per_row=10)
+    assert abs(float(loss) - np.log(Vi)) < 0.5
+    loss.backward()
+    for n, p in model.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+    assert float(model.transformer.embedding_layers['actions'].weight.grad.abs().sum()) > 0
+
+
+def test_c4_shape_matches_oracle_fp32_and_bf16(gpu):
+    """d = 256 / H = 4 / two concatenated features at a small batch: fp32 path against the fp64 oracle (probabilities 1e-6,
+    loss 1e-5, gradients 2e-4 relative); bf16 path (fused 256-wide GEMM + LN kernels) within the documented bf16 bars."""
+    from oracle import torch_ref as tr
+    Vi, Va, S, B = 300, 20, 24, 6
+    b, ids, acts = _c4_batch(B, S, Vi, Va, seed=5)
+    items, act_items = ids[:, 2:S - 1].contiguous(), acts[:, 2:S - 1].contiguous()
+    labels = torch.from_numpy(b['labels_padded']).cuda()
+    m32 = _c4_model(torch.float32, layers=2, Vi=Vi, Va=Va, seed=9)
+    with torch.no_grad():
+        for n, p in m32.named_parameters():
+            if n.endswith('bias') or n.endswith('beta'):
+                p.normal_(0, 0.05)
+    P = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in m32.state_dict().items() if 'pos_encoding' not in k}
+    tP = {k[len('transformer.'):]: v for k, v in P.items() if k.startswith('transformer.')}
+    hP = {k[len('head.'):]: v for k, v in P.items() if k.startswith('head.')}
+    enc = tr.transformer_forward({'items': ids.cpu(), 'actions': acts.cpu()}, tP, 2, 4)
+    rows, _ = tr.gather_masked_rows(enc, ids.cpu())
+    rprobs = torch.softmax(tr.softmax_head_logits(rows, hP, 4), -1)
+    ref = tr.sparse_ce_tf(rprobs, torch.from_numpy(b['labels']).long()).mean()
+    ref.backward()
+    probs = m32({'asin': items, 'act': act_items}, training=False)
+    got = probs.reshape(-1, Vi)[labels.reshape(-1) != -1]
+    assert float((got.cpu().double() - rprobs.detach()).abs().max()) < 1e-6
+    loss = m32.cloze_loss({'asin': items, 'act': act_items}, labels, training=True)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5
+    for n, p in m32.named_parameters():
+        gr = P[n].grad
+        if float(gr.abs().max()) < 1e-9:
+            continue
+        assert float((p.grad.cpu().double() - gr).abs().max()) < 2e-4 * float(gr.abs().max()), n
+    m16 = _c4_model(torch.bfloat16, layers=2, Vi=Vi, Va=Va, seed=9)
+    m16.load_state_dict(m32.state_dict())
+    l16 = m16.cloze_loss({'asin': items, 'act': act_items}, labels, training=True)
+    l16.backward()
+    assert abs(float(l16) - float(ref)) < 5e-3 * float(ref)
+    worst = 0.0
+    for n, p in m16.named_parameters():
+        gr = P[n].grad
+        if float(gr.abs().max()) < 1e-9:
+            continue
+        worst = max(worst, float((p.grad.cpu().double() - gr).norm() / gr.norm()))
+    assert worst < 0.2, worst       # bf16 carries 8 significant bits; the q / k projections of a 2-layer toy model are the noisiest

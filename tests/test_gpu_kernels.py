@@ -440,7 +440,10 @@ def test_errors_are_loud(ops):
 
 
 @pytest.mark.parametrize('M,N,K,rate', [(300, 128, 128, 0.1), (129, 128, 104, 0.0), (77, 64, 64, 0.2), (1, 128, 128, 0.5),
-                                        (4096, 128, 256, 0.1)])
+                                        (4096, 128, 256, 0.1),
+                                        # config 4 (d_model = 256): the 64-row x 256-column kernel
+                                        (300, 256, 256, 0.1), (65, 256, 104, 0.0), (1, 256, 256, 0.5), (4100, 256, 104, 0.1),
+                                        (130, 192, 192, 0.2)])
 def test_gemm_nt_add_ln_is_bit_identical_to_the_two_kernels(ops, M, N, K, rate):
     """b4c_gemm_nt_add_ln == b4c_gemm_nt followed by b4c_add_dropout_layernorm_fwd (transformer.py:204-213), bit for bit."""
     rng = np.random.default_rng(M + N + K)
