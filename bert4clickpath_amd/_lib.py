@@ -74,6 +74,8 @@ def lib():
             'b4c_pack_weights_batched': (i32, [vp, i32, i32, i32, vp]),
             'b4c_attn_fwd': (i32, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
             'b4c_attn_bwd': (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+            'b4c_attn_bwd_workspace_bytes': (i64, [i32, i32, i32, i32, i32]),
+            'b4c_attn_bwd_ws': (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
             'b4c_add_dropout_layernorm_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, u64, i32, vp]),
             'b4c_add_dropout_layernorm_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, i32, vp]),
             'b4c_mask_positions': (i32, [vp, i32, i32, i64, vp, vp, vp, i32, vp, vp]),

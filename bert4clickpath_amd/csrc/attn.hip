@@ -245,7 +245,18 @@ int b4c_attn_fwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, void 
                       int H, int dh, hipStream_t st);
 int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const void *o, int ld_o, const void *d_o,
                       int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B, int S, int H, int dh,
-                      hipStream_t st);
+                      void *workspace, int64_t workspace_bytes, hipStream_t st);
+int64_t b4c_attn_bwd_mfma_workspace_bytes(int B, int S, int H, int dh);
+
+// bf16 shapes the MFMA kernels do not cover (S > 512 or head depth 16 / 128) run on the fp32-math row kernels, which are
+// several times slower: say so once per process instead of degrading silently.
+static void note_row_fallback(const char *who, int S, int dh) {
+    static bool said = false;
+    if (said) return;
+    said = true;
+    fprintf(stderr, "[b4c] %s: bf16 attention with S=%d, head depth %d is outside the MFMA kernels (S <= 512, depth 32 / 64); "
+                    "using the fp32-math row kernels (exact, several times slower).  This notice is printed once.\n", who, S, dh);
+}
 
 static int check_attn(const char *who, int ld_qkv, int ld_o, int B, int S, int H, int dh) {
     B4C_REQUIRE(B > 0 && S > 0 && H > 0 && dh > 0, "%s: bad shape", who);
@@ -281,6 +292,7 @@ extern "C" int b4c_attn_fwd(const void *qkv, int ld_qkv, const uint8_t *key_pad,
     if (dtype == B4C_BF16 && !force_row()) {
         rc = b4c_attn_fwd_mfma(qkv, ld_qkv, key_pad, o, ld_o, lse, B, S, H, dh, st);
         if (rc != B4C_EUNSUPPORTED) return rc;
+        note_row_fallback("attn_fwd", S, dh);
     }
     const float sq = sqrtf((float)dh);
     dim3 grid((S + 255) / 256, B * H);
@@ -293,17 +305,29 @@ extern "C" int b4c_attn_fwd(const void *qkv, int ld_qkv, const uint8_t *key_pad,
     return b4c_check_launch("attn_fwd");
 }
 
+extern "C" int64_t b4c_attn_bwd_workspace_bytes(int B, int S, int H, int dh, int dtype) {
+    return dtype == B4C_BF16 ? b4c_attn_bwd_mfma_workspace_bytes(B, S, H, dh) : 0;
+}
+
 extern "C" int b4c_attn_bwd(const void *qkv, int ld_qkv, const uint8_t *key_pad, const void *o, int ld_o,
                             const void *d_o, int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B,
                             int S, int H, int dh, int dtype, void *stream) {
+    return b4c_attn_bwd_ws(qkv, ld_qkv, key_pad, o, ld_o, d_o, ld_do, lse, delta, dqkv, ld_dqkv, B, S, H, dh, nullptr, 0, dtype, stream);
+}
+
+extern "C" int b4c_attn_bwd_ws(const void *qkv, int ld_qkv, const uint8_t *key_pad, const void *o, int ld_o,
+                               const void *d_o, int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B,
+                               int S, int H, int dh, void *workspace, int64_t workspace_bytes, int dtype, void *stream) {
     B4C_REQUIRE(qkv && key_pad && o && d_o && lse && delta && dqkv, "attn_bwd: null pointer");
     int rc = check_attn("attn_bwd", ld_qkv, ld_o, B, S, H, dh);
     if (rc) return rc;
     B4C_REQUIRE(ld_do >= H * dh && ld_do % 8 == 0 && ld_dqkv >= 3 * H * dh && ld_dqkv % 8 == 0, "attn_bwd: bad pitch");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == B4C_BF16 && !force_row()) {
-        rc = b4c_attn_bwd_mfma(qkv, ld_qkv, key_pad, o, ld_o, d_o, ld_do, lse, delta, dqkv, ld_dqkv, B, S, H, dh, st);
+        rc = b4c_attn_bwd_mfma(qkv, ld_qkv, key_pad, o, ld_o, d_o, ld_do, lse, delta, dqkv, ld_dqkv, B, S, H, dh, workspace,
+                               workspace_bytes, st);
         if (rc != B4C_EUNSUPPORTED) return rc;
+        note_row_fallback("attn_bwd", S, dh);
     }
     const float sq = sqrtf((float)dh);
     dim3 grid((S + 255) / 256, B * H);

@@ -99,10 +99,11 @@ __device__ __forceinline__ bf16x8 frag_tr(const char *p, int second_off) {
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 // ------------------------------------------------------------------------------------------
-// forward: 512 threads, wave w owns query tile w (S <= 256 -> at most 8 tiles)
+// forward: 512 threads, wave w owns query tiles w, w + 8, ... (QPW of them: S <= 256 QPW; QPW = 2 covers S <= 512, where
+// the K / V images of one (sequence, head) take 147 KB of LDS and one workgroup runs per CU)
 // ------------------------------------------------------------------------------------------
-template <int DH>
-__global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
+template <int DH, int QPW>
+__global__ void __launch_bounds__(512, (QPW == 1 ? 4 : 2)) attn_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
                                                             bf16_t *__restrict__ o, int ld_o, float *__restrict__ lse, int S, int H,
                                                             float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -123,19 +124,22 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__r
 
     // every global load of the workgroup is issued up front: the key-padding byte (unconditional on a clamped index: a
     // conditional load behind the staging barrier was an exposed round trip), Q fragments, then K / V rows
-    const uint8_t r_padk = key_pad[tok0 + (tid < S ? tid : S - 1)];       // S_pad <= 256 < 512 threads
-    const int qrow = wave * 32 + r;
-    const bool qvalid = wave < nkt && qrow < S;
-    bf16x8 qf[NKS];
+    const uint8_t r_padk = key_pad[tok0 + (tid < S ? tid : S - 1)];       // S_pad <= 512 = threads
+    bf16x8 qf[QPW][NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (qvalid) v = *reinterpret_cast<const u32x4 *>(qkv + (tok0 + qrow) * ld + hh * DH + ks * 16 + hf * 8);
-        qf[ks] = __builtin_bit_cast(bf16x8, v);
+    for (int qi = 0; qi < QPW; ++qi) {
+        const int qrow = (wave + 8 * qi) * 32 + r;
+        const bool qvalid = wave + 8 * qi < nkt && qrow < S;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (qvalid) v = *reinterpret_cast<const u32x4 *>(qkv + (tok0 + qrow) * ld + hh * DH + ks * 16 + hf * 8);
+            qf[qi][ks] = __builtin_bit_cast(bf16x8, v);
+        }
     }
-    if (tid < ATT_MAX_KT) sLive[tid] = 0;
+    if (tid < ATT_MAX_KT * QPW) sLive[tid] = 0;
     {
-        constexpr int NIT = (256 * CH + 511) / 512;
+        constexpr int NIT = (256 * QPW * CH + 511) / 512;
         u32x4 rk[NIT], rv[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -165,13 +169,12 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__r
         if (live) sLive[k >> 5] = 1;     // benign race: every writer stores 1
     }
     __syncthreads();
-    const bool active = wave < nkt;     // wave-uniform
     // Fully padded key tiles contribute exp(-1e9 - m) == 0 and are skipped -- unless the sequence has no
     // unmasked key at all (never the case for chained inputs: [CLS]/[SEP] are real tokens), where the
     // reference's softmax degenerates to uniform weights: then every tile is processed.
     int any_live = 0;
 #pragma unroll
-    for (int kt = 0; kt < ATT_MAX_KT; ++kt) any_live |= (kt < nkt) ? sLive[kt] : 0;
+    for (int kt = 0; kt < ATT_MAX_KT * QPW; ++kt) any_live |= (kt < nkt) ? sLive[kt] : 0;
     const int force = !any_live;
 
     // Online softmax over the key tiles (one 32 x 32 score tile live at a time instead of all of them: ~100 registers,
@@ -179,86 +182,100 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_mfma_kernel(const bf16_t *__r
     // -- with l and O rescaled -- only when a score exceeds it by 2^12 (after the first live tile that is rare), so
     // the usual per-tile rescale of O disappears.  The two lanes of a query (key halves) share m: their P values
     // meet in the same PV MFMA.
-    float m = -INFINITY, l = 0.f;
-    f32x16 oacc[NDT];
+    float m[QPW], l[QPW];
+    f32x16 oacc[QPW][NDT];
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) oacc[dt][t] = 0.f;
-    for (int kt = 0; kt < (active ? nkt : 0); ++kt) {
-        if (!(sLive[kt] | force)) continue;       // wave-uniform
-        f32x16 acc;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sK + (kt * 32 + r) * KSTR + ks * 32 + hf * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
-        }
-        float tm = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            acc[t] = __builtin_fmaf(acc[t], scale2, sMask[kt * 32 + rowmap(t, hf)]);
-            tm = fmaxf(tm, acc[t]);
-        }
-        tm = fmaxf(tm, __shfl_xor(tm, 32));
-        const bool raise = tm > m + 12.0f;
-        if (__any(raise)) {
-            if (raise) {
-                const float al = __builtin_amdgcn_exp2f(m - tm);      // 0 at the first live tile (m = -inf)
-                m = tm;
-                l *= al;
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) oacc[dt][t] *= al;
-            }
-        }
-        const float mref = (m == -INFINITY) ? 0.f : m;                 // a tile of -inf scores only: p = 0
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            acc[t] = __builtin_amdgcn_exp2f(acc[t] - mref);
-            l += acc[t];
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            float pv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pv[j] = acc[8 * s2 + j];
-            const bf16x8 pf = pack8(pv);
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                // V^T[dh = dt*32 + r][keys kt*32 + 16 s2 + 4 hf + {0..3, 8..11}] from row-major V
-                const char *vb = sV + (kt * 32 + 16 * s2 + 4 * hf + (li >> 2)) * KSTR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
-                const bf16x8 vf = frag_tr(vb, 8 * KSTR);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
-            }
-        }
-    }
-    l += __shfl_xor(l, 32);
-    // O^T (dh on the registers, query on the lane) -> row-major bf16 through the wave's slice of the K image (dead once
-    // every wave has left the key loop), then whole 16-B chunks: full rows per store instruction instead of 8 B per lane
-    // scattered over 32 rows.
-    B4C_LDS_BARRIER();
-    if (active) {
-        const float inv = 1.0f / l;
-        char *st = smem + wave * (32 * KSTR);
+    for (int qi = 0; qi < QPW; ++qi) {
+        m[qi] = -INFINITY;
+        l[qi] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int tq = 0; tq < 4; ++tq) {
-                bf16x4 w;
+            for (int t = 0; t < 16; ++t) oacc[qi][dt][t] = 0.f;
+    }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(oacc[dt][4 * tq + j] * inv);
-                *reinterpret_cast<bf16x4 *>(st + r * KSTR + (dt * 32 + 8 * tq + 4 * hf) * 2) = w;
+    for (int qi = 0; qi < QPW; ++qi) {
+        const bool active = wave + 8 * qi < nkt;     // wave-uniform
+        for (int kt = 0; kt < (active ? nkt : 0); ++kt) {
+            if (!(sLive[kt] | force)) continue;       // wave-uniform
+            f32x16 acc;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sK + (kt * 32 + r) * KSTR + ks * 32 + hf * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][ks], acc, 0, 0, 0);
+            }
+            float tm = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                acc[t] = __builtin_fmaf(acc[t], scale2, sMask[kt * 32 + rowmap(t, hf)]);
+                tm = fmaxf(tm, acc[t]);
+            }
+            tm = fmaxf(tm, __shfl_xor(tm, 32));
+            const bool raise = tm > m[qi] + 12.0f;
+            if (__any(raise)) {
+                if (raise) {
+                    const float al = __builtin_amdgcn_exp2f(m[qi] - tm);      // 0 at the first live tile (m = -inf)
+                    m[qi] = tm;
+                    l[qi] *= al;
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) oacc[qi][dt][t] *= al;
+                }
+            }
+            const float mref = (m[qi] == -INFINITY) ? 0.f : m[qi];                 // a tile of -inf scores only: p = 0
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                acc[t] = __builtin_amdgcn_exp2f(acc[t] - mref);
+                l[qi] += acc[t];
             }
 #pragma unroll
-        for (int i = 0; i < 32 * CH / 64; ++i) {
-            const int c = lane + 64 * i, row = c / CH, part = c % CH;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(st + row * KSTR + part * 16);
-            if (wave * 32 + row < S) att_store16<B4C_NT(B4C_NT_ATTN_O)>(o + (tok0 + wave * 32 + row) * ld_o + hh * DH + part * 8, v);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = acc[8 * s2 + j];
+                const bf16x8 pf = pack8(pv);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    // V^T[dh = dt*32 + r][keys kt*32 + 16 s2 + 4 hf + {0..3, 8..11}] from row-major V
+                    const char *vb = sV + (kt * 32 + 16 * s2 + 4 * hf + (li >> 2)) * KSTR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
+                    const bf16x8 vf = frag_tr(vb, 8 * KSTR);
+                    oacc[qi][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[qi][dt], 0, 0, 0);
+                }
+            }
         }
-        if (qvalid && hf == 0 && lse) lse[((int64_t)b * H + hh) * S + qrow] = (m + __log2f(l)) * 0.6931471805599453f;
+        l[qi] += __shfl_xor(l[qi], 32);
+    }
+    // O^T (dh on the registers, query on the lane) -> row-major bf16 through this query tile's slice of the K image (dead
+    // once every wave has left the key loops), then whole 16-B chunks: full rows per store instruction instead of 8 B per
+    // lane scattered over 32 rows.
+    B4C_LDS_BARRIER();
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi) {
+        const int qt = wave + 8 * qi;
+        if (qt < nkt) {
+            const float inv = 1.0f / l[qi];
+            char *st = smem + qt * (32 * KSTR);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    bf16x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(oacc[qi][dt][4 * tq + j] * inv);
+                    *reinterpret_cast<bf16x4 *>(st + r * KSTR + (dt * 32 + 8 * tq + 4 * hf) * 2) = w;
+                }
+#pragma unroll
+            for (int i = 0; i < 32 * CH / 64; ++i) {
+                const int c = lane + 64 * i, row = c / CH, part = c % CH;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(st + row * KSTR + part * 16);
+                if (qt * 32 + row < S) att_store16<B4C_NT(B4C_NT_ATTN_O)>(o + (tok0 + qt * 32 + row) * ld_o + hh * DH + part * 8, v);
+            }
+            const int qrow = qt * 32 + r;
+            if (qrow < S && hf == 0 && lse) lse[((int64_t)b * H + hh) * S + qrow] = (m[qi] + __log2f(l[qi])) * 0.6931471805599453f;
+        }
     }
 }
 
@@ -271,12 +288,18 @@ template <int DH>
 __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
                                                             const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o,
                                                             int ld_do, const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
-                                                            int ld_dq, int S, int H, float scale) {
+                                                            int ld_dq, int S, int H, float scale, int key0, float *__restrict__ dq_acc,
+                                                            int acc_mode) {
+    // Sequences longer than 256 run this kernel once per block of 256 keys (key0 = 0, 256, ...): a launch owns the dK / dV
+    // rows of its keys and the part of dQ that sums over them.  acc_mode 0: dQ is complete, written as bf16; 1: first
+    // block, the partial dQ goes to dq_acc (fp32 [B*S][H*DH]); 2: middle block, dq_acc += partial; 3: last block,
+    // dQ = bf16(dq_acc + partial).  Every launch streams all the query tiles.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSTR = DH * 2 + 16;
     constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8;
     constexpr int QBUF = 2 * 32 * KSTR + 256;          // sQ | sdO | lse[32] | delta[32]
-    const int nkt = (S + 31) >> 5, S_pad = nkt * 32;
+    const int nqt = (S + 31) >> 5;                                   // query tiles: the whole sequence
+    const int nkt = min(ATT_MAX_KT, (S - key0 + 31) >> 5), S_pad = nkt * 32;     // key tiles of this launch
     const int TSTR = S_pad * 2 + 16;
     char *sK = smem;
     char *sV = sK + S_pad * KSTR;
@@ -329,9 +352,9 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__rest
     for (int c = tid; c < S_pad * CH; c += 512) {
         const int row = c / CH, part = c % CH;
         u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (row < S) {
-            kv = *reinterpret_cast<const u32x4 *>(kbase + (int64_t)row * ld + part * 8);
-            vv = *reinterpret_cast<const u32x4 *>(vbase + (int64_t)row * ld + part * 8);
+        if (key0 + row < S) {
+            kv = *reinterpret_cast<const u32x4 *>(kbase + (int64_t)(key0 + row) * ld + part * 8);
+            vv = *reinterpret_cast<const u32x4 *>(vbase + (int64_t)(key0 + row) * ld + part * 8);
         }
         *reinterpret_cast<u32x4 *>(sK + row * KSTR + part * 16) = kv;
         *reinterpret_cast<u32x4 *>(sV + row * KSTR + part * 16) = vv;
@@ -340,7 +363,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__rest
 
     // this wave's key tile; the lane's key inside it is r
     const int kt = wave;
-    const int key = kt * 32 + r;
+    const int key = key0 + kt * 32 + r;
     const bool key_live = kt < nkt && key < S && !key_pad[tok0 + key];
     const float madd = (kt >= nkt || key >= S) ? -INFINITY : (key_live ? 0.f : -1e9f);
     const bool tile_live = __any(key_live);           // ballot over the wave's 64 lanes (both halves hold the same keys)
@@ -351,12 +374,12 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__rest
         for (int t = 0; t < 16; ++t) { dk[dt][t] = 0.f; dv[dt][t] = 0.f; }
     __syncthreads();
 
-    for (int qt = 0; qt < nkt; ++qt) {
+    for (int qt = 0; qt < nqt; ++qt) {
         const int q0 = qt * 32;
         char *cur = sQB + (qt & 1) * QBUF;
         const char *sQ = cur, *sdO = cur + 32 * KSTR;
         const float *sLse = reinterpret_cast<const float *>(cur + 2 * 32 * KSTR), *sDelta = sLse + 32;
-        const bool more = qt + 1 < nkt;
+        const bool more = qt + 1 < nqt;
         if (more) prefetch(q0 + 32);
         if (kt < nkt) {
             if (tile_live) {
@@ -415,7 +438,15 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__rest
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int q = q0 + qi * 16 + 4 * g + t;
-                if (q < S) dqkv[(tok0 + q) * ld_dq + hh * DH + di * 16 + li] = (bf16_t)(qa[t] * scale);
+                if (q < S) {
+                    float v = qa[t] * scale;
+                    if (acc_mode != 0) {
+                        float *ap = dq_acc + (tok0 + q) * (int64_t)dm + hh * DH + di * 16 + li;
+                        if (acc_mode >= 2) v += *ap;
+                        if (acc_mode <= 2) *ap = v;
+                    }
+                    if (acc_mode == 0 || acc_mode == 3) dqkv[(tok0 + q) * ld_dq + hh * DH + di * 16 + li] = (bf16_t)v;
+                }
             }
         }
         if (more) commit(sQB + ((qt + 1) & 1) * QBUF);
@@ -696,28 +727,55 @@ static int att_num_cus() {
     }
     return n;
 }
-static bool mfma_shape_ok(int S, int dh) { return (dh == 32 || dh == 64) && S <= 32 * ATT_MAX_KT; }
+#define ATT_MAX_S 512      // two query tiles per wave in the forward; key blocks of 256 in the backward
+static bool mfma_shape_ok(int S, int dh) { return (dh == 32 || dh == 64) && S <= ATT_MAX_S; }
 
 int b4c_attn_fwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, void *o, int ld_o, float *lse, int B, int S,
                       int H, int dh, hipStream_t st) {
     if (!mfma_shape_ok(S, dh)) return B4C_EUNSUPPORTED;
     const int S_pad = (S + 31) / 32 * 32;
-    const size_t shm = 2 * (size_t)S_pad * (dh * 2 + 16) + (size_t)S_pad * 4 + ATT_MAX_KT * 4;
+    const int qpw = S_pad > 32 * ATT_MAX_KT ? 2 : 1;
+    const size_t shm = 2 * (size_t)S_pad * (dh * 2 + 16) + (size_t)S_pad * 4 + ATT_MAX_KT * qpw * 4;
     const float scale = 1.0f / sqrtf((float)dh);
-    if (dh == 64) {
-        allow_lds_attn(attn_fwd_mfma_kernel<64>, shm);
-        attn_fwd_mfma_kernel<64><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (bf16_t *)o, ld_o, lse, S, H, scale);
-    } else {
-        allow_lds_attn(attn_fwd_mfma_kernel<32>, shm);
-        attn_fwd_mfma_kernel<32><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (bf16_t *)o, ld_o, lse, S, H, scale);
-    }
+#define ATT_FWD_LAUNCH(DHH, QQ)                                                                                          \
+    do {                                                                                                                 \
+        allow_lds_attn(attn_fwd_mfma_kernel<DHH, QQ>, shm);                                                              \
+        attn_fwd_mfma_kernel<DHH, QQ><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (bf16_t *)o, ld_o, lse, S, H, scale); \
+    } while (0)
+    if (dh == 64) { if (qpw == 1) ATT_FWD_LAUNCH(64, 1); else ATT_FWD_LAUNCH(64, 2); }
+    else { if (qpw == 1) ATT_FWD_LAUNCH(32, 1); else ATT_FWD_LAUNCH(32, 2); }
+#undef ATT_FWD_LAUNCH
     return b4c_check_launch("attn_fwd_mfma");
+}
+
+int64_t b4c_attn_bwd_mfma_workspace_bytes(int B, int S, int H, int dh) {
+    if (!mfma_shape_ok(S, dh) || S <= 32 * ATT_MAX_KT) return 0;
+    return (int64_t)B * S * H * dh * (int64_t)sizeof(float);       // fp32 dQ accumulator across the key blocks
 }
 
 int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const void *o, int ld_o, const void *d_o,
                       int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B, int S, int H, int dh,
-                      hipStream_t st) {
+                      void *workspace, int64_t workspace_bytes, hipStream_t st) {
     if (!mfma_shape_ok(S, dh)) return B4C_EUNSUPPORTED;
+    const float scale_s = 1.0f / sqrtf((float)dh);
+    if (S > 32 * ATT_MAX_KT) {
+        // one launch per block of 256 keys; the partial dQ sums meet in an fp32 accumulator (caller's workspace)
+        if (!workspace || workspace_bytes < b4c_attn_bwd_mfma_workspace_bytes(B, S, H, dh)) return B4C_EUNSUPPORTED;
+        const size_t kstr2 = dh * 2 + 16, tstr2 = 256 * 2 + 16;
+        const size_t shm2 = 2 * 256 * kstr2 + 2 * (2 * 32 * kstr2 + 256) + 32 * tstr2;
+        const int nblk = (S + 255) / 256;
+        for (int kb = 0; kb < nblk; ++kb) {
+            const int mode = kb == 0 ? 1 : (kb == nblk - 1 ? 3 : 2);
+            if (dh == 64) {
+                allow_lds_attn(attn_bwd_mfma_kernel<64>, shm2);
+                attn_bwd_mfma_kernel<64><<<B * H, 512, shm2, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale_s, kb * 256, (float *)workspace, mode);
+            } else {
+                allow_lds_attn(attn_bwd_mfma_kernel<32>, shm2);
+                attn_bwd_mfma_kernel<32><<<B * H, 512, shm2, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale_s, kb * 256, (float *)workspace, mode);
+            }
+        }
+        return b4c_check_launch("attn_bwd_mfma (key blocks)");
+    }
     const int S_pad = (S + 31) / 32 * 32;
     const size_t kstr = dh * 2 + 16, tstr = S_pad * 2 + 16;
     const size_t shm = 2 * S_pad * kstr + 2 * (2 * 32 * kstr + 256) + 32 * tstr;
@@ -738,10 +796,10 @@ int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const
     }
     if (dh == 64) {
         allow_lds_attn(attn_bwd_mfma_kernel<64>, shm);
-        attn_bwd_mfma_kernel<64><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale);
+        attn_bwd_mfma_kernel<64><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, 0, nullptr, 0);
     } else {
         allow_lds_attn(attn_bwd_mfma_kernel<32>, shm);
-        attn_bwd_mfma_kernel<32><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale);
+        attn_bwd_mfma_kernel<32><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, 0, nullptr, 0);
     }
     return b4c_check_launch("attn_bwd_mfma");
 }

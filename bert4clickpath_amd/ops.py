@@ -360,13 +360,23 @@ def attn_fwd(qkv, key_pad, B, S, H, dh):
     return o, lse
 
 
+_attn_ws = {}
+
+
 def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
+    need = L.lib().b4c_attn_bwd_workspace_bytes(B, S, H, dh, dt_code(qkv.dtype))     # > 0 only for bf16 256 < S <= 512
+    ws = None
+    if need:
+        ws = _attn_ws.get(qkv.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+            _attn_ws[qkv.device] = ws
     with _record('attn_bwd', B * S * 8 * H * dh * qkv.element_size(), 10 * B * S * S * H * dh):
-        L.check(L.lib().b4c_attn_bwd(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), o.stride(0), _p(d_o), d_o.stride(0),
-                                     _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, dt_code(qkv.dtype), _st()),
-                'attn_bwd')
+        L.check(L.lib().b4c_attn_bwd_ws(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), o.stride(0), _p(d_o), d_o.stride(0),
+                                        _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, _p(ws), need,
+                                        dt_code(qkv.dtype), _st()), 'attn_bwd')
     return dqkv
 
 

@@ -225,7 +225,10 @@ def _attn_ref(qkv, pad, B, S, H, dh):
 
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('B,S,H,dh', [(3, 13, 2, 32), (2, 200, 2, 64), (2, 70, 1, 16), (1, 300, 2, 128), (2, 256, 2, 64),
-                                      (3, 32, 1, 64), (2, 33, 4, 32), (5, 53, 2, 32), (2, 129, 3, 64)])
+                                      (3, 32, 1, 64), (2, 33, 4, 32), (5, 53, 2, 32), (2, 129, 3, 64),
+                                      # config 5 lengths: 256 < S <= 512 -- two query tiles per wave in the forward, one backward
+                                      # launch per block of 256 keys (bf16); the fp32 path stays on the exact row kernels
+                                      (2, 512, 4, 64), (3, 257, 2, 64), (2, 300, 2, 32), (1, 481, 1, 64)])
 def test_attention_fwd_bwd(ops, dtype, B, S, H, dh):
     g = torch.Generator().manual_seed(S + dh)
     d = H * dh
@@ -249,6 +252,10 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H, dh):
     # padded keys receive exactly zero dK / dV
     kv_grad = dqkv[:, d:].reshape(B, S, 2 * d)
     assert float(kv_grad[0, S - 4:].abs().max()) == 0.0
+    if dtype == torch.bfloat16 and S > 256 and dh in (32, 64):
+        assert ops.L.lib().b4c_attn_bwd_workspace_bytes(B, S, H, dh, ops.L.BF16) == B * S * H * dh * 4     # the MFMA route ran
+        again = ops.attn_bwd(qd, pad.cuda(), o, dod, lse, B, S, H, dh)
+        assert torch.equal(again, dqkv)              # key blocks are summed in a fixed order
 
 
 def test_attention_bwd_more_items_than_workgroups(ops):
