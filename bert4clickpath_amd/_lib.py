@@ -101,6 +101,11 @@ def lib():
             'b4c_compact_labels': (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp]),
             'b4c_attn_weights': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
             'b4c_transpose_add': (i32, [vp, i32, vp, i32, i32, i32, vp]),
+            'b4c_log_uniform_sample': (i32, [u64, i32, i64, vp, vp, vp]),
+            'b4c_row_dot': (i32, [vp, i32, vp, i32, vp, i64, i32, i32, vp]),
+            'b4c_sampled_ce_fwd_bwd': (i32, [vp, i32, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, vp]),
+            'b4c_scatter_add_1d': (i32, [vp, vp, vp, i64, vp]),
+            'b4c_row_scale_f32': (i32, [vp, i32, vp, vp, i32, i64, i32, i32, vp]),
             'b4c_rows_gather_f32': (i32, [vp, i32, vp, vp, i32, i64, i32, vp]),
             'b4c_rows_scatter_add_f32': (i32, [vp, i32, vp, vp, i32, i64, i32, vp]),
         }

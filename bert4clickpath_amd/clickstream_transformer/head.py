@@ -217,3 +217,73 @@ class ClozeMaskedItemPrediction(SoftMaxHead):
 
     def logits(self, x2d, out_fp32=False):
         return self._project(self.trunk(x2d), out_fp32)
+
+
+class SampledSoftmaxHead(SoftMaxHead):
+    """Large-catalogue masked-item head (BASELINE.json configs[4]: vocab 2M; NOT in the reference):
+    relu(Dense) x n, then an item projection stored VOCABULARY-MAJOR -- ``output_embedding`` (V, K) and
+    ``output_bias`` (V) -- so that its gradient is row-sparse like an embedding table's.
+      training  (cloze_ce under grad): sampled softmax over `num_sampled` shared log-uniform negatives + the true item
+                (tf.nn.sampled_softmax_loss semantics: logQ correction, accidental hits removed); only the sampled and
+                the label rows of the projection are read and receive gradient;
+      scoring   (forward / logits / predict_topk, and cloze_ce without grad): the full softmax over V, as SoftMaxHead.
+    Item ids are assumed sorted by decreasing frequency (the log-uniform sampler's premise).
+    No reference oracle: checked against the build's own fp64 restatement (oracle/numpy_ref.sampled_softmax_loss)."""
+
+    def __init__(self, dense_layer_dims, output_vocab_size, num_sampled=8192, input_dim=None, **kwargs):
+        super().__init__(dense_layer_dims, output_vocab_size, None)
+        self.num_sampled = int(num_sampled)
+        if self.num_sampled % 8:
+            raise ValueError('num_sampled must be a multiple of 8')
+        self.last_samples = None          # (samples int64 [Ns], labels int32 [R]) of the latest sampled step: the touched rows
+        if input_dim is not None:
+            self.build(input_dim)
+
+    def build(self, input_dim):
+        if self._packs is not None:
+            return
+        prev = int(input_dim)
+        for h in self.dense_layer_dims:
+            self.intermediate_layers.append(Dense(prev, h))
+            prev = h
+        V = self.output_vocab_size
+        lim = (6.0 / (prev + V)) ** 0.5                     # glorot uniform of a Dense(prev -> V) kernel
+        self.output_embedding = nn.Parameter(torch.empty(V, prev).uniform_(-lim, lim))
+        self.output_bias = nn.Parameter(torch.zeros(V))
+        self._packs = [ops.PackedLinear([l.kernel], [l.bias]) for l in self.intermediate_layers] + \
+                      [ops.TiedPackedLinear(self.output_embedding, 0, V, self.output_bias)]
+
+    def _built(self):
+        return self._packs is not None
+
+    def _params(self):
+        out = []
+        for l in self.intermediate_layers:
+            out += [l.kernel, l.bias]
+        return out + [self.output_embedding, self.output_bias]
+
+    def _proj(self):
+        return int(self.output_embedding.shape[1]), self.output_embedding, self.output_bias
+
+    def _project(self, h, out_fp32=False):
+        return ops.TiedLogitsFn.apply(h, self.output_embedding, self.output_bias, self._packs[-1], bool(out_fp32))
+
+    def logits(self, x2d, out_fp32=False):
+        return self._project(self.trunk(x2d), out_fp32)
+
+    def touched_rows(self):
+        """Rows of ``output_embedding`` the latest sampled training step touched (for GradReducer.set_touched_rows)."""
+        s, y = self.last_samples
+        return torch.cat([s, y.to(torch.int64).clamp(min=0)])
+
+    def cloze_ce(self, x2d, labels_i32, variant, unit_grad=False, samples=None):
+        if not (torch.is_grad_enabled() and self.num_sampled > 0):
+            return super().cloze_ce(x2d, labels_i32, variant, unit_grad)         # full softmax (evaluation)
+        from .transformer import dropout_seeds
+        h = self.trunk(x2d)
+        if samples is None:
+            samples, logq = ops.log_uniform_sample(dropout_seeds.next(), self.num_sampled, self.output_vocab_size, h.device)
+        else:
+            samples, logq = samples
+        self.last_samples = (samples, labels_i32)
+        return ops.SampledCEFn.apply(h, self.output_embedding, self.output_bias, labels_i32, samples, logq, unit_grad)

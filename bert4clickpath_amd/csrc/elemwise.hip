@@ -468,3 +468,197 @@ extern "C" int b4c_rows_scatter_add_f32(const float *src, int ld_src, const int6
     rows_f32_kernel<true><<<ew_grid(n * (width / 4), 256), 256, 0, (hipStream_t)stream>>>(src, ld_src, idx, dst, ld_dst, n, width);
     return b4c_check_launch("rows_scatter_add_f32");
 }
+
+// ------------------------------------------------------------------------------------------
+// sampled-softmax head (BASELINE.json configs[4]; north_star extension with NO reference counterpart):
+// K shared negatives per step from a log-uniform (Zipfian) sampler WITH replacement over [0, range_max):
+//   P(c) = log((c + 2) / (c + 1)) / log(range_max + 1),   expected count Q(c) = K P(c)
+// (the distribution of tf.random.log_uniform_candidate_sampler; ids are assumed sorted by decreasing frequency).
+// One 24-bit uniform per sample from the counter hash: u = (rand64(seed, i) >> 40) / 2^24,
+//   id = min(range_max - 1, floor(exp(u log(range_max + 1))) - 1),  logq = log(K P(id)).
+// ------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ float b4c_log_uniform_logq(int64_t c, int64_t range_max, int num_sampled) {
+    // log((c + 2) / (c + 1)) as log1p(1 / (c + 1)): the quotient itself is 1 + 5e-7 at c = 2M, below fp32 resolution
+    return logf((float)num_sampled * (log1pf(1.0f / ((float)c + 1.0f)) / logf((float)range_max + 1.0f)));
+}
+
+__global__ void __launch_bounds__(256) log_uniform_sample_kernel(uint64_t seed, int n, int64_t range_max, int64_t *__restrict__ ids,
+                                                                 float *__restrict__ logq) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // double precision: the id is a floor() of an exponential, and a host regenerating the ids must land on the same side
+    const double u = (double)(b4c_rand64(seed, (uint64_t)i) >> 40) * (1.0 / 16777216.0);
+    int64_t c = (int64_t)floor(exp(u * log((double)range_max + 1.0))) - 1;
+    c = c < 0 ? 0 : (c >= range_max ? range_max - 1 : c);
+    ids[i] = c;
+    if (logq) logq[i] = b4c_log_uniform_logq(c, range_max, n);
+}
+
+extern "C" int b4c_log_uniform_sample(uint64_t seed, int n, int64_t range_max, int64_t *ids, float *logq, void *stream) {
+    B4C_REQUIRE(ids && n > 0 && range_max > 0, "log_uniform_sample: bad argument");
+    log_uniform_sample_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(seed, n, range_max, ids, logq);
+    return b4c_check_launch("log_uniform_sample");
+}
+
+// out[r] = sum_c a[r][c] * b[r][c]   (fp32 accumulate; one wave per row; width % 8 == 0)
+template <typename T>
+__global__ void __launch_bounds__(256) row_dot_kernel(const T *__restrict__ a, int lda, const T *__restrict__ b, int ldb,
+                                                      float *__restrict__ out, int64_t R, int width) {
+    const int lane = threadIdx.x & 63;
+    const int cpr = width >> 3;
+    for (int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < R; row += (int64_t)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane; c < cpr; c += 64) {
+            float x[8], y[8];
+            Vec8<T>::load(a + row * lda + c * 8, x);
+            Vec8<T>::load(b + row * ldb + c * 8, y);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += x[k] * y[k];
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[row] = s;
+    }
+}
+
+extern "C" int b4c_row_dot(const void *a, int lda, const void *b, int ldb, float *out, int64_t R, int width, int dtype, void *stream) {
+    B4C_REQUIRE(a && b && out && R >= 0 && width > 0 && width % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "row_dot: bad shape");
+    if (R == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(R, 4);
+    if (dtype == B4C_F32) row_dot_kernel<float><<<grid, 256, 0, st>>>((const float *)a, lda, (const float *)b, ldb, out, R, width);
+    else if (dtype == B4C_BF16) row_dot_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t *)a, lda, (const bf16_t *)b, ldb, out, R, width);
+    else B4C_REQUIRE(false, "row_dot: dtype %d", dtype);
+    return b4c_check_launch("row_dot");
+}
+
+// Sampled-softmax cross-entropy with its backward, in place (tf.nn.sampled_softmax_loss semantics, remove_accidental_hits):
+//   z_j  = Z[r][j]                      j-th shared negative: h . w_s + b_s - logQ(s), already folded in by the GEMM
+//   z_t  = ztrue[r] - logQ(y_r)         true class (ztrue = h . w_y + b_y)
+//   negatives with samples[j] == y_r are removed (-inf);   loss_r = logsumexp(z_t, z_.) - z_t
+//   Z[r][j] <- gs * softmax_j,  dtrue[r] <- gs * (softmax_t - 1);  rows with label < 0 or >= range_max: loss 0, zero gradient.
+template <typename T>
+__global__ void __launch_bounds__(256) sampled_ce_kernel(T *__restrict__ Z, int ld, const float *__restrict__ ztrue,
+                                                         const int64_t *__restrict__ samples, const int32_t *__restrict__ labels,
+                                                         int64_t range_max, float *__restrict__ item_loss, float *__restrict__ dtrue,
+                                                         const float *__restrict__ grad_scale, int64_t R, int K) {
+    __shared__ float buf[4];
+    const int tid = threadIdx.x;
+    const int nch = ld >> 3;
+    const float gs = grad_scale[0];
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        T *zr = Z + row * ld;
+        const int y = labels[row];
+        if (y < 0 || y >= range_max) {
+            for (int c = tid; c < nch; c += 256) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = 0.f;
+                Vec8<T>::store(zr + c * 8, v);
+            }
+            if (tid == 0) { item_loss[row] = 0.f; dtrue[row] = 0.f; }
+            continue;
+        }
+        const float zt = ztrue[row] - b4c_log_uniform_logq(y, range_max, K);
+        float m = zt;
+        for (int c = tid; c < nch; c += 256) {
+            float v[8];
+            Vec8<T>::load(zr + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = c * 8 + k;
+                if (j < K && samples[j] != y) m = fmaxf(m, v[k]);
+            }
+        }
+        m = wave_max(m);
+        __syncthreads();
+        if ((tid & 63) == 0) buf[tid >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(buf[0], buf[1]), fmaxf(buf[2], buf[3]));
+        float s = 0.f;
+        for (int c = tid; c < nch; c += 256) {
+            float v[8];
+            Vec8<T>::load(zr + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = c * 8 + k;
+                if (j < K && samples[j] != y) s += expf(v[k] - m);
+            }
+        }
+        s = ew_block_sum<4>(s, buf) + expf(zt - m);
+        const float inv = 1.0f / s;
+        for (int c = tid; c < nch; c += 256) {
+            float v[8];
+            Vec8<T>::load(zr + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = c * 8 + k;
+                v[k] = (j < K && samples[j] != y) ? gs * expf(v[k] - m) * inv : 0.f;
+            }
+            Vec8<T>::store(zr + c * 8, v);
+        }
+        if (tid == 0) {
+            item_loss[row] = logf(s) + m - zt;
+            dtrue[row] = gs * (expf(zt - m) * inv - 1.0f);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int b4c_sampled_ce_fwd_bwd(void *Z, int ld, const float *ztrue, const int64_t *samples, const int32_t *labels,
+                                      int64_t range_max, float *item_loss, float *dtrue, const float *grad_scale, int64_t R,
+                                      int K, int dtype, void *stream) {
+    B4C_REQUIRE(Z && ztrue && samples && labels && item_loss && dtrue && grad_scale && R >= 0 && K > 0 && range_max > 0,
+                "sampled_ce_fwd_bwd: bad argument");
+    B4C_REQUIRE(ld % 8 == 0 && ld >= K, "sampled_ce_fwd_bwd: pitch");
+    if (R == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)(R < 4096 ? R : 4096);
+    if (dtype == B4C_F32) sampled_ce_kernel<float><<<grid, 256, 0, st>>>((float *)Z, ld, ztrue, samples, labels, range_max, item_loss, dtrue, grad_scale, R, K);
+    else if (dtype == B4C_BF16) sampled_ce_kernel<bf16_t><<<grid, 256, 0, st>>>((bf16_t *)Z, ld, ztrue, samples, labels, range_max, item_loss, dtrue, grad_scale, R, K);
+    else B4C_REQUIRE(false, "sampled_ce_fwd_bwd: dtype %d", dtype);
+    return b4c_check_launch("sampled_ce_fwd_bwd");
+}
+
+// dst[idx[i]] += src[i]  (fp32, float atomics; idx < 0 skipped): bias gradients of the sampled classes
+__global__ void __launch_bounds__(256) scatter_add_1d_kernel(const float *__restrict__ src, const int64_t *__restrict__ idx,
+                                                             float *__restrict__ dst, int64_t n) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        if (idx[i] >= 0) atomicAdd(dst + idx[i], src[i]);
+}
+
+extern "C" int b4c_scatter_add_1d(const float *src, const int64_t *idx, float *dst, int64_t n, void *stream) {
+    B4C_REQUIRE(src && idx && dst && n >= 0, "scatter_add_1d: bad argument");
+    if (n == 0) return B4C_OK;
+    scatter_add_1d_kernel<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(src, idx, dst, n);
+    return b4c_check_launch("scatter_add_1d");
+}
+
+// out[r][:] = scale[r] * src[r][:]  (fp32 out; T in): the true-class rows' gradient dtrue_r * h_r
+template <typename T>
+__global__ void __launch_bounds__(256) row_scale_kernel(const T *__restrict__ src, int ld, const float *__restrict__ scale,
+                                                        float *__restrict__ out, int ld_out, int64_t R, int width) {
+    const int cpr = width >> 3;
+    const int64_t total = R * cpr;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr) << 3;
+        float v[8];
+        Vec8<T>::load(src + r * ld + c, v);
+        const float s = scale[r];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= s;
+        Vec8<float>::store(out + r * ld_out + c, v);
+    }
+}
+
+extern "C" int b4c_row_scale_f32(const void *src, int ld, const float *scale, float *out, int ld_out, int64_t R, int width,
+                                 int dtype, void *stream) {
+    B4C_REQUIRE(src && scale && out && R >= 0 && width > 0 && width % 8 == 0 && ld % 8 == 0 && ld_out % 8 == 0, "row_scale_f32: bad shape");
+    if (R == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(R * (width / 8), 256);
+    if (dtype == B4C_F32) row_scale_kernel<float><<<grid, 256, 0, st>>>((const float *)src, ld, scale, out, ld_out, R, width);
+    else if (dtype == B4C_BF16) row_scale_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t *)src, ld, scale, out, ld_out, R, width);
+    else B4C_REQUIRE(false, "row_scale_f32: dtype %d", dtype);
+    return b4c_check_launch("row_scale_f32");
+}

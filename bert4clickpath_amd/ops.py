@@ -600,17 +600,15 @@ def adam_step_(p, g, m, v, lr_t, beta1, beta2, eps, grad_mul=1.0):
                 'adam_step')
 
 
-def keep_mask(seed, n, rate):
-    """Host regeneration of a dropout keep-mask (tests): element e kept iff b4c_keep(seed, e, rate) --
-    Threefry-2x32, 12 rounds, key = seed, counter = e >> 2, one 16-bit uniform per element (csrc/common.h)."""
+def rand64_host(seed, ctr):
+    """Host restatement of b4c_rand64 (csrc/common.h): Threefry-2x32, 12 rounds, key = seed, counter = ctr (uint64 array)."""
     import numpy as np
     M = np.uint64(0xFFFFFFFF)
 
     def rotl(x, r):
         return ((x << np.uint64(r)) | (x >> np.uint64(32 - r))) & M
 
-    e = np.arange(n, dtype=np.uint64)
-    ctr = e >> np.uint64(2)
+    ctr = np.asarray(ctr, dtype=np.uint64)
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
     k2 = np.uint64(0x1BD11BDA) ^ k0 ^ k1
@@ -624,7 +622,15 @@ def keep_mask(seed, n, rate):
             x1 = rotl(x1, r) ^ x0
         x0 = (x0 + a0) & M
         x1 = (x1 + a1 + np.uint64(j)) & M
-    h = x0 | (x1 << np.uint64(32))
+    return x0 | (x1 << np.uint64(32))
+
+
+def keep_mask(seed, n, rate):
+    """Host regeneration of a dropout keep-mask (tests): element e kept iff b4c_keep(seed, e, rate) --
+    counter = e >> 2, one 16-bit uniform per element (csrc/common.h)."""
+    import numpy as np
+    e = np.arange(n, dtype=np.uint64)
+    h = rand64_host(seed, e >> np.uint64(2))
     u16 = (h >> (np.uint64(16) * (e & np.uint64(3)))) & np.uint64(0xFFFF)
     t = np.float32(rate) * np.float32(65536.0)
     thr = int(t)
@@ -1422,3 +1428,91 @@ class TiedLogitsFn(torch.autograd.Function):
         dtab = torch.zeros(table.shape, dtype=torch.float32, device=h.device)
         transpose_add_(dtab[off:off + pack.N], dWt)
         return dh, dtab, db, None, None
+
+
+# --------------------------------------------------------------------------------------
+# sampled-softmax head (config 5; no reference counterpart)
+# --------------------------------------------------------------------------------------
+def log_uniform_sample(seed, n, range_max, device):
+    """n ids (int64) from the log-uniform sampler over [0, range_max) with replacement, and log Q(id) (fp32)."""
+    ids = torch.empty(n, dtype=torch.int64, device=device)
+    logq = torch.empty(n, dtype=torch.float32, device=device)
+    L.check(L.lib().b4c_log_uniform_sample(int(seed) & 0xFFFFFFFFFFFFFFFF, n, range_max, _p(ids), _p(logq), _st()),
+            'log_uniform_sample')
+    return ids, logq
+
+
+def row_dot(a, b):
+    out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    L.check(L.lib().b4c_row_dot(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), a.shape[0], a.shape[1], dt_code(a.dtype),
+                                _st()), 'row_dot')
+    return out
+
+
+def scatter_add_1d_(dst, idx, src):
+    L.check(L.lib().b4c_scatter_add_1d(_p(src), _p(idx), _p(dst), idx.shape[0], _st()), 'scatter_add_1d')
+
+
+def row_scale_f32(src, scale):
+    out = torch.empty(src.shape[0], src.shape[1], dtype=torch.float32, device=src.device)
+    L.check(L.lib().b4c_row_scale_f32(_p(src), src.stride(0), _p(scale), _p(out), out.stride(0), src.shape[0], src.shape[1],
+                                      dt_code(src.dtype), _st()), 'row_scale_f32')
+    return out
+
+
+class SampledCEFn(torch.autograd.Function):
+    """Sampled-softmax masked-item loss (tf.nn.sampled_softmax_loss semantics: shared log-uniform negatives, logQ
+    correction, accidental hits removed), mean over valid rows.  The vocabulary-major projection table (V, K) is only
+    touched at the sampled and the label rows: its gradient is row-sparse.
+    apply(h [R, K], table (V, K) fp32, bias (V,) fp32, labels_i32 [R], samples int64 [Ns], logq fp32 [Ns], unit_grad)"""
+
+    @staticmethod
+    def forward(ctx, h, table, bias, labels_i32, samples, logq, unit_grad):
+        h = h.contiguous()
+        V, Kd = table.shape
+        Ns = samples.shape[0]
+        valid_m = (labels_i32 >= 0) & (labels_i32 < V)
+        valid = valid_m.sum().to(torch.float32)
+        scale = torch.where(valid > 0, 1.0 / valid.clamp(min=1.0), torch.zeros_like(valid)).reshape(1)
+        tab = table.detach()
+        Ws = rows_gather_f32(tab, samples).to(h.dtype)                               # [Ns, K]
+        bs = (bias.detach()[samples] - logq).contiguous()
+        Z = gemm_nt(h, Ws, Ns, bs)                                                   # negatives' logits, bias - logQ folded in
+        idx_y = torch.where(valid_m, labels_i32, torch.full_like(labels_i32, -1)).to(torch.int64)
+        Wy = rows_gather_f32(tab, idx_y).to(h.dtype)                                 # [R, K], zero rows where ignored
+        ztrue = row_dot(h, Wy) + bias.detach()[idx_y.clamp(min=0)]
+        item = torch.empty(h.shape[0], dtype=torch.float32, device=h.device)
+        dtrue = torch.empty(h.shape[0], dtype=torch.float32, device=h.device)
+        if h.shape[0]:
+            L.check(L.lib().b4c_sampled_ce_fwd_bwd(_p(Z), Z.stride(0), _p(ztrue), _p(samples), _p(labels_i32), V, _p(item),
+                                                   _p(dtrue), _p(scale), h.shape[0], Ns, dt_code(Z.dtype), _st()),
+                    'sampled_ce_fwd_bwd')
+        ctx.save_for_backward(h, Z, dtrue, Ws, Wy, samples, idx_y)
+        ctx.params, ctx.unit_grad = (table, bias), unit_grad
+        return item.sum() * scale[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        h, dZ, dtrue, Ws, Wy, samples, idx_y = ctx.saved_tensors
+        table, bias = ctx.params
+        Kd = h.shape[1]
+        if not ctx.unit_grad:
+            dZ = dZ * g.to(dZ.dtype)
+            dtrue = dtrue * g.to(torch.float32)
+        dh = gemm_nt(dZ, Ws.t().contiguous(), Kd)
+        dh = torch.addcmul(dh, dtrue.to(dh.dtype)[:, None], Wy)
+        dWT, dbs = gemm_tn(h, dZ, Kd, dZ.shape[1])                  # [K, Ns] = h^T dZ, [Ns] = column sums of dZ
+        dWs = torch.zeros(dZ.shape[1], Kd, dtype=torch.float32, device=h.device)
+        transpose_add_(dWs, dWT)
+        dWy = row_scale_f32(h, dtrue)
+        inplace = _inplace_ok(table, bias)
+        tg = table.grad if inplace else torch.zeros(table.shape, dtype=torch.float32, device=h.device)
+        bg = bias.grad if inplace else torch.zeros(bias.shape, dtype=torch.float32, device=h.device)
+        rows_scatter_add_f32_(tg, samples, dWs)
+        rows_scatter_add_f32_(tg, idx_y, dWy)
+        scatter_add_1d_(bg, samples, dbs.contiguous())
+        scatter_add_1d_(bg, idx_y, dtrue.contiguous())
+        if inplace:
+            _ready(table, bias)
+            return dh, None, None, None, None, None, None
+        return dh, tg, bg, None, None, None, None

@@ -334,6 +334,25 @@ int b4c_rows_gather_f32(const float *src, int ld_src, const int64_t *idx, float 
 int b4c_rows_scatter_add_f32(const float *src, int ld_src, const int64_t *idx, float *dst, int ld_dst, int64_t n,
                              int width, void *stream);
 
+/* ---- sampled-softmax head (BASELINE.json configs[4], SURVEY D10: north_star extension, NO reference counterpart) ----
+ * Shared negatives from a log-uniform sampler WITH replacement over [0, range_max): P(c) = log((c+2)/(c+1)) / log(range_max+1)
+ * (the distribution of tf.random.log_uniform_candidate_sampler), expected count Q(c) = n P(c).  Sample i uses the 24-bit
+ * uniform (b4c rand64(seed, i) >> 40) / 2^24, so a host can regenerate the ids.  ids int64 [n], logq fp32 [n] = log Q(id). */
+int b4c_log_uniform_sample(uint64_t seed, int n, int64_t range_max, int64_t *ids, float *logq, void *stream);
+/* out[r] = sum_c a[r][c] b[r][c]  (fp32; width % 8 == 0): the true-class logits h_r . w_{y_r}. */
+int b4c_row_dot(const void *a, int lda, const void *b, int ldb, float *out, int64_t R, int width, int dtype, void *stream);
+/* tf.nn.sampled_softmax_loss semantics (remove_accidental_hits): Z [R][ld] holds the K negatives' logits with bias - logQ
+ * folded in, ztrue[r] = h_r . w_y + b_y; the kernel subtracts logQ(y), drops negatives equal to the row's label, and
+ * writes loss_r = logsumexp(z_true, z_neg) - z_true to item_loss, grad_scale[0] * softmax over the negatives IN PLACE of
+ * Z, and grad_scale[0] * (softmax_true - 1) to dtrue.  Rows with label < 0 or >= range_max are ignored. */
+int b4c_sampled_ce_fwd_bwd(void *Z, int ld, const float *ztrue, const int64_t *samples, const int32_t *labels,
+                           int64_t range_max, float *item_loss, float *dtrue, const float *grad_scale, int64_t R,
+                           int K, int dtype, void *stream);
+/* dst[idx[i]] += src[i] (fp32 atomics, idx < 0 skipped);  out[r][:] = scale[r] * src[r][:] (fp32 out). */
+int b4c_scatter_add_1d(const float *src, const int64_t *idx, float *dst, int64_t n, void *stream);
+int b4c_row_scale_f32(const void *src, int ld, const float *scale, float *out, int ld_out, int64_t R, int width,
+                      int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

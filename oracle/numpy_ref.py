@@ -353,6 +353,28 @@ def tied_item_head(x, params, n_hidden, table, id_offset=10, out_vocab=None, ret
     return (probs, logits) if return_logits else probs
 
 
+def log_uniform_logq(c, range_max, num_sampled):
+    """log of the expected count of class c among num_sampled log-uniform draws with replacement:
+    P(c) = log((c + 2) / (c + 1)) / log(range_max + 1)  (tf.random.log_uniform_candidate_sampler's distribution)."""
+    c = np.asarray(c, dtype=np.float64)
+    return np.log(num_sampled * (np.log((c + 2.0) / (c + 1.0)) / np.log(range_max + 1.0)))
+
+
+def sampled_softmax_loss(h, W, b, labels, samples, range_max):
+    """Sampled-softmax cross-entropy per row, tf.nn.sampled_softmax_loss semantics (extension, NO reference counterpart):
+    logits over [true class, shared negatives], each minus log Q(class); negatives equal to the row's label are removed;
+    loss = logsumexp - true logit.  h (R, K), W (V, K) vocabulary-major, b (V,), labels (R,) int, samples (Ns,) int."""
+    h, W, b = (np.asarray(t, dtype=np.float64) for t in (h, W, b))
+    labels, samples = np.asarray(labels, dtype=np.int64), np.asarray(samples, dtype=np.int64)
+    Ns = samples.shape[0]
+    zt = np.sum(h * W[labels], axis=1) + b[labels] - log_uniform_logq(labels, range_max, Ns)
+    zn = h @ W[samples].T + b[samples][None, :] - log_uniform_logq(samples, range_max, Ns)[None, :]
+    zn = np.where(samples[None, :] == labels[:, None], -np.inf, zn)
+    allz = np.concatenate([zt[:, None], zn], axis=1)
+    m = allz.max(axis=1, keepdims=True)
+    return (m[:, 0] + np.log(np.exp(allz - m).sum(axis=1))) - zt
+
+
 # ----------------------------------------------------------------------------
 # R13/R14  loss  (examples/.../utils.py:56-134; clickstream_transformer/losses.py:31-98)
 # ----------------------------------------------------------------------------

@@ -537,3 +537,115 @@ def test_topk_threshold_kernel_equals_list_kernel(gpu, dtype):
         _, want = nr.top_k(ref, k)
         rows = [r for r in range(R) if r != 5]                     # NaNs never enter a list; the restatement has no NaN rule
         assert np.array_equal(i1.cpu().numpy()[rows], want[rows])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# config 5 enabler: sampled-softmax head -- extension, NO reference oracle (build's own fp64 restatement)
+# ------------------------------------------------------------------------------------------------------------
+def test_log_uniform_sampler_regenerates_on_host_and_follows_its_distribution(gpu):
+    from bert4clickpath_amd import ops
+    n, rng_max = 8192, 200000
+    ids, logq = ops.log_uniform_sample(1234567, n, rng_max, 'cuda')
+    u = (ops.rand64_host(1234567, np.arange(n, dtype=np.uint64)) >> np.uint64(40)).astype(np.float64) / 16777216.0
+    want = np.clip(np.floor(np.exp(u * np.log(rng_max + 1.0))).astype(np.int64) - 1, 0, rng_max - 1)
+    got = ids.cpu().numpy()
+    assert (got == want).mean() > 0.9995 and np.abs(got - want).max() <= 1     # fp64 exp on both sides: a last-bit tie at most
+    assert float(np.abs(logq.cpu().numpy() - nr.log_uniform_logq(got, rng_max, n)).max()) < 1e-4
+    # half of the mass of a log-uniform sampler lies below sqrt(range_max)
+    assert abs(float((ids < int(rng_max ** 0.5)).float().mean()) - 0.5) < 0.03
+    ids2, _ = ops.log_uniform_sample(1234567, n, rng_max, 'cuda')
+    assert torch.equal(ids, ids2) and not torch.equal(ids, ops.log_uniform_sample(7, n, rng_max, 'cuda')[0])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_sampled_softmax_head_matches_fp64_restatement(gpu, dtype):
+    from bert4clickpath_amd import ops, optim
+    from bert4clickpath_amd.clickstream_transformer import SampledSoftmaxHead
+    torch.manual_seed(31)
+    V, Kd, R, Ns = 5000, 64, 37, 256
+    head = SampledSoftmaxHead([48, Kd], V, num_sampled=Ns, input_dim=32).cuda()
+    with torch.no_grad():
+        head.output_bias.normal_(0, 0.3)
+    x = torch.randn(R, 32, device='cuda').to(dtype).requires_grad_(True)
+    labels = torch.randint(0, V, (R,), dtype=torch.int32)
+    labels[:6] = torch.tensor([0, 1, 2, 3, 0, 1])          # frequent ids: accidental hits among the log-uniform negatives
+    labels[9] = -1                                           # ignored row
+    lab = labels.cuda()
+    samples, logq = ops.log_uniform_sample(99, Ns, V, 'cuda')
+    assert int((samples[None, :] == lab[:, None].long()).sum()) > 0       # the accidental-hit branch is exercised
+    loss = head.cloze_ce(x, lab, 0, samples=(samples, logq))
+    (2.0 * loss).backward()
+    # fp64 restatement, differentiable in torch; values checked against the numpy restatement
+    P = {n: p.detach().cpu().double().clone().requires_grad_(True) for n, p in head.named_parameters()}
+    xr = x.detach().cpu().double().requires_grad_(True)
+    h = tr.dense_stack(xr, P, 2)
+    W, b = P['output_embedding'], P['output_bias']
+    keep = labels >= 0
+    yl, s = labels[keep].long(), samples.cpu()
+    zt = (h[keep] * W[yl]).sum(1) + b[yl] - torch.from_numpy(nr.log_uniform_logq(yl.numpy(), V, Ns))
+    zn = h[keep] @ W[s].t() + b[s][None] - torch.from_numpy(nr.log_uniform_logq(s.numpy(), V, Ns))[None]
+    zn = zn.masked_fill(s[None, :] == yl[:, None], float('-inf'))
+    item = torch.logsumexp(torch.cat([zt[:, None], zn], 1), 1) - zt
+    ref = item.mean()
+    (2.0 * ref).backward()
+    item_np = nr.sampled_softmax_loss(h[keep].detach().numpy(), W.detach().numpy(), b.detach().numpy(), yl.numpy(), s.numpy(), V)
+    assert float(np.abs(item_np - item.detach().numpy()).max()) < 1e-10
+    if dtype == torch.float32:
+        assert abs(float(loss) - float(ref)) < 1e-5
+        tol = 2e-4
+    else:
+        assert abs(float(loss) - float(ref)) < 2e-2 * float(ref)
+        tol = 0.1       # bf16 weights, activations and logits (8 significant bits)
+    assert float((x.grad.cpu().double() - xr.grad).norm() / xr.grad.norm()) < tol
+    for n, p in head.named_parameters():
+        gr = P[n].grad
+        assert float((p.grad.cpu().double() - gr).norm() / gr.norm()) < tol, n
+    # the projection gradient is row-sparse: only sampled and label rows are touched
+    touched = torch.zeros(V, dtype=torch.bool)
+    touched[head.touched_rows().cpu()] = True
+    assert float(head.output_embedding.grad.cpu()[~touched].abs().max()) == 0.0
+    assert float(head.output_embedding.grad.cpu()[touched].abs().sum()) > 0
+    # scoring path = full softmax over V, same parameters
+    with torch.no_grad():
+        full = head.cloze_ce(x.detach(), lab, 0)
+        lg = head.logits(x.detach(), out_fp32=True)[:, :V].double().cpu()
+    want = torch.nn.functional.cross_entropy(h.detach() @ W.detach().t() + b.detach(), labels.long().clamp(min=0), reduction='none')[keep].mean()
+    assert abs(float(full) - float(want)) < (1e-4 if dtype == torch.float32 else 3e-2) * float(want)
+    assert float((lg - (h.detach() @ W.detach().t() + b.detach())).abs().max()) < (1e-4 if dtype == torch.float32 else 0.15)
+    # arena mode (in-place, row-sparse scatter into the flat gradient buffer) gives the same gradients
+    g_plain = {n: p.grad.detach().clone() for n, p in head.named_parameters()}
+    opt = optim.Adam(head.parameters())
+    opt.zero_grad()
+    head.cloze_ce(x.detach(), lab, 0, samples=(samples, logq)).backward()
+    for n, p in head.named_parameters():
+        a = 0.5 * g_plain[n].float()
+        assert float((p.grad.float() - a).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2) * float(a.abs().max()) + 1e-9, n
+    ops.inplace_grads = False
+
+
+def test_sampled_head_in_the_model_trains(gpu):
+    """ClickstreamTransformer + SampledSoftmaxHead: a few Adam steps lower the FULL-softmax loss; a fresh sample set per
+    step; predict_topk ranks over all V items."""
+    from bert4clickpath_amd import optim
+    from bert4clickpath_amd.clickstream_transformer import SampledSoftmaxHead
+    V = 400
+    head = SampledSoftmaxHead([32, 64], V, num_sampled=64)
+    model = _model(V=V, d=32, L=1, H=2, dtype=torch.bfloat16, head=head, seed=4)
+    b, items, labels = _batch(16, 21, V, seed=2)
+    opt = optim.Adam(model.parameters(), learning_rate=3e-3)
+    with torch.no_grad():
+        before = float(model.cloze_loss({'asin': items}, labels, training=False))
+    seen = []
+    for _ in range(30):
+        opt.zero_grad()
+        model.cloze_loss({'asin': items}, labels, training=True).backward()
+        seen.append(model.head.last_samples[0].clone())
+        opt.step()
+    with torch.no_grad():
+        after = float(model.cloze_loss({'asin': items}, labels, training=False))
+    assert after < before - 0.5, (before, after)
+    assert not torch.equal(seen[0], seen[1])
+    top, hit, _ = model.predict_topk({'asin': items}, 10, labels)
+    assert top.shape[1] == 10 and float(hit.mean()) > 0.3        # it memorises the one batch it saw
+    from bert4clickpath_amd import ops
+    ops.inplace_grads = False
