@@ -59,22 +59,30 @@ def parse():
     ap.add_argument('--ops_flags', default='', help='A/B switches of bert4clickpath_amd.ops, e.g. "fused_ln=0,sorted_embed_bwd=0"')
     ap.add_argument('--materialised_logits', action='store_true',
                     help='A/B: vocabulary projection writes the (R x V) logits and the CE reads them (ops.flash_ce = False)')
-    ap.add_argument('--config', default='c2', choices=['c2', 'c4'], help='c2 = BASELINE.json configs[1] (default, the metric\'s workload); '
-                    'c4 = configs[3]: items(192) + actions(64) concatenated -> d_model 256, 4 heads, 6 layers, vocab 100,000')
+    ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c5'], help='c2 = BASELINE.json configs[1] (default, the metric\'s workload); '
+                    'c4 = configs[3]: items(192) + actions(64) concatenated -> d_model 256, 4 heads, 6 layers, vocab 100,000; '
+                    'c5 = configs[4], one GPU\'s share: vocab 2,000,000, seq 512, d_model 256, 4 heads, 4 layers, batch 1024, sampled-softmax head '
+                    '(8,192 shared log-uniform negatives; no reference counterpart)')
     ap.add_argument('--action_dim', type=int, default=0, help='second feature (actions) embedding dim, part of d_model; 0 = single feature')
     ap.add_argument('--action_vocab', type=int, default=1000)
     ap.add_argument('--traffic_json', default=None, help='optional JSON with PMC-derived HBM bytes per launch')
     a = ap.parse_args()
     if a.config == 'c4':
         a.vocab, a.d_model, a.layers, a.heads, a.action_dim = 100000, 256, 6, 4, 64
+    a.sampled = 0
+    if a.config == 'c5':
+        a.vocab, a.seq, a.d_model, a.layers, a.heads, a.batch, a.sampled = 2000000, 512, 256, 4, 4, 1024, 8192
+        a.eval_steps = 0          # scoring over 2M items materialises 41 GB of probabilities per batch: not part of this line
+        a.no_cpu_baseline = True
     return a
 
 
 def build_model(a, device):
-    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SampledSoftmaxHead, SoftMaxHead
     torch.manual_seed(1234)
     vocab = ['i%d' % i for i in range(a.vocab)]
-    head = SoftMaxHead([1024, 512, 256, 128], a.vocab)
+    head = SampledSoftmaxHead([1024, 512, 256, 128], a.vocab, num_sampled=a.sampled) if a.sampled else \
+        SoftMaxHead([1024, 512, 256, 128], a.vocab)
     chains, vocabs, dims = {'items': ['asin']}, {'items': vocab}, {'items': a.d_model - a.action_dim}
     if a.action_dim > 0:      # second feature, concatenated on the last axis (reference transformer.py:384-388)
         chains['actions'], vocabs['actions'], dims['actions'] = ['act'], ['a%d' % i for i in range(a.action_vocab)], a.action_dim
@@ -92,6 +100,8 @@ def backward_order(model):
 
     def key(p):
         n = names[id(p)]
+        if n == 'head.output_embedding':       # the sampled head's vocabulary-major projection: row-sparse gradient, kept
+            return (L + 3, n)                  # at the very end of the arena next to the embedding tables (parallel.py)
         if n.startswith('head.'):
             return (0, n)
         if 'enc_layers.' in n:
@@ -242,9 +252,13 @@ def main():
     model = build_model(a, device)
     opt = optim.Adam(model.parameters(), order=backward_order(model))
     arena = opt.arena
-    head_end = max(arena.slice_of(p)[1] for n, p in model.named_parameters() if n.startswith('head.'))
+    head_end = max(arena.slice_of(p)[1] for n, p in model.named_parameters() if n.startswith('head.') and n != 'head.output_embedding')
     emb_start = min(arena.slice_of(p)[0] for n, p in model.named_parameters() if 'embedding_layers' in n)
-    reducer = parallel.GradReducer(arena, bucket_bounds=[head_end, emb_start], reduce='sum')
+    tables = [p for n, p in model.named_parameters() if 'embedding_layers' in n]
+    # config 5: the 2M-row tables' gradients travel as (indices, rows) instead of a 2 GB dense all-reduce
+    sparse = (tables + [model.head.output_embedding]) if (a.sampled and world > 1) else []
+    reducer = parallel.GradReducer(arena, bucket_bounds=[head_end, emb_start], reduce='sum', sparse_params=sparse)
+    specials = torch.tensor([3, 4], device=device)
     batches = make_batches(a, rank, device)
 
     def step(i):
@@ -256,6 +270,10 @@ def main():
         else:       # device-side index generation + label compaction, cap = 10 rows per sequence, no host sync
             loss = model.cloze_loss(b['feats'], b['labels_padded'], training=True, max_masked_per_row=10)
         loss.backward()
+        if sparse:
+            for t, f in zip(tables, b['feats'].values()):
+                reducer.set_touched_rows(t, torch.cat([f.reshape(-1), specials]))
+            reducer.set_touched_rows(model.head.output_embedding, model.head.touched_rows())
         reducer.finish()
         opt.step(reducer.grad_mul)
         return loss
@@ -312,9 +330,11 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if a.dtype == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BERT4Rec Cloze training step: vocab=%d seq_len=%d d_model=%d layers=%d heads=%d dff=100 '
-                                   'head=[1024,512,256,128]->V batch=%d seq/GPU x %d GPU, 10 masked/seq, dropout=%.2f, Zipf(1.1) ids, '
+                                   'head=[1024,512,256,128]->V%s batch=%d seq/GPU x %d GPU, 10 masked/seq, dropout=%.2f, Zipf(1.1) ids, '
                                    '%d resident batches, [MASK] indices %s%s'
-                                   % (a.vocab, a.seq, a.d_model, a.layers, a.heads, a.batch, world, a.dropout, len(batches),
+                                   % (a.vocab, a.seq, a.d_model, a.layers, a.heads,
+                                      ' (sampled softmax, %d shared log-uniform negatives)' % a.sampled if a.sampled else '',
+                                      a.batch, world, a.dropout, len(batches),
                                       'precomputed on the host' if a.host_flat_idx else 'generated on the device inside the step',
                                       '; two concatenated features items(%d)+actions(%d, vocab %d)' % (a.d_model - a.action_dim, a.action_dim, a.action_vocab)
                                       if a.action_dim > 0 else ''),

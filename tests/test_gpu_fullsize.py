@@ -266,3 +266,41 @@ def test_c4_shape_matches_oracle_fp32_and_bf16(gpu):
             continue
         worst = max(worst, float((p.grad.cpu().double() - gr).norm() / gr.norm()))
     assert worst < 0.2, worst       # bf16 carries 8 significant bits; the q / k projections of a 2-layer toy model are the noisiest
+
+
+def test_c5_shape_slice_runs_on_the_mfma_and_sampled_paths(gpu):
+    """Config 5's shape on one GPU at a small batch: vocab 2,000,000 (embedding table HBM-resident, 2 GB fp32), S = 512,
+    d_model 256, 4 heads, sampled-softmax head with 8,192 shared negatives.  Properties: the S = 512 MFMA attention is
+    the path taken (workspace query), the loss starts near log V = 14.5 (with the logQ correction the sampled softmax estimates the full
+    one) and is finite, gradients of both 2M-row tables are row-sparse, one Adam step keeps everything finite."""
+    from bert4clickpath_amd import input_pipeline, ops, optim
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SampledSoftmaxHead
+    V, S, B = 2000000, 512, 24
+    torch.manual_seed(77)
+    head = SampledSoftmaxHead([256, 128], V, num_sampled=8192)
+    model = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': 256}, head,
+                                   value_to_head='[MASK]', num_encoder_layers=2, num_attention_heads=4, dropout_rate=0.1,
+                                   compute_dtype=torch.bfloat16).cuda()
+    assert ops.L.lib().b4c_attn_bwd_workspace_bytes(B, S, 4, 64, ops.L.BF16) == B * S * 256 * 4
+    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=9)
+    ids = torch.from_numpy(b['ids']).cuda()
+    items = ids[:, 2:S - 1].contiguous()
+    labels = torch.from_numpy(b['labels_padded']).cuda()
+    opt = optim.Adam(model.parameters())
+    try:
+        opt.zero_grad()
+        loss = model.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10)
+        loss.backward()
+        assert bool(torch.isfinite(loss)) and 11.0 < float(loss) < 18.0
+        table = model.transformer.embedding_layers['items'].weight
+        touched = torch.zeros(V + 11, dtype=torch.bool, device='cuda')
+        touched[ids.reshape(-1)] = True
+        assert float(table.grad[~touched].abs().max()) == 0.0 and float(table.grad[touched].abs().sum()) > 0
+        t2 = torch.zeros(V, dtype=torch.bool, device='cuda')
+        t2[head.touched_rows()] = True
+        assert int(t2.sum()) <= 8192 + B * 10
+        assert float(head.output_embedding.grad[~t2].abs().max()) == 0.0 and float(head.output_embedding.grad[t2].abs().sum()) > 0
+        opt.step()
+        assert bool(torch.isfinite(opt.arena.flat).all())
+    finally:
+        ops.inplace_grads = False
