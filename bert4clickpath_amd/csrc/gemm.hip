@@ -883,7 +883,7 @@ __device__ __forceinline__ void wide_store(char *s, int tid, const u32x4 (&reg)[
 
 __global__ void __launch_bounds__(512) gemm_nt_wide_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ Bt, int ldb,
                                                            bf16_t *__restrict__ C, int ldc, int M, int N, int K,
-                                                           const float *__restrict__ bias, int mt, int tiles_per_chunk) {
+                                                           const float *__restrict__ bias, int mt, int tiles_per_chunk, int chunks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *sW = smem;                                     // 2 x WIDE_TILE_BYTES
     char *sOut = smem + 2 * WIDE_TILE_BYTES;             // 2 x WOUT_BYTES
@@ -891,12 +891,17 @@ __global__ void __launch_bounds__(512) gemm_nt_wide_kernel(const bf16_t *__restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = wave >> 2;                          // 0 compute, 1 move
     const int rtid = tid & 255;
-    const int m0 = (blockIdx.x % mt) * TILE;
     const int ntn = (N + TILE - 1) / TILE;
-    const int nt0 = (blockIdx.x / mt) * tiles_per_chunk;
-    const int nt1 = min(ntn, nt0 + tiles_per_chunk);
+    // chunks > 0: the `chunks` workgroups of one M tile have consecutive ids (co-resident, the A rows shared in L2) and
+    // walk the N tiles INTERLEAVED (workgroup c takes tiles c, c + chunks, ...): at any moment they extend the same 128
+    // output rows by adjacent 256-B pieces -- longer contiguous runs per row for the write-back than when each workgroup
+    // sweeps a distant column range.  chunks == 0: the first form (one contiguous range of N tiles per workgroup).
+    const int tstep = chunks > 0 ? chunks : 1;
+    const int m0 = (chunks > 0 ? (int)(blockIdx.x / chunks) : (int)(blockIdx.x % mt)) * TILE;
+    const int nt0 = chunks > 0 ? (int)(blockIdx.x % chunks) : (int)(blockIdx.x / mt) * tiles_per_chunk;
+    const int nt1 = chunks > 0 ? ntn : min(ntn, nt0 + tiles_per_chunk);
     if (nt0 >= nt1) return;
-    const int ntiles = nt1 - nt0;
+    const int ntiles = (nt1 - nt0 + tstep - 1) / tstep;
     const int wm = (wave & 3) >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
 
     // One 16 x 16-B register block serves whichever role the wave has (the roles are exclusive; separate arrays
@@ -919,20 +924,21 @@ __global__ void __launch_bounds__(512) gemm_nt_wide_kernel(const bf16_t *__restr
         wide_store_r<0>(sW, rtid, R);
         if (rtid < 128) sBias[rtid] = (bias && nt0 * TILE + rtid < N) ? bias[nt0 * TILE + rtid] : 0.f;
         if (ntiles > 1) {
-            wide_load_r<0>(Bt, ldb, (nt0 + 1) * TILE, N, K, rtid, R);
-            if (rtid < 128 && bias && (nt0 + 1) * TILE + rtid < N) xb = bias[(nt0 + 1) * TILE + rtid];
+            wide_load_r<0>(Bt, ldb, (nt0 + tstep) * TILE, N, K, rtid, R);
+            if (rtid < 128 && bias && (nt0 + tstep) * TILE + rtid < N) xb = bias[(nt0 + tstep) * TILE + rtid];
         }
     }
     __syncthreads();
 
     for (int t = 0; t <= ntiles; ++t) {                  // one extra iteration: the stores trail by one tile
         const int buf = t & 1;
-        const int n0 = (nt0 + t) * TILE;
+        const int n0 = (nt0 + t * tstep) * TILE;
+        const int n2 = n0 + 2 * tstep * TILE;            // the tile two steps ahead
         if (role == 1) {
             if (buf == 0) {          // x (R[0..7]) -> LDS buffer 1, refill y (R[8..15])
                 if (t + 2 < ntiles) {
-                    wide_load_r<8>(Bt, ldb, n0 + 2 * TILE, N, K, rtid, R);
-                    yb = (rtid < 128 && bias && n0 + 2 * TILE + rtid < N) ? bias[n0 + 2 * TILE + rtid] : 0.f;
+                    wide_load_r<8>(Bt, ldb, n2, N, K, rtid, R);
+                    yb = (rtid < 128 && bias && n2 + rtid < N) ? bias[n2 + rtid] : 0.f;
                 }
                 if (t + 1 < ntiles) {
                     wide_store_r<0>(sW + WIDE_TILE_BYTES, rtid, R);
@@ -940,8 +946,8 @@ __global__ void __launch_bounds__(512) gemm_nt_wide_kernel(const bf16_t *__restr
                 }
             } else {                 // y -> LDS buffer 0, refill x
                 if (t + 2 < ntiles) {
-                    wide_load_r<0>(Bt, ldb, n0 + 2 * TILE, N, K, rtid, R);
-                    xb = (rtid < 128 && bias && n0 + 2 * TILE + rtid < N) ? bias[n0 + 2 * TILE + rtid] : 0.f;
+                    wide_load_r<0>(Bt, ldb, n2, N, K, rtid, R);
+                    xb = (rtid < 128 && bias && n2 + rtid < N) ? bias[n2 + rtid] : 0.f;
                 }
                 if (t + 1 < ntiles) {
                     wide_store_r<8>(sW, rtid, R);
@@ -950,7 +956,7 @@ __global__ void __launch_bounds__(512) gemm_nt_wide_kernel(const bf16_t *__restr
             }
             if (t >= 1) {            // tile t-1: rows of 256 B, 16 lanes per row
                 const char *so = sOut + (buf ^ 1) * WOUT_BYTES;
-                const int ns = n0 - TILE;
+                const int ns = n0 - tstep * TILE;
                 const bool interior = (m0 + TILE <= M) && (ns + TILE <= N);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -1010,6 +1016,117 @@ __global__ void __launch_bounds__(512) gemm_nt_wide_kernel(const bf16_t *__restr
 #undef AF
 }
 
+// Second form of the materialised vocabulary projection: 256-thread workgroups, TWO per CU (69 KB of LDS each), every wave
+// computes AND moves; the phases of the two co-resident workgroups overlap (one stores its tile while the other
+// multiplies) instead of two wave roles inside one workgroup.  A fragments stay in registers for the workgroup's
+// whole chunk of N tiles, the next W tile is in flight in registers during the current tile's MFMAs and stores.
+__global__ void __launch_bounds__(256, 2) gemm_nt_wide2_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ Bt, int ldb,
+                                                            bf16_t *__restrict__ C, int ldc, int M, int N, int K,
+                                                            const float *__restrict__ bias, int mt, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sW = smem;
+    char *sOut = smem + WIDE_TILE_BYTES;
+    float *sBias = reinterpret_cast<float *>(smem + WIDE_TILE_BYTES + WOUT_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = (blockIdx.x % mt) * TILE;
+    const int ntn = (N + TILE - 1) / TILE;
+    const int nt0 = (blockIdx.x / mt) * tiles_per_chunk;
+    const int nt1 = min(ntn, nt0 + tiles_per_chunk);
+    if (nt0 >= nt1) return;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    u32x4 R[16];
+#define AF2(i, kk) __builtin_bit_cast(bf16x8, R[(i) * 8 + (kk)])
+    {
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(A + (int64_t)m0 * lda, (int64_t)M - m0, TILE, (int64_t)lda * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int row = wm * 64 + i * 32 + r, col = kk * 16 + h * 8;
+                R[i * 8 + kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((row * lda + col) * 2) | oob_if(col >= K), 0, 0);
+            }
+    }
+    u32x4 pw[8];
+    float pb = 0.f;
+    auto fetch = [&](int nt) {
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(Bt + (int64_t)nt * TILE * ldb, (int64_t)N - (int64_t)nt * TILE, TILE, (int64_t)ldb * 2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + i * 256;
+            const int row = c >> 4, cc = c & 15;
+            pw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((row * ldb + cc * 8) * 2) | oob_if(cc * 8 >= K), 0, 0);
+        }
+        const int col = nt * TILE + (tid & 127);
+        pb = (bias && col < N) ? bias[col] : 0.f;
+    };
+    fetch(nt0);
+    for (int nt = nt0; nt < nt1; ++nt) {
+        const int n0 = nt * TILE;
+        wide_store(sW, tid, pw);
+        if (tid < 128) sBias[tid] = pb;
+        __syncthreads();
+        if (nt + 1 < nt1) fetch(nt + 1);
+        const char *w0 = sW + (wn * 64 + r) * WIDE_STR;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const bf16x8 fw0 = *reinterpret_cast<const bf16x8 *>(w0 + kk * 32 + h * 16);
+            const bf16x8 fw1 = *reinterpret_cast<const bf16x8 *>(w0 + 32 * WIDE_STR + kk * 32 + h * 16);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw0, AF2(0, kk), acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw0, AF2(1, kk), acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw1, AF2(0, kk), acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw1, AF2(1, kk), acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                const int nl = wn * 64 + j * 32 + 8 * tq + 4 * h;
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sBias + nl);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+                    bf16x4_t w;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w[k] = (bf16_t)(acc[j][i][4 * tq + k] + b4[k]);
+                    *reinterpret_cast<bf16x4_t *>(sOut + (wm * 64 + i * 32 + r) * WOUT_STR + nl * 2) = w;
+                }
+            }
+        __syncthreads();
+        const bool interior = (m0 + TILE <= M) && (n0 + TILE <= N);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = tid + q * 256;
+            const int row = c >> 4, pc = c & 15;
+            const int64_t grow = m0 + row;
+            const int gcol = n0 + pc * 8;
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(sOut + row * WOUT_STR + pc * 16);
+            const u32x2 hi = *reinterpret_cast<const u32x2 *>(sOut + row * WOUT_STR + pc * 16 + 8);
+            if (interior || (grow < M && gcol < N)) {
+                const u32x4 w4 = {lo[0], lo[1], hi[0], hi[1]};
+                __builtin_nontemporal_store(w4, reinterpret_cast<u32x4 *>(C + grow * ldc + gcol));
+            }
+        }
+    }
+#undef AF2
+}
+
+static int g_wide_form = -1;
+static int wide_form() {
+    if (g_wide_form < 0) {
+        const char *e = getenv("B4C_WIDE_FORM");
+        g_wide_form = e ? atoi(e) : 1;
+    }
+    return g_wide_form;
+}
+extern "C" void b4c_set_wide_form(int f) { g_wide_form = f; }     // scratch A/B switch (not part of include/b4c.h)
+
 static bool vec_ok_wide(const void *C, int ldc, int N, const float *bias) {
     return (N % 8 == 0) && (ldc % 8 == 0) && (((uintptr_t)C & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
 }
@@ -1035,9 +1152,21 @@ extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void
         if (chunks < 1) chunks = 1;
         const int tpc = (int)ceil_div64(ntn, chunks);
         chunks = (int)ceil_div64(ntn, tpc);
+        if (wide_form() == 2) {
+            int chunks2 = (int)ceil_div64(512 * 5, mt);      // two workgroups per CU resident, ~5 rounds over the launch
+            if (chunks2 > ntn) chunks2 = ntn;
+            if (chunks2 < 1) chunks2 = 1;
+            const int tpc2 = (int)ceil_div64(ntn, chunks2);
+            chunks2 = (int)ceil_div64(ntn, tpc2);
+            const size_t shm2 = WIDE_TILE_BYTES + WOUT_BYTES + 128 * sizeof(float);
+            allow_lds(gemm_nt_wide2_kernel, shm2);
+            gemm_nt_wide2_kernel<<<mt * chunks2, 256, shm2, st_w>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, mt, tpc2);
+            return b4c_check_launch("gemm_nt_wide2");
+        }
         const size_t shm_w = 2 * WIDE_TILE_BYTES + 2 * WOUT_BYTES + 2 * 128 * sizeof(float);
         allow_lds(gemm_nt_wide_kernel, shm_w);
-        gemm_nt_wide_kernel<<<mt * chunks, 512, shm_w, st_w>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, mt, tpc);
+        const int interleave = wide_form() == 3 ? chunks : 0;
+        gemm_nt_wide_kernel<<<mt * chunks, 512, shm_w, st_w>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, mt, tpc, interleave);
         return b4c_check_launch("gemm_nt_wide");
     }
     const int64_t mt_n = ceil_div64(M, TILE), nt_n = ceil_div64(N, TILE);

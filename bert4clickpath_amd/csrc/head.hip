@@ -489,13 +489,118 @@ __global__ void __launch_bounds__(512, 4) softmax_ce_bf16_kernel(bf16_t *__restr
     }
 }
 
+// Rows wider than the register-resident limit (V > 65,536: config 4's 100,000 items on the fp32 / materialised route):
+// the same arithmetic streamed -- max, sum of exponentials, (TF variant) S / Pu, then the gradient in place.  The row
+// (<= 1 MB) is re-read from L2 / Infinity Cache by the workgroup that just read it.
+template <typename T>
+__global__ void __launch_bounds__(1024) softmax_ce_stream_kernel(T *__restrict__ x, int ld, const int32_t *__restrict__ labels,
+                                                                 float *__restrict__ item_loss, const float *__restrict__ grad_scale,
+                                                                 int64_t R, int V, int variant) {
+    __shared__ float buf[16];
+    __shared__ float s_ey;
+    const int tid = threadIdx.x;
+    const int nch_ld = ld >> 3, nch = (V + 7) >> 3;
+    const float gs = grad_scale[0];
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        T *xr = x + row * ld;
+        const int y = labels[row];
+        const bool valid = y >= 0 && y < V;
+        if (!valid) {
+            for (int c = tid; c < nch_ld; c += 1024) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = 0.f;
+                Vec8<T>::store(xr + c * 8, v);
+            }
+            if (tid == 0) item_loss[row] = (y >= V) ? NAN : 0.f;
+            continue;
+        }
+        float m = -INFINITY;
+        for (int c = tid; c < nch; c += 1024) {
+            float v[8];
+            Vec8<T>::load(xr + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c * 8 + k < V) m = fmaxf(m, v[k]);
+        }
+        m = block_max<16>(m, buf);
+        float z = 0.f;
+        for (int c = tid; c < nch; c += 1024) {
+            float v[8];
+            Vec8<T>::load(xr + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c * 8 + k < V) {
+                    const float e = expf(v[k] - m);
+                    z += e;
+                    if (c * 8 + k == y) s_ey = e;
+                }
+        }
+        z = block_sum<16>(z, buf);
+        const float invz = 1.0f / z;
+        const float py = s_ey * invz;
+        float loss = -logf(py), invS = 1.f, G = 0.f, inv_pyc = 1.0f / py;
+        if (variant == B4C_CE_TF) {
+            float S = 0.f, Pu = 0.f;
+            for (int c = tid; c < nch; c += 1024) {
+                float v[8];
+                Vec8<T>::load(xr + c * 8, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c * 8 + k < V) {
+                        const float p = expf(v[k] - m) * invz;
+                        S += fminf(fmaxf(p, KERAS_EPS), 1.0f - KERAS_EPS);
+                        if (p >= KERAS_EPS && p <= 1.0f - KERAS_EPS) Pu += p;
+                    }
+            }
+            S = block_sum<16>(S, buf);
+            Pu = block_sum<16>(Pu, buf);
+            const float pyc = fminf(fmaxf(py, KERAS_EPS), 1.0f - KERAS_EPS);
+            const float uy = (py >= KERAS_EPS && py <= 1.0f - KERAS_EPS) ? 1.f : 0.f;
+            loss = logf(S) - logf(pyc);
+            invS = 1.0f / S;
+            G = Pu * invS - uy * py / pyc;
+            inv_pyc = uy / pyc;
+        }
+        for (int c = tid; c < nch_ld; c += 1024) {
+            float v[8];
+            if (c < nch) Vec8<T>::load(xr + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = c * 8 + k;
+                float g = 0.f;
+                if (j < V) {
+                    const float p = expf(v[k] - m) * invz;
+                    if (variant == B4C_CE_TF) {
+                        const float u = (p >= KERAS_EPS && p <= 1.0f - KERAS_EPS) ? 1.f : 0.f;
+                        g = p * (u * invS - G) - (j == y ? py * inv_pyc : 0.f);
+                    } else {
+                        g = p - (j == y ? 1.f : 0.f);
+                    }
+                }
+                v[k] = g * gs;
+            }
+            Vec8<T>::store(xr + c * 8, v);
+        }
+        if (tid == 0) item_loss[row] = loss;
+        __syncthreads();
+    }
+}
+
 extern "C" int b4c_softmax_ce_fwd_bwd(void *logits, int ld, const int32_t *labels, float *item_loss,
                                       const float *grad_scale, int64_t R, int V, int variant, int dtype, void *stream) {
     B4C_REQUIRE(logits && labels && item_loss && grad_scale && R >= 0 && V > 0, "softmax_ce_fwd_bwd: bad argument");
     B4C_REQUIRE(ld % 8 == 0 && ld >= V, "softmax_ce_fwd_bwd: pitch");
     B4C_REQUIRE(variant == B4C_CE_TF || variant == B4C_CE_PLAIN, "softmax_ce_fwd_bwd: variant %d", variant);
-    B4C_REQUIRE(ld <= 8 * 8 * 1024, "softmax_ce_fwd_bwd: V=%d exceeds the register-resident limit 65536 (use a sampled head)", V);
     if (R == 0) return B4C_OK;
+    if (ld > 8 * 8 * 1024) {      // beyond the register-resident limit: streamed kernel
+        const int gs_ = (int)(R < 2048 ? R : 2048);
+        hipStream_t st_ = (hipStream_t)stream;
+        if (dtype == B4C_F32) softmax_ce_stream_kernel<float><<<gs_, 1024, 0, st_>>>((float *)logits, ld, labels, item_loss, grad_scale, R, V, variant);
+        else if (dtype == B4C_BF16) softmax_ce_stream_kernel<bf16_t><<<gs_, 1024, 0, st_>>>((bf16_t *)logits, ld, labels, item_loss, grad_scale, R, V, variant);
+        else B4C_REQUIRE(false, "softmax_ce_fwd_bwd: dtype %d", dtype);
+        return b4c_check_launch("softmax_ce_stream");
+    }
     const int nch = (int)ceil_div64(ld / 8, 1024);
     const int grid = (int)(R < 2048 ? R : 2048);
     hipStream_t st = (hipStream_t)stream;

@@ -352,7 +352,7 @@ def test_mask_positions_and_gather(ops):
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('V', [37, 1000, 50000, 54293])
+@pytest.mark.parametrize('V', [37, 1000, 50000, 54293, 100000])      # 100,000 (config 4): beyond the register-resident rows
 def test_softmax_and_losses(ops, dtype, V):
     g = torch.Generator().manual_seed(V)
     R, ld = 9, (V + 7) // 8 * 8
