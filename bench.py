@@ -52,6 +52,10 @@ def parse():
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_rows', type=int, default=256, help='sequences in the bounded CPU-baseline sample (SURVEY 8d: B=256)')
     ap.add_argument('--eval_steps', type=int, default=6, help='timed scoring batches (0 = skip the scoring leg)')
+    ap.add_argument('--dense', action='store_true', help='A/B: run the encoder on the padded (B, S) layout as the reference does '
+                    '(default: padding-free layout, pad positions are not computed -- DESIGN.md section 3)')
+    ap.add_argument('--full_length', action='store_true', help='SURVEY 8d no-padding variant: every sequence has 197 items (the packed '
+                    'layout then equals the dense one)')
     ap.add_argument('--host_flat_idx', action='store_true', help='A/B: hand the step host-precomputed [MASK] indices (round-1 bench)')
     ap.add_argument('--record_steps', type=int, default=5,
                     help='timed steps (the first N of the timed region) whose launches are bracketed by HIP events for the roofline; '
@@ -115,7 +119,7 @@ def make_batches(a, rank, device):
     from bert4clickpath_amd import input_pipeline
     out = []
     for j in range(a.n_batches):
-        b = input_pipeline.synthetic_cloze_batch(a.batch, a.seq, a.vocab, seed=4321 + rank + 1000 * j,
+        b = input_pipeline.synthetic_cloze_batch(a.batch, a.seq, a.vocab, seed=4321 + rank + 1000 * j, full_length=a.full_length,
                                                  n_extra_features=1 if a.action_dim > 0 else 0, extra_vocab=a.action_vocab)
         ids = torch.from_numpy(b['ids'])
         feats = {'asin': ids[:, 2:a.seq - 1].contiguous().to(device)}
@@ -125,6 +129,9 @@ def make_batches(a, rank, device):
                     'flat_idx': torch.from_numpy(b['flat_idx']).to(device),
                     'labels': torch.from_numpy(b['labels']).to(device),
                     'labels_padded': torch.from_numpy(b['labels_padded']).to(device),      # (B, 10) float32, -1 = pad
+                    # host-side batch metadata, as the input pipeline has it when it pads (input_pipeline.py:198-214):
+                    # number of non-pad positions of the chained batch ([CLS] [SEP] items [SEP])
+                    'n_real': int((b['ids'] != 0).sum()),
                     'R': int(b['labels'].shape[0])})
     return out
 
@@ -207,7 +214,8 @@ def eval_leg(model, batches, a, peak_tf):
     def score(i):
         b = batches[i % len(batches)]
         with torch.no_grad():
-            probs = model(b['feats'], training=False, max_matches=10)       # (B, 10, V), no host sync
+            probs = model(b['feats'], training=False, max_matches=10, packed=False if a.dense else None,
+                          n_real_tokens=None if a.dense else b['n_real'])       # (B, 10, V), no host sync
             rec.update_state(b['labels_padded'], probs)
             ndcg.update_state(b['labels_padded'], probs)
     for i in range(2):
@@ -266,9 +274,10 @@ def main():
         opt.zero_grad()
         reducer.begin_backward()
         if a.host_flat_idx:
-            loss = model.cloze_loss(b['feats'], b['labels'], training=True, flat_idx=b['flat_idx'])
+            loss = model.cloze_loss(b['feats'], b['labels'], training=True, flat_idx=b['flat_idx'], packed=False)
         else:       # device-side index generation + label compaction, cap = 10 rows per sequence, no host sync
-            loss = model.cloze_loss(b['feats'], b['labels_padded'], training=True, max_masked_per_row=10)
+            loss = model.cloze_loss(b['feats'], b['labels_padded'], training=True, max_masked_per_row=10,
+                                    packed=False if a.dense else None, n_real_tokens=None if a.dense else b['n_real'])
         loss.backward()
         if sparse:
             for t, f in zip(tables, b['feats'].values()):
@@ -331,13 +340,16 @@ def main():
             'dtype': 'bf16' if a.dtype == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BERT4Rec Cloze training step: vocab=%d seq_len=%d d_model=%d layers=%d heads=%d dff=100 '
                                    'head=[1024,512,256,128]->V%s batch=%d seq/GPU x %d GPU, 10 masked/seq, dropout=%.2f, Zipf(1.1) ids, '
-                                   '%d resident batches, [MASK] indices %s%s'
+                                   '%d resident batches, [MASK] indices %s%s; encoder on %s'
                                    % (a.vocab, a.seq, a.d_model, a.layers, a.heads,
                                       ' (sampled softmax, %d shared log-uniform negatives)' % a.sampled if a.sampled else '',
                                       a.batch, world, a.dropout, len(batches),
                                       'precomputed on the host' if a.host_flat_idx else 'generated on the device inside the step',
                                       '; two concatenated features items(%d)+actions(%d, vocab %d)' % (a.d_model - a.action_dim, a.action_dim, a.action_vocab)
-                                      if a.action_dim > 0 else ''),
+                                      if a.action_dim > 0 else '',
+                                      'the padded (B, S) layout' if a.dense else
+                                      'the padding-free layout (%.0f %% of the B x S positions are real tokens)'
+                                      % (100.0 * sum(b['n_real'] for b in batches) / (len(batches) * a.batch * a.seq))),
                        'global_batch': a.batch * world, 'seq_len': a.seq, 'parallelism': 'dp%d' % world,
                        'grad_reduce': 'sum (reference semantics)'},
             'tokens_per_s': a.batch * world * a.seq * a.steps / dt,

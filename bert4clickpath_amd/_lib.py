@@ -106,6 +106,11 @@ def lib():
             'b4c_sampled_ce_fwd_bwd': (i32, [vp, i32, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, vp]),
             'b4c_scatter_add_1d': (i32, [vp, vp, vp, i64, vp]),
             'b4c_row_scale_f32': (i32, [vp, i32, vp, vp, i32, i64, i32, i32, vp]),
+            'b4c_nonpad_positions': (i32, [vp, i32, i32, i64, vp, vp, vp, i32, vp, vp, vp]),
+            'b4c_remap_index': (i32, [vp, vp, vp, i64, vp]),
+            'b4c_embed_concat_pe_fwd_packed': (i32, [i32, pp, pp, c.POINTER(i32), c.POINTER(i64), vp, f32, vp, i32, vp, i32, i32, i32, f32, u64, vp, i64, i32, vp]),
+            'b4c_attn_fwd_varlen': (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+            'b4c_attn_bwd_varlen': (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
             'b4c_rows_gather_f32': (i32, [vp, i32, vp, vp, i32, i64, i32, vp]),
             'b4c_rows_scatter_add_f32': (i32, [vp, i32, vp, vp, i32, i64, i32, vp]),
         }

@@ -144,7 +144,7 @@ class ClickstreamTransformer(nn.Module):
         return flat.reshape(a.shape)
 
     # ---- shared front half: chain, look up, encode -------------------------------------------
-    def _encode(self, inputs, training):
+    def _encode(self, inputs, training, pack=False, n_real_tokens=None):
         raw_features, seg_starts, seg_ends = self.transformer_input_prep(features=inputs)
         dev = self.transformer.pos_encoding.device
         if dev.type != 'cuda':
@@ -158,9 +158,36 @@ class ClickstreamTransformer(nn.Module):
                 x = torch.from_numpy(self.lookup(name, x))
             features[name] = torch.as_tensor(x).to(device=dev, dtype=torch.int64)
         seq = {name: features[name] for name in self.sequential_input_config.keys()}
-        enc, key_pad = self.transformer(seq, training, None, return_key_pad=True)
         first = list(self.sequential_input_config.keys())[0]
+        self._packed = None
+        if pack:
+            # padding-free layout: the encoder runs on the real tokens only (pad keys are masked, pad queries are never read,
+            # their gradient under the Cloze loss is exactly zero -- include/b4c.h "packed token layout")
+            ids0 = seq[first].contiguous()
+            B, S = ids0.shape
+            cap = int(n_real_tokens) if n_real_tokens is not None else B * S
+            _, cu, tok_src, packed_of, _ = ops.nonpad_positions(ids0, cap)
+            T_real = cap if n_real_tokens is not None else int(cu[-1].item())       # the caller's count avoids the read-back
+            self._packed = ops.Packed(cu, tok_src, packed_of, B, S, T_real, S)
+        enc, key_pad = self.transformer(seq, training, None, return_key_pad=True, packed=self._packed)
         return enc, seq[first], raw_features[first], seg_starts, seg_ends
+
+    def _use_packed(self, inputs, packed, n_real_tokens):
+        """packed=None: use the padding-free layout when the caller supplies the real-token count (no read-back needed);
+        True: always (one device read-back for the count when it is not given); False: dense."""
+        if packed is False or self.value_to_head is None:
+            return False
+        if packed is None and n_real_tokens is None:
+            return False
+        first_in = self.sequential_input_config[list(self.sequential_input_config.keys())[0]]
+        x = inputs[first_in[0]]
+        L0 = (x.shape[1] if isinstance(x, torch.Tensor) else np.asarray(x, dtype=object).shape[1])
+        S = sum((inputs[n].shape[1] if isinstance(inputs[n], torch.Tensor) else np.asarray(inputs[n], dtype=object).shape[1])
+                for n in first_in) + len(first_in) + 2
+        ok = self.transformer.packed_supported(S)
+        if packed is True and not ok:
+            raise B4CError('packed=True needs bf16 compute, head depth 32 / 64 and an encoder length <= 512')
+        return ok
 
     def _match_positions(self, ids_first, raw_first, cap=None):
         """Flat (b*S+s) indices, row-major, where the first feature's RAW value == value_to_head."""
@@ -176,12 +203,15 @@ class ClickstreamTransformer(nn.Module):
         return ops.mask_positions(ids_first.contiguous(), int(vid), cap)
 
     # ---- reference call ------------------------------------------------------------------------
-    def forward(self, inputs, training=None, mask=None, max_matches=None):
+    def forward(self, inputs, training=None, mask=None, max_matches=None, packed=None, n_real_tokens=None):
         """inputs: dict feature-name -> (B, Li) strings or int64 ids (+ optional 'instance_id').
-        Returns head_unit(head_input), or {'instance_id', 'logits'} when 'instance_id' is present."""
-        enc, ids_first, raw_first, seg_starts, seg_ends = self._encode(
-            {k: v for k, v in inputs.items() if k != 'instance_id'}, training)
-        B, S, d = enc.shape
+        Returns head_unit(head_input), or {'instance_id', 'logits'} when 'instance_id' is present.
+        packed / n_real_tokens: as in cloze_loss (value_to_head models only)."""
+        feats = {k: v for k, v in inputs.items() if k != 'instance_id'}
+        pack = self._use_packed(feats, packed, n_real_tokens)
+        enc, ids_first, raw_first, seg_starts, seg_ends = self._encode(feats, training, pack, n_real_tokens)
+        B, S = ids_first.shape
+        d = enc.shape[-1]
         if self.segment_to_head is not None:
             head_input = enc[:, seg_starts[self.segment_to_head]:seg_ends[self.segment_to_head], :].contiguous()
         elif self.value_to_head is not None:
@@ -191,7 +221,9 @@ class ClickstreamTransformer(nn.Module):
                 head_input = enc.new_zeros(B, 0, d)
             else:
                 pidx = ops.padded_index(counts, offsets, flat, B, M)
-                head_input = ops.GatherRowsFn.apply(enc.reshape(B * S, d), pidx, B * M).view(B, M, d)
+                if self._packed is not None:
+                    pidx = ops.remap_index(pidx, self._packed.packed_of)
+                head_input = ops.GatherRowsFn.apply(enc.reshape(-1, d), pidx, B * M).view(B, M, d)
         else:
             raise ValueError("One of value_to_head and segment_to_head must be provided.")
         logits = self.head(head_input)
@@ -200,13 +232,14 @@ class ClickstreamTransformer(nn.Module):
         return logits
 
     # ---- fused MI355X entry points ----------------------------------------------------------------
-    def _masked_rows(self, inputs, training, flat_idx=None, cap=None, labels_padded=None):
+    def _masked_rows(self, inputs, training, flat_idx=None, cap=None, labels_padded=None, pack=False, n_real_tokens=None):
         """Encoder output rows at the [MASK] positions, row-major.
         flat_idx given: used as is.  cap given: the sync-free form -- index generation and label compaction stay on
         the device, exactly `cap` rows come back (those beyond the real count R are zero rows whose label is -1) together
-        with the compact int32 labels.  Neither: R is read back from the device (one host sync)."""
-        enc, ids_first, raw_first, _, _ = self._encode(inputs, training)
-        B, S, d = enc.shape
+        with the compact int32 labels.  Neither: R is read back from the device (one host sync).
+        pack: the encoder runs on the padding-free layout; the dense [MASK] indices are mapped to its rows."""
+        enc, ids_first, raw_first, _, _ = self._encode(inputs, training, pack, n_real_tokens)
+        d = enc.shape[-1]
         lab = None
         if flat_idx is None and cap is not None:
             counts, offsets, flat, _ = self._match_positions(ids_first, raw_first, cap)
@@ -216,24 +249,31 @@ class ClickstreamTransformer(nn.Module):
             _, offsets, flat, _ = self._match_positions(ids_first, raw_first)
             R = int(offsets[-1].item())
             flat_idx = flat[:R]
-        rows = ops.GatherRowsFn.apply(enc.reshape(B * S, d), flat_idx, flat_idx.shape[0])
+        if self._packed is not None:
+            flat_idx = ops.remap_index(flat_idx.contiguous(), self._packed.packed_of)
+        rows = ops.GatherRowsFn.apply(enc.reshape(-1, d), flat_idx, flat_idx.shape[0])
         return rows, lab
 
-    def cloze_loss(self, inputs, labels, training=True, flat_idx=None, variant='tf', unit_grad=False, max_masked_per_row=None):
+    def cloze_loss(self, inputs, labels, training=True, flat_idx=None, variant='tf', unit_grad=False, max_masked_per_row=None,
+                   packed=None, n_real_tokens=None):
         """Masked-item training loss == ClozeMaskedLoss(sparse_categorical_crossentropy)(labels, self(inputs)).
         labels: (B, M) float32 padded with -1 (reference format) or compact (R,) int ids in row-major mask order.
         flat_idx (R,) int32 skips the device-side index generation.  max_masked_per_row=M (the pipeline's
         MAX_MASKED_ITEMS, cloze_constants.py:1) selects the sync-free form: [MASK] positions and the labels of the padded
         (B, Mlab) tensor are compacted on the device, the head runs on B*M rows (the unused ones are ignored rows), and no
-        value is read back to the host."""
+        value is read back to the host.
+        n_real_tokens (host int: non-pad positions of the chained batch, which the input pipeline knows when it pads) /
+        packed: run the encoder on the padding-free layout (bf16 throughput path; same loss and gradients, the pad
+        positions' work is not done)."""
+        pack = self._use_packed(inputs, packed, n_real_tokens)
         lab = torch.as_tensor(labels, device=self.transformer.pos_encoding.device)
         if max_masked_per_row is not None and flat_idx is None:
             if lab.dim() != 2:
                 raise ValueError('the sync-free form needs the padded (B, M) labels')
             rows, lab = self._masked_rows(inputs, training, None, cap=int(lab.shape[0]) * int(max_masked_per_row),
-                                          labels_padded=lab)
+                                          labels_padded=lab, pack=pack, n_real_tokens=n_real_tokens)
         else:
-            rows, _ = self._masked_rows(inputs, training, flat_idx)
+            rows, _ = self._masked_rows(inputs, training, flat_idx, pack=pack, n_real_tokens=n_real_tokens)
             if lab.dim() == 2:
                 lab = lab[lab != -1.0]
             lab = lab.to(torch.int32).contiguous()
@@ -245,11 +285,12 @@ class ClickstreamTransformer(nn.Module):
         return ops.FusedSoftmaxCEFn.apply(self.head.logits(rows), lab, self.head.output_vocab_size, code, unit_grad)
 
     @torch.no_grad()
-    def predict_topk(self, inputs, k, labels=None, flat_idx=None):
+    def predict_topk(self, inputs, k, labels=None, flat_idx=None, packed=None, n_real_tokens=None):
         """Top-k item ids (label space) at every masked position, ranked over all V items.  Ranks the
         logits (softmax is monotone); returns (topk_idx (R,k) int32, hit (R,), ndcg (R,)) -- the
         latter two when labels are given."""
-        rows, _ = self._masked_rows(inputs, False, flat_idx)
+        rows, _ = self._masked_rows(inputs, False, flat_idx, pack=self._use_packed(inputs, packed, n_real_tokens),
+                                    n_real_tokens=n_real_tokens)
         logits = self.head.logits(rows, out_fp32=True)
         lab = None
         if labels is not None:

@@ -217,22 +217,32 @@ class EncoderLayer(nn.Module):
     def get_config(self):
         return {'d_model': self.d_model, 'num_heads': self.num_heads, 'dff': self.dff, 'rate': self.rate}
 
-    def forward(self, x, training=None, mask=None):
+    def forward(self, x, training=None, mask=None, packed=None):
+        """x (B, S, d); or, with `packed` (ops.Packed), the (1, T, d) rows of the real tokens only and mask = the (T,) key
+        bytes the embedding stage produced for them."""
         B, S, d = x.shape
         training = bool(training)
-        key_pad = mask if (mask is not None and mask.dtype == torch.uint8 and mask.dim() == 2) else \
-            _mask_to_bytes(mask, B, S, x.device)
-        x2 = x.reshape(B * S, d)
+        cu = None
+        if packed is not None:
+            key_pad, cu = mask, packed.cu
+            x2 = x.reshape(-1, d)
+            out_shape = x.shape
+            B, S = packed.B, packed.max_len
+        else:
+            key_pad = mask if (mask is not None and mask.dtype == torch.uint8 and mask.dim() == 2) else \
+                _mask_to_bytes(mask, B, S, x.device)
+            x2 = x.reshape(B * S, d)
+            out_shape = (B, S, d)
         m, f = self.mha, self.ffn
         s1 = dropout_seeds.next() if training else 0
         s2 = dropout_seeds.next() if training else 0
         need_tape = training or torch.is_grad_enabled()
         out1 = ops.AttnBlockFn.apply(x2, key_pad, m.wq.kernel, m.wq.bias, m.wk.kernel, m.wk.bias, m.wv.kernel, m.wv.bias,
                                      m.dense.kernel, m.dense.bias, self.layernorm1.gamma, self.layernorm1.beta,
-                                     m._pk_qkv, m._pk_o, B, S, self.num_heads, self.rate if training else 0.0, s1, need_tape)
+                                     m._pk_qkv, m._pk_o, B, S, self.num_heads, self.rate if training else 0.0, s1, need_tape, cu)
         out2 = ops.FFNBlockFn.apply(out1, f[0].kernel, f[0].bias, f[1].kernel, f[1].bias, self.layernorm2.gamma,
                                     self.layernorm2.beta, f._pk1, f._pk2, self.rate if training else 0.0, s2, need_tape)
-        return out2.view(B, S, d)
+        return out2.view(out_shape)
 
 
 class Encoder(nn.Module):
@@ -250,13 +260,13 @@ class Encoder(nn.Module):
         return {'num_layers': self.num_layers, 'd_model': self.d_model, 'num_heads': self.num_heads, 'dff': self.dff,
                 'dropout_rate': self.dropout_rate}
 
-    def forward(self, inputs, training=None, mask=None, _input_dropout_done=False):
+    def forward(self, inputs, training=None, mask=None, _input_dropout_done=False, packed=None):
         x = inputs
         if training and self.dropout_rate > 0 and not _input_dropout_done:
             x = ops.DropoutFn.apply(x, float(self.dropout_rate), dropout_seeds.next())
         B, S, d = x.shape
         layers = [{'mha': l.mha, 'ffn': l.ffn, 'ln1': l.layernorm1, 'ln2': l.layernorm2} for l in self.enc_layers]
-        if mask is not None and mask.dtype == torch.uint8 and mask.dim() == 2 and \
+        if packed is None and mask is not None and mask.dtype == torch.uint8 and mask.dim() == 2 and \
                 ops.encoder_stack_supported(x, layers, bool(training), self.dropout_rate):
             # one autograd node for the whole stack: LayerNorm backward runs in GEMM epilogues (ops.EncoderStackFn)
             for lay in layers:
@@ -265,7 +275,7 @@ class Encoder(nn.Module):
                                            float(self.dropout_rate))
             return out.view(B, S, d)
         for layer in self.enc_layers:
-            x = layer(x, training, mask)
+            x = layer(x, training, mask, packed)
         return x
 
 
@@ -325,8 +335,14 @@ class Transformer(nn.Module):
                 'encoder_ff_dim': self.encoder_ff_dim, 'dropout_rate': self.dropout_rate,
                 'item_embedding_weights': self.item_embedding_weights}
 
-    def forward(self, inputs, training=None, mask=None, return_key_pad=False):
-        """inputs: dict feature -> (B,S) int64 ids (first feature defines the padding mask)."""
+    def packed_supported(self, S):
+        """The padding-free layout runs on the bf16 MFMA attention kernels only (head depth 32 / 64, S <= 512)."""
+        dh = self.d_model // self.num_attention_heads
+        return self.compute_dtype == torch.bfloat16 and dh in (32, 64) and S <= 512
+
+    def forward(self, inputs, training=None, mask=None, return_key_pad=False, packed=None):
+        """inputs: dict feature -> (B,S) int64 ids (first feature defines the padding mask).
+        packed (ops.Packed of the first feature's ids): run on the real tokens only -> ((1, T, d) rows, (T,) key bytes)."""
         feats = list(inputs.keys())
         if set(feats) != set(self.embedding_dims.keys()):
             raise KeyError('Transformer inputs %s do not match embedded features %s' % (feats, list(self.embedding_dims)))
@@ -338,6 +354,9 @@ class Transformer(nn.Module):
             raise B4CError('sequence length %d exceeds the positional table (10000)' % S)
         rate = self.dropout_rate if training else 0.0
         seed = dropout_seeds.next() if training else 0
-        x, key_pad = ops.EmbedFn.apply(self.pos_encoding, self.scale, rate, seed, self.compute_dtype, len(ids), *ids, *tables)
-        out = self.encoder(x, training, key_pad, _input_dropout_done=True)
+        if packed is not None and not self.packed_supported(S):
+            raise B4CError('packed layout needs bf16, head depth 32 / 64 and S <= 512')
+        x, key_pad = ops.EmbedFn.apply(self.pos_encoding, self.scale, rate, seed, self.compute_dtype,
+                                       len(ids) if packed is None else (len(ids), packed), *ids, *tables)
+        out = self.encoder(x, training, key_pad, _input_dropout_done=True, packed=packed)
         return (out, key_pad) if return_key_pad else out

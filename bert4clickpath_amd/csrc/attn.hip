@@ -242,10 +242,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T *__restrict__
 
 // bf16 MFMA forward/backward (attn_mfma.hip); return B4C_EUNSUPPORTED when the shape is not covered.
 int b4c_attn_fwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, void *o, int ld_o, float *lse, int B, int S,
-                      int H, int dh, hipStream_t st);
+                      int H, int dh, const int32_t *cu, hipStream_t st);
 int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const void *o, int ld_o, const void *d_o,
                       int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B, int S, int H, int dh,
-                      void *workspace, int64_t workspace_bytes, hipStream_t st);
+                      void *workspace, int64_t workspace_bytes, const int32_t *cu, hipStream_t st);
 int64_t b4c_attn_bwd_mfma_workspace_bytes(int B, int S, int H, int dh);
 
 // bf16 shapes the MFMA kernels do not cover (S > 512 or head depth 16 / 128) run on the fp32-math row kernels, which are
@@ -290,7 +290,7 @@ extern "C" int b4c_attn_fwd(const void *qkv, int ld_qkv, const uint8_t *key_pad,
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == B4C_BF16 && !force_row()) {
-        rc = b4c_attn_fwd_mfma(qkv, ld_qkv, key_pad, o, ld_o, lse, B, S, H, dh, st);
+        rc = b4c_attn_fwd_mfma(qkv, ld_qkv, key_pad, o, ld_o, lse, B, S, H, dh, nullptr, st);
         if (rc != B4C_EUNSUPPORTED) return rc;
         note_row_fallback("attn_fwd", S, dh);
     }
@@ -325,7 +325,7 @@ extern "C" int b4c_attn_bwd_ws(const void *qkv, int ld_qkv, const uint8_t *key_p
     hipStream_t st = (hipStream_t)stream;
     if (dtype == B4C_BF16 && !force_row()) {
         rc = b4c_attn_bwd_mfma(qkv, ld_qkv, key_pad, o, ld_o, d_o, ld_do, lse, delta, dqkv, ld_dqkv, B, S, H, dh, workspace,
-                               workspace_bytes, st);
+                               workspace_bytes, nullptr, st);
         if (rc != B4C_EUNSUPPORTED) return rc;
         note_row_fallback("attn_bwd", S, dh);
     }
@@ -340,4 +340,35 @@ extern "C" int b4c_attn_bwd_ws(const void *qkv, int ld_qkv, const uint8_t *key_p
     } else
         B4C_REQUIRE(false, "attn_bwd: dtype %d", dtype);
     return b4c_check_launch("attn_bwd");
+}
+
+
+// ---- packed (padding-free) layout: sequence b owns rows cu_seqlens[b] .. cu_seqlens[b+1] of qkv / o / d_o / dqkv; max_len is
+// the longest sequence (LDS sizing, lse / delta pitch: [B][H][max_len]).  bf16, head depth 32 / 64, max_len <= 512 only: the
+// packed layout exists for the throughput path, the fp32 parity path stays dense.  key_pad [total tokens]: all zeros unless
+// the caller keeps masked keys inside the packed rows.
+extern "C" int b4c_attn_fwd_varlen(const void *qkv, int ld_qkv, const uint8_t *key_pad, const int32_t *cu_seqlens, void *o, int ld_o,
+                                   float *lse, int B, int max_len, int H, int dh, int dtype, void *stream) {
+    B4C_REQUIRE(qkv && key_pad && cu_seqlens && o, "attn_fwd_varlen: null pointer");
+    int rc = check_attn("attn_fwd_varlen", ld_qkv, ld_o, B, max_len, H, dh);
+    if (rc) return rc;
+    B4C_REQUIRE(dtype == B4C_BF16, "attn_fwd_varlen: bf16 only");
+    rc = b4c_attn_fwd_mfma(qkv, ld_qkv, key_pad, o, ld_o, lse, B, max_len, H, dh, cu_seqlens, (hipStream_t)stream);
+    B4C_REQUIRE(rc != B4C_EUNSUPPORTED, "attn_fwd_varlen: max_len %d / head depth %d outside the MFMA kernels (<= 512, 32 or 64)", max_len, dh);
+    return rc;
+}
+
+extern "C" int b4c_attn_bwd_varlen(const void *qkv, int ld_qkv, const uint8_t *key_pad, const int32_t *cu_seqlens, const void *o,
+                                   int ld_o, const void *d_o, int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv,
+                                   int B, int max_len, int H, int dh, void *workspace, int64_t workspace_bytes, int dtype,
+                                   void *stream) {
+    B4C_REQUIRE(qkv && key_pad && cu_seqlens && o && d_o && lse && delta && dqkv, "attn_bwd_varlen: null pointer");
+    int rc = check_attn("attn_bwd_varlen", ld_qkv, ld_o, B, max_len, H, dh);
+    if (rc) return rc;
+    B4C_REQUIRE(dtype == B4C_BF16, "attn_bwd_varlen: bf16 only");
+    B4C_REQUIRE(ld_do >= H * dh && ld_do % 8 == 0 && ld_dqkv >= 3 * H * dh && ld_dqkv % 8 == 0, "attn_bwd_varlen: bad pitch");
+    rc = b4c_attn_bwd_mfma(qkv, ld_qkv, key_pad, o, ld_o, d_o, ld_do, lse, delta, dqkv, ld_dqkv, B, max_len, H, dh, workspace,
+                           workspace_bytes, cu_seqlens, (hipStream_t)stream);
+    B4C_REQUIRE(rc != B4C_EUNSUPPORTED, "attn_bwd_varlen: shape outside the MFMA kernels, or workspace missing for max_len > 256");
+    return rc;
 }

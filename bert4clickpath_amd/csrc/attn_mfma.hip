@@ -104,11 +104,16 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 // ------------------------------------------------------------------------------------------
 template <int DH, int QPW>
 __global__ void __launch_bounds__(512, (QPW == 1 ? 4 : 2)) attn_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
-                                                            bf16_t *__restrict__ o, int ld_o, float *__restrict__ lse, int S, int H,
-                                                            float scale) {
+                                                            bf16_t *__restrict__ o, int ld_o, float *__restrict__ lse, int S_arg, int H,
+                                                            float scale, const int32_t *__restrict__ cu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSTR = DH * 2 + 16;
     constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8;
+    const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
+    // packed (padding-free) layout: sequence b owns rows cu[b] .. cu[b+1] of qkv / o; S_arg is the longest sequence
+    // (LDS is sized for it, lse rows keep the pitch S_arg).  cu == NULL: dense, every sequence S_arg rows.
+    const int S = cu ? cu[b + 1] - cu[b] : S_arg;
+    const int64_t tok0 = cu ? (int64_t)cu[b] : (int64_t)b * S_arg;
     const int nkt = (S + 31) >> 5, S_pad = nkt * 32;
     char *sK = smem;
     char *sV = sK + S_pad * KSTR;
@@ -117,8 +122,7 @@ __global__ void __launch_bounds__(512, (QPW == 1 ? 4 : 2)) attn_fwd_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const float scale2 = scale * 1.4426950408889634f;
     const int li = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
-    const int64_t tok0 = (int64_t)b * S;
+    if (S <= 0) return;
     const bf16_t *kbase = qkv + tok0 * ld + dm + hh * DH;
     const bf16_t *vbase = kbase + dm;
 
@@ -274,7 +278,7 @@ __global__ void __launch_bounds__(512, (QPW == 1 ? 4 : 2)) attn_fwd_mfma_kernel(
                 if (qt * 32 + row < S) att_store16<B4C_NT(B4C_NT_ATTN_O)>(o + (tok0 + qt * 32 + row) * ld_o + hh * DH + part * 8, v);
             }
             const int qrow = qt * 32 + r;
-            if (qrow < S && hf == 0 && lse) lse[((int64_t)b * H + hh) * S + qrow] = (m[qi] + __log2f(l[qi])) * 0.6931471805599453f;
+            if (qrow < S && hf == 0 && lse) lse[((int64_t)b * H + hh) * S_arg + qrow] = (m[qi] + __log2f(l[qi])) * 0.6931471805599453f;
         }
     }
 }
@@ -288,8 +292,8 @@ template <int DH>
 __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
                                                             const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o,
                                                             int ld_do, const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
-                                                            int ld_dq, int S, int H, float scale, int key0, float *__restrict__ dq_acc,
-                                                            int acc_mode) {
+                                                            int ld_dq, int S_arg, int H, float scale, int key0, float *__restrict__ dq_acc,
+                                                            int acc_mode, const int32_t *__restrict__ cu) {
     // Sequences longer than 256 run this kernel once per block of 256 keys (key0 = 0, 256, ...): a launch owns the dK / dV
     // rows of its keys and the part of dQ that sums over them.  acc_mode 0: dQ is complete, written as bf16; 1: first
     // block, the partial dQ goes to dq_acc (fp32 [B*S][H*DH]); 2: middle block, dq_acc += partial; 3: last block,
@@ -298,8 +302,23 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__rest
     constexpr int KSTR = DH * 2 + 16;
     constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8;
     constexpr int QBUF = 2 * 32 * KSTR + 256;          // sQ | sdO | lse[32] | delta[32]
+    const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
+    const int S = cu ? cu[b + 1] - cu[b] : S_arg;                    // packed layout: this sequence's own length
+    const int64_t tok0 = cu ? (int64_t)cu[b] : (int64_t)b * S_arg;
     const int nqt = (S + 31) >> 5;                                   // query tiles: the whole sequence
-    const int nkt = min(ATT_MAX_KT, (S - key0 + 31) >> 5), S_pad = nkt * 32;     // key tiles of this launch
+    const int nkt_all = (S - key0 + 31) >> 5;
+    const int nkt = nkt_all > ATT_MAX_KT ? ATT_MAX_KT : (nkt_all < 0 ? 0 : nkt_all), S_pad = nkt * 32;   // key tiles of this launch
+    if (nkt == 0) {
+        // a sequence that ends before this key block (packed layout, mixed lengths): nothing to add; the last block
+        // still has to turn the accumulated dQ into bf16
+        if (acc_mode == 3) {
+            for (int c = threadIdx.x; c < S * DH; c += 512) {
+                const int q = c / DH, e = c % DH;
+                dqkv[(tok0 + q) * ld_dq + hh * DH + e] = (bf16_t)dq_acc[(tok0 + q) * (int64_t)dm + hh * DH + e];
+            }
+        }
+        return;
+    }
     const int TSTR = S_pad * 2 + 16;
     char *sK = smem;
     char *sV = sK + S_pad * KSTR;
@@ -307,14 +326,12 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__rest
     char *sDS = sQB + 2 * QBUF;                          // [32][TSTR] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int li = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / H, hh = blockIdx.x % H, dm = H * DH;
-    const int64_t tok0 = (int64_t)b * S;
     const bf16_t *qbase = qkv + tok0 * ld + hh * DH;
     const bf16_t *kbase = qbase + dm;
     const bf16_t *vbase = qbase + 2 * dm;
     const bf16_t *gbase = d_o + tok0 * ld_do + hh * DH;
     const bf16_t *obase = o + tok0 * ld_o + hh * DH;
-    const float *lbase = lse + ((int64_t)b * H + hh) * S;
+    const float *lbase = lse + ((int64_t)b * H + hh) * S_arg;
 
     // staging roles for a 32-query tile: threads [0, 32 CH) carry Q chunks, [256, 256 + 32 CH) carry dO (+ O for delta)
     const bool roleQ = tid < 32 * CH, roleG = tid >= 256 && tid < 256 + 32 * CH;
@@ -481,20 +498,23 @@ template <int DH>
 __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
                                                                 const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o,
                                                                 int ld_do, const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
-                                                                int ld_dq, int S, int H, float scale, int n_items, int *__restrict__ work_counter) {
+                                                                int ld_dq, int S_arg, int H, float scale, int n_items, int *__restrict__ work_counter,
+                                                                const int32_t *__restrict__ cu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSTR = DH * 2 + 16;
     constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8;
-    const int nkt = (S + 31) >> 5, S_pad = nkt * 32;
-    const int TSTR = S_pad * 2 + 16;
+    // the LDS layout is that of the longest sequence S_arg; with the packed layout (cu != NULL) every item brings its own
+    // length S <= S_arg and only walks its own tiles
+    const int S_pad_max = ((S_arg + 31) >> 5) * 32;
+    const int TSTR = S_pad_max * 2 + 16;
     char *sK = smem;
-    char *sV = sK + S_pad * KSTR;
-    char *sQa = sV + S_pad * KSTR;
-    char *sGa = sQa + S_pad * KSTR;
-    char *sDS = sGa + S_pad * KSTR;                       // [32][TSTR] bf16
+    char *sV = sK + S_pad_max * KSTR;
+    char *sQa = sV + S_pad_max * KSTR;
+    char *sGa = sQa + S_pad_max * KSTR;
+    char *sDS = sGa + S_pad_max * KSTR;                       // [32][TSTR] bf16
     float *sLseA = reinterpret_cast<float *>(sDS + 32 * TSTR);
-    float *sDeltaA = sLseA + S_pad;
-    int *sNZ = reinterpret_cast<int *>(sDeltaA + S_pad);  // [ATT_MAX_KT][SPT]: does this slice of the query tile hold a nonzero dO?
+    float *sDeltaA = sLseA + S_pad_max;
+    int *sNZ = reinterpret_cast<int *>(sDeltaA + S_pad_max);  // [ATT_MAX_KT][SPT]: does this slice of the query tile hold a nonzero dO?
     int *sNext = sNZ + ATT_MAX_KT * 4;                    // the item this workgroup takes next
     char *sDQ = reinterpret_cast<char *>(sNext + 4);      // [32][KSTR] bf16: the dQ tile on its way out as row chunks
     constexpr int RPW = 64 / CH, SPT = 32 / RPW;          // rows one wave stages per pass, such slices per query tile
@@ -512,13 +532,15 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
     const int tid = threadIdx.x + opaque0, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int li = lane & 15, g = lane >> 4;
     const int b = item / H, hh = item % H;
-    const int64_t tok0 = (int64_t)b * S;
+    const int S = cu ? cu[b + 1] - cu[b] : S_arg;
+    const int64_t tok0 = cu ? (int64_t)cu[b] : (int64_t)b * S_arg;
+    const int nkt = (S + 31) >> 5, S_pad = nkt * 32;
     const bf16_t *qbase = qkv + tok0 * ld + hh * DH;
     const bf16_t *kbase = qbase + dm;
     const bf16_t *vbase = qbase + 2 * dm;
     const bf16_t *gbase = d_o + tok0 * ld_do + hh * DH;
     const bf16_t *obase = o + tok0 * ld_o + hh * DH;
-    const float *lbase = lse + ((int64_t)b * H + hh) * S;
+    const float *lbase = lse + ((int64_t)b * H + hh) * S_arg;
 
 #ifdef B4C_ATTN_PHASES
     unsigned long long att_t[4] = {0, 0, 0, 0};
@@ -526,9 +548,9 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
     ATT_STAMP(0);
     // the two small loads go out first, unconditional on clamped indices (a conditional scalar load is waited for on
     // the spot; behind the staging they were two exposed round trips per item)
-    const float r_lse = lbase[tid < S ? tid : S - 1];                    // S_pad <= 256 < 512 threads
+    const float r_lse = lbase[tid < S ? tid : (S > 0 ? S - 1 : 0)];      // S_pad <= 256 < 512 threads
     const int key_c = wave * 32 + r;
-    const uint8_t r_pad = key_pad[tok0 + (key_c < S ? key_c : S - 1)];
+    const uint8_t r_pad = key_pad[tok0 + (key_c < S ? key_c : (S > 0 ? S - 1 : 0))];
     {   // all global loads of the workgroup are issued before the first LDS write (one latency, not one per pass)
         constexpr int NIT = (256 * CH + 511) / 512;
         u32x4 rk[NIT], rv[NIT], rq[NIT], rg[NIT], ro[NIT];
@@ -731,7 +753,7 @@ static int att_num_cus() {
 static bool mfma_shape_ok(int S, int dh) { return (dh == 32 || dh == 64) && S <= ATT_MAX_S; }
 
 int b4c_attn_fwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, void *o, int ld_o, float *lse, int B, int S,
-                      int H, int dh, hipStream_t st) {
+                      int H, int dh, const int32_t *cu, hipStream_t st) {
     if (!mfma_shape_ok(S, dh)) return B4C_EUNSUPPORTED;
     const int S_pad = (S + 31) / 32 * 32;
     const int qpw = S_pad > 32 * ATT_MAX_KT ? 2 : 1;
@@ -740,7 +762,7 @@ int b4c_attn_fwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, void 
 #define ATT_FWD_LAUNCH(DHH, QQ)                                                                                          \
     do {                                                                                                                 \
         allow_lds_attn(attn_fwd_mfma_kernel<DHH, QQ>, shm);                                                              \
-        attn_fwd_mfma_kernel<DHH, QQ><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (bf16_t *)o, ld_o, lse, S, H, scale); \
+        attn_fwd_mfma_kernel<DHH, QQ><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (bf16_t *)o, ld_o, lse, S, H, scale, cu); \
     } while (0)
     if (dh == 64) { if (qpw == 1) ATT_FWD_LAUNCH(64, 1); else ATT_FWD_LAUNCH(64, 2); }
     else { if (qpw == 1) ATT_FWD_LAUNCH(32, 1); else ATT_FWD_LAUNCH(32, 2); }
@@ -755,7 +777,7 @@ int64_t b4c_attn_bwd_mfma_workspace_bytes(int B, int S, int H, int dh) {
 
 int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const void *o, int ld_o, const void *d_o,
                       int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B, int S, int H, int dh,
-                      void *workspace, int64_t workspace_bytes, hipStream_t st) {
+                      void *workspace, int64_t workspace_bytes, const int32_t *cu, hipStream_t st) {
     if (!mfma_shape_ok(S, dh)) return B4C_EUNSUPPORTED;
     const float scale_s = 1.0f / sqrtf((float)dh);
     if (S > 32 * ATT_MAX_KT) {
@@ -768,10 +790,10 @@ int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const
             const int mode = kb == 0 ? 1 : (kb == nblk - 1 ? 3 : 2);
             if (dh == 64) {
                 allow_lds_attn(attn_bwd_mfma_kernel<64>, shm2);
-                attn_bwd_mfma_kernel<64><<<B * H, 512, shm2, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale_s, kb * 256, (float *)workspace, mode);
+                attn_bwd_mfma_kernel<64><<<B * H, 512, shm2, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale_s, kb * 256, (float *)workspace, mode, cu);
             } else {
                 allow_lds_attn(attn_bwd_mfma_kernel<32>, shm2);
-                attn_bwd_mfma_kernel<32><<<B * H, 512, shm2, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale_s, kb * 256, (float *)workspace, mode);
+                attn_bwd_mfma_kernel<32><<<B * H, 512, shm2, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale_s, kb * 256, (float *)workspace, mode, cu);
             }
         }
         return b4c_check_launch("attn_bwd_mfma (key blocks)");
@@ -787,19 +809,19 @@ int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const
         if (hipMemsetAsync(delta, 0, sizeof(int), st) != hipSuccess) return B4C_ELAUNCH;
         if (dh == 64) {
             allow_lds_attn(attn_bwd_resident_kernel<64>, shm_res);
-            attn_bwd_resident_kernel<64><<<grid_res, 512, shm_res, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, B * H, (int *)delta);
+            attn_bwd_resident_kernel<64><<<grid_res, 512, shm_res, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, B * H, (int *)delta, cu);
         } else {
             allow_lds_attn(attn_bwd_resident_kernel<32>, shm_res);
-            attn_bwd_resident_kernel<32><<<grid_res, 512, shm_res, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, B * H, (int *)delta);
+            attn_bwd_resident_kernel<32><<<grid_res, 512, shm_res, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, B * H, (int *)delta, cu);
         }
         return b4c_check_launch("attn_bwd_resident");
     }
     if (dh == 64) {
         allow_lds_attn(attn_bwd_mfma_kernel<64>, shm);
-        attn_bwd_mfma_kernel<64><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, 0, nullptr, 0);
+        attn_bwd_mfma_kernel<64><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, 0, nullptr, 0, cu);
     } else {
         allow_lds_attn(attn_bwd_mfma_kernel<32>, shm);
-        attn_bwd_mfma_kernel<32><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, 0, nullptr, 0);
+        attn_bwd_mfma_kernel<32><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, 0, nullptr, 0, cu);
     }
     return b4c_check_launch("attn_bwd_mfma");
 }

@@ -42,20 +42,23 @@ struct EmbedArgs {
 template <typename T>
 __global__ void __launch_bounds__(256) embed_fwd_kernel(EmbedArgs a, const float *__restrict__ pe, float scale,
                                                         T *__restrict__ out, int ld_out, uint8_t *__restrict__ key_pad,
-                                                        int64_t T_tok, int S, int d, float rate, uint64_t seed) {
+                                                        int64_t T_tok, int S, int d, float rate, uint64_t seed,
+                                                        const int32_t *__restrict__ token_src) {
     const int cpr = d >> 3;  // 8-column chunks per row
     const int64_t total = T_tok * cpr;
     const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t t = i / cpr;
         const int c = (int)(i - t * cpr) << 3;
-        const int s = (int)(t % S);
+        // packed layout: output row t is the dense position token_src[t] = b * S + s (its ids and its positional row)
+        const int64_t ts = token_src ? (int64_t)token_src[t] : t;
+        const int s = (int)(ts % S);
         int f = 0;
 #pragma unroll
         for (int k = 1; k < B4C_MAX_FEATURES; ++k)
             if (k < a.n && c >= a.col0[k]) f = k;
-        int64_t id = a.ids[f][t];
-        if (c == 0 && key_pad) key_pad[t] = (a.ids[0][t] == 0) ? 1 : 0;
+        int64_t id = a.ids[f][ts];
+        if (c == 0 && key_pad) key_pad[t] = (a.ids[0][ts] == 0) ? 1 : 0;
         id = id < 0 ? 0 : (id >= a.rows[f] ? a.rows[f] - 1 : id);
         const int fd = a.col0[f + 1] - a.col0[f];
         const int cf = c - a.col0[f];
@@ -149,18 +152,29 @@ extern "C" int b4c_embed_concat_pe_fwd(int n_feat, const int64_t *const *h_ids, 
                                        const int *h_dims, const int64_t *h_rows, const float *pe, float scale,
                                        void *out, int ld_out, uint8_t *key_pad, int B, int S, int d_model,
                                        float dropout_rate, uint64_t seed, int dtype, void *stream) {
+    return b4c_embed_concat_pe_fwd_packed(n_feat, h_ids, h_tables, h_dims, h_rows, pe, scale, out, ld_out, key_pad, B, S, d_model,
+                                          dropout_rate, seed, nullptr, (int64_t)B * S, dtype, stream);
+}
+
+extern "C" int b4c_embed_concat_pe_fwd_packed(int n_feat, const int64_t *const *h_ids, const float *const *h_tables,
+                                              const int *h_dims, const int64_t *h_rows, const float *pe, float scale,
+                                              void *out, int ld_out, uint8_t *key_pad, int B, int S, int d_model,
+                                              float dropout_rate, uint64_t seed, const int32_t *token_src, int64_t n_tokens,
+                                              int dtype, void *stream) {
     EmbedArgs a;
     int rc = fill_embed_args(a, n_feat, h_ids, (float *const *)h_tables, h_dims, h_rows, d_model);
     if (rc) return rc;
     B4C_REQUIRE(pe && out && B > 0 && S > 0 && ld_out >= d_model && ld_out % 8 == 0, "embed_fwd: bad shape");
     B4C_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f, "embed_fwd: dropout_rate %f", dropout_rate);
-    const int64_t T_tok = (int64_t)B * S;
+    B4C_REQUIRE(n_tokens >= 0 && n_tokens <= (int64_t)B * S, "embed_fwd: n_tokens %lld out of range", (long long)n_tokens);
+    const int64_t T_tok = token_src ? n_tokens : (int64_t)B * S;
+    if (T_tok == 0) return B4C_OK;
     const int grid = grid_for(T_tok * (d_model / 8), 256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == B4C_F32)
-        embed_fwd_kernel<float><<<grid, 256, 0, st>>>(a, pe, scale, (float *)out, ld_out, key_pad, T_tok, S, d_model, dropout_rate, seed);
+        embed_fwd_kernel<float><<<grid, 256, 0, st>>>(a, pe, scale, (float *)out, ld_out, key_pad, T_tok, S, d_model, dropout_rate, seed, token_src);
     else if (dtype == B4C_BF16)
-        embed_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>(a, pe, scale, (bf16_t *)out, ld_out, key_pad, T_tok, S, d_model, dropout_rate, seed);
+        embed_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>(a, pe, scale, (bf16_t *)out, ld_out, key_pad, T_tok, S, d_model, dropout_rate, seed, token_src);
     else
         B4C_REQUIRE(false, "embed_fwd: dtype %d", dtype);
     return b4c_check_launch("embed_fwd");
@@ -557,12 +571,13 @@ extern "C" int b4c_add_dropout_layernorm_bwd(const void *dout, const void *z, co
 // ------------------------------------------------------------------------------------------
 // [MASK] positions: count per row (one wave per row), single-block scan, ordered write
 // ------------------------------------------------------------------------------------------
+template <bool NE>
 __global__ void __launch_bounds__(256) mask_count_kernel(const int64_t *__restrict__ ids, int B, int S, int64_t value,
                                                          int32_t *__restrict__ counts) {
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= B) return;
     int c = 0;
-    for (int s = lane; s < S; s += 64) c += (ids[(int64_t)wave * S + s] == value);
+    for (int s = lane; s < S; s += 64) c += ((ids[(int64_t)wave * S + s] == value) != NE);
     c = (int)wave_sum((float)c);  // S < 2^24 so the float sum is exact
     if (lane == 0) counts[wave] = c;
 }
@@ -590,18 +605,21 @@ __global__ void __launch_bounds__(1024) mask_scan_kernel(const int32_t *__restri
     if (tid == 1023) { offsets[B] = part[1023]; if (maxcount) maxcount[0] = pmax[1023]; }
 }
 
+// `inverse` (optional, int32 [B*S]): inverse[b*S + s] = rank of the hit in row-major order, -1 elsewhere
+template <bool NE>
 __global__ void __launch_bounds__(256) mask_write_kernel(const int64_t *__restrict__ ids, int B, int S, int64_t value,
                                                          const int32_t *__restrict__ offsets, int32_t *__restrict__ flat_idx,
-                                                         int32_t cap) {
+                                                         int32_t cap, int32_t *__restrict__ inverse) {
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= B) return;
     int32_t base = offsets[wave];
     for (int s0 = 0; s0 < S; s0 += 64) {
         const int s = s0 + lane;
-        const bool hit = s < S && ids[(int64_t)wave * S + s] == value;
+        const bool hit = s < S && ((ids[(int64_t)wave * S + s] == value) != NE);
         const unsigned long long bal = __ballot(hit);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
         if (hit && base + before < cap) flat_idx[base + before] = wave * S + s;
+        if (inverse && s < S) inverse[wave * S + s] = (hit && base + before < cap) ? base + before : -1;
         base += __popcll(bal);
     }
 }
@@ -612,10 +630,38 @@ extern "C" int b4c_mask_positions(const int64_t *ids, int B, int S, int64_t valu
     B4C_REQUIRE((int64_t)B * S < (1ll << 31), "mask_positions: B*S must fit int32");
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)ceil_div64((int64_t)B * 64, 256);
-    mask_count_kernel<<<grid, 256, 0, st>>>(ids, B, S, value, counts);
+    mask_count_kernel<false><<<grid, 256, 0, st>>>(ids, B, S, value, counts);
     mask_scan_kernel<<<1, 1024, 0, st>>>(counts, B, offsets, maxcount);
-    mask_write_kernel<<<grid, 256, 0, st>>>(ids, B, S, value, offsets, flat_idx, cap);
+    mask_write_kernel<false><<<grid, 256, 0, st>>>(ids, B, S, value, offsets, flat_idx, cap, nullptr);
     return b4c_check_launch("mask_positions");
+}
+
+// Packed (padding-free) token layout: the positions whose id is NOT `pad_value`, row-major.
+//   counts[B] = real tokens per sequence, cu_seqlens[B+1] = their exclusive scan (cu[B] = T_real), token_src[cap] = b*S + s
+//   of every real token (entries >= T_real untouched), packed_of[B*S] = packed row of a dense position or -1.
+extern "C" int b4c_nonpad_positions(const int64_t *ids, int B, int S, int64_t pad_value, int32_t *counts, int32_t *cu_seqlens,
+                                    int32_t *token_src, int32_t cap, int32_t *packed_of, int32_t *maxcount, void *stream) {
+    B4C_REQUIRE(ids && counts && cu_seqlens && token_src && B > 0 && S > 0 && cap >= 0, "nonpad_positions: bad argument");
+    B4C_REQUIRE((int64_t)B * S < (1ll << 31), "nonpad_positions: B*S must fit int32");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)ceil_div64((int64_t)B * 64, 256);
+    mask_count_kernel<true><<<grid, 256, 0, st>>>(ids, B, S, pad_value, counts);
+    mask_scan_kernel<<<1, 1024, 0, st>>>(counts, B, cu_seqlens, maxcount);
+    mask_write_kernel<true><<<grid, 256, 0, st>>>(ids, B, S, pad_value, cu_seqlens, token_src, cap, packed_of);
+    return b4c_check_launch("nonpad_positions");
+}
+
+// out[i] = idx[i] >= 0 ? map[idx[i]] : -1   (dense [MASK] positions -> rows of the packed encoder output)
+__global__ void __launch_bounds__(256) remap_index_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ map,
+                                                          int32_t *__restrict__ out, int64_t n) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i < n) out[i] = idx[i] >= 0 ? map[idx[i]] : -1;
+}
+extern "C" int b4c_remap_index(const int32_t *idx, const int32_t *map, int32_t *out, int64_t n, void *stream) {
+    B4C_REQUIRE(idx && map && out && n >= 0, "remap_index: bad argument");
+    if (n == 0) return B4C_OK;
+    remap_index_kernel<<<(int)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>(idx, map, out, n);
+    return b4c_check_launch("remap_index");
 }
 
 __global__ void __launch_bounds__(256) padded_index_kernel(const int32_t *__restrict__ counts, const int32_t *__restrict__ offsets,

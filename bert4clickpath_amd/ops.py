@@ -141,7 +141,39 @@ def _feature_arrays(ids_list, tables):
     return n, ids_arr, tab_arr, dims, rows
 
 
-def embed_concat_pe_fwd(ids_list, tables, pe, scale, rate, seed, dtype):
+class Packed:
+    """Padding-free token layout of one batch (include/b4c.h "packed token layout"): the T real tokens of the (B, S) batch in
+    row-major order.  cu [B+1] int32 (sequence b = packed rows cu[b] .. cu[b+1]), tok_src [>= T] int32 (dense position
+    b*S + s of packed row t), packed_of [B*S] int32 (inverse, -1 at pads), max_len (upper bound of the longest sequence)."""
+    __slots__ = ('cu', 'tok_src', 'packed_of', 'B', 'S', 'T', 'max_len', 'ids_packed')
+
+    def __init__(self, cu, tok_src, packed_of, B, S, T, max_len):
+        self.cu, self.tok_src, self.packed_of, self.B, self.S, self.T, self.max_len = cu, tok_src, packed_of, B, S, T, max_len
+        self.ids_packed = None
+
+
+def nonpad_positions(ids, cap, pad_value=0):
+    """-> (counts [B], cu [B+1], tok_src [cap], packed_of [B*S], maxcount [1]) (all int32): b4c_nonpad_positions."""
+    _cuda(ids)
+    B, S = ids.shape
+    dev = ids.device
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    cu = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    tok_src = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+    packed_of = torch.empty(B * S, dtype=torch.int32, device=dev)
+    mx = torch.empty(1, dtype=torch.int32, device=dev)
+    L.check(L.lib().b4c_nonpad_positions(_p(ids), B, S, pad_value, _p(counts), _p(cu), _p(tok_src), cap, _p(packed_of), _p(mx),
+                                         _st()), 'nonpad_positions')
+    return counts, cu, tok_src, packed_of, mx
+
+
+def remap_index(idx, mapping):
+    out = torch.empty_like(idx)
+    L.check(L.lib().b4c_remap_index(_p(idx), _p(mapping), _p(out), idx.shape[0], _st()), 'remap_index')
+    return out
+
+
+def embed_concat_pe_fwd(ids_list, tables, pe, scale, rate, seed, dtype, packed=None):
     _cuda(pe, *ids_list, *tables)
     B, S = ids_list[0].shape
     d = sum(int(t.shape[1]) for t in tables)
@@ -153,9 +185,18 @@ def embed_concat_pe_fwd(ids_list, tables, pe, scale, rate, seed, dtype):
             raise B4CError('embedding tables must be contiguous float32')
     if pe.shape[0] < S or pe.shape[1] != d:
         raise B4CError('positional table (%d,%d) too small for S=%d d=%d' % (pe.shape[0], pe.shape[1], S, d))
+    n, ids_arr, tab_arr, dims, rows = _feature_arrays(ids_list, tables)
+    if packed is not None:      # rows of the real tokens only
+        T_tok = packed.T
+        out = torch.empty(1, T_tok, d, dtype=dtype, device=pe.device)
+        key_pad = torch.empty(T_tok, dtype=torch.uint8, device=pe.device)
+        with _record('embed_fwd', T_tok * d * (4 + out.element_size())):
+            L.check(L.lib().b4c_embed_concat_pe_fwd_packed(n, ids_arr, tab_arr, dims, rows, _p(pe), scale, _p(out), d, _p(key_pad),
+                                                           B, S, d, rate, seed, _p(packed.tok_src), T_tok, dt_code(dtype), _st()),
+                    'embed_concat_pe_fwd_packed')
+        return out, key_pad
     out = torch.empty(B, S, d, dtype=dtype, device=pe.device)
     key_pad = torch.empty(B, S, dtype=torch.uint8, device=pe.device)
-    n, ids_arr, tab_arr, dims, rows = _feature_arrays(ids_list, tables)
     with _record('embed_fwd', B * S * d * (4 + out.element_size())):
         L.check(L.lib().b4c_embed_concat_pe_fwd(n, ids_arr, tab_arr, dims, rows, _p(pe), scale, _p(out), d, _p(key_pad),
                                                 B, S, d, rate, seed, dt_code(dtype), _st()), 'embed_concat_pe_fwd')
@@ -350,20 +391,27 @@ def _ready(*params):
             _grad_ready_cb(p)
 
 
-def attn_fwd(qkv, key_pad, B, S, H, dh):
+def attn_fwd(qkv, key_pad, B, S, H, dh, cu=None):
+    """cu (int32 [B+1]): packed layout -- sequence b owns rows cu[b] .. cu[b+1] of qkv, S = upper bound of the longest one."""
     d = H * dh
-    o = torch.empty(B * S, d, dtype=qkv.dtype, device=qkv.device)
+    T_tok = qkv.shape[0]
+    o = torch.empty(T_tok, d, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
-    with _record('attn_fwd', B * S * 4 * d * qkv.element_size(), 4 * B * S * S * d):
-        L.check(L.lib().b4c_attn_fwd(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), d, _p(lse), B, S, H, dh,
-                                     dt_code(qkv.dtype), _st()), 'attn_fwd')
+    # algorithmic work of the packed layout is counted with the mean squared length bounded by T * S (an upper bound)
+    with _record('attn_fwd', T_tok * 4 * d * qkv.element_size(), 4 * T_tok * S * d):
+        if cu is None:
+            L.check(L.lib().b4c_attn_fwd(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), d, _p(lse), B, S, H, dh,
+                                         dt_code(qkv.dtype), _st()), 'attn_fwd')
+        else:
+            L.check(L.lib().b4c_attn_fwd_varlen(_p(qkv), qkv.stride(0), _p(key_pad), _p(cu), _p(o), d, _p(lse), B, S, H, dh,
+                                                dt_code(qkv.dtype), _st()), 'attn_fwd_varlen')
     return o, lse
 
 
 _attn_ws = {}
 
 
-def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh):
+def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, cu=None):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     need = L.lib().b4c_attn_bwd_workspace_bytes(B, S, H, dh, dt_code(qkv.dtype))     # > 0 only for bf16 256 < S <= 512
@@ -373,10 +421,16 @@ def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh):
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
             _attn_ws[qkv.device] = ws
-    with _record('attn_bwd', B * S * 8 * H * dh * qkv.element_size(), 10 * B * S * S * H * dh):
-        L.check(L.lib().b4c_attn_bwd_ws(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), o.stride(0), _p(d_o), d_o.stride(0),
-                                        _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, _p(ws), need,
-                                        dt_code(qkv.dtype), _st()), 'attn_bwd')
+    T_tok = qkv.shape[0]
+    with _record('attn_bwd', T_tok * 8 * H * dh * qkv.element_size(), 10 * T_tok * S * H * dh):
+        if cu is None:
+            L.check(L.lib().b4c_attn_bwd_ws(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), o.stride(0), _p(d_o), d_o.stride(0),
+                                            _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, _p(ws), need,
+                                            dt_code(qkv.dtype), _st()), 'attn_bwd')
+        else:
+            L.check(L.lib().b4c_attn_bwd_varlen(_p(qkv), qkv.stride(0), _p(key_pad), _p(cu), _p(o), o.stride(0), _p(d_o),
+                                                d_o.stride(0), _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, _p(ws),
+                                                need, dt_code(qkv.dtype), _st()), 'attn_bwd_varlen')
     return dqkv
 
 
@@ -748,12 +802,20 @@ def _as2d(x):
 # autograd blocks
 # --------------------------------------------------------------------------------------
 class EmbedFn(torch.autograd.Function):
-    """R6: gather + concat + *sqrt(d) + PE (+ input dropout).  apply(pe, scale, rate, seed, dtype, n, *ids, *tables)"""
+    """R6: gather + concat + *sqrt(d) + PE (+ input dropout).  apply(pe, scale, rate, seed, dtype, n, *ids, *tables);
+    n may be (n, Packed): the packed layout, output (1, T, d)."""
 
     @staticmethod
     def forward(ctx, pe, scale, rate, seed, dtype, n, *args):
+        packed = None
+        if isinstance(n, tuple):
+            n, packed = n
         ids, tables = list(args[:n]), list(args[n:])
-        out, key_pad = embed_concat_pe_fwd(ids, [t.detach() for t in tables], pe, scale, rate, seed, dtype)
+        out, key_pad = embed_concat_pe_fwd(ids, [t.detach() for t in tables], pe, scale, rate, seed, dtype, packed)
+        if packed is not None:
+            # backward works on the packed ids (one gather per feature): B = 1, S = T rows
+            src = packed.tok_src[:packed.T].long()
+            ids = [i.reshape(-1)[src].reshape(1, -1).contiguous() for i in ids]
         ctx.save_for_backward(*ids, *tables)
         ctx.n, ctx.scale, ctx.rate, ctx.seed = n, scale, rate, seed
         ctx.mark_non_differentiable(key_pad)
@@ -764,6 +826,7 @@ class EmbedFn(torch.autograd.Function):
         flush_pending_dw()
         saved = ctx.saved_tensors
         ids, tables = list(saved[:ctx.n]), list(saved[ctx.n:])
+        dout = dout.reshape(ids[0].shape[0], ids[0].shape[1], -1)
         if _inplace_ok(*tables):
             embed_concat_pe_bwd(ids, tables, dout.contiguous(), ctx.scale, ctx.rate, ctx.seed, into=[t.grad for t in tables])
             _ready(*tables)
@@ -776,7 +839,7 @@ class AttnBlockFn(torch.autograd.Function):
     """R8 + first half of R10: LN1(x + drop(MHA(x))).  x: [T, d] in the compute dtype."""
 
     @staticmethod
-    def forward(ctx, x, key_pad, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, pk_qkv, pk_o, B, S, H, rate, seed, training):
+    def forward(ctx, x, key_pad, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, pk_qkv, pk_o, B, S, H, rate, seed, training, cu=None):
         T_tok, d = x.shape
         dh = d // H
         wt_qkv, _, b_qkv = pk_qkv.get(x.dtype, d, training)
@@ -784,7 +847,7 @@ class AttnBlockFn(torch.autograd.Function):
         with _timed('qkv_fwd'):
             qkv = gemm_nt(x, wt_qkv, 3 * d, b_qkv)
         with _timed('attn_fwd'):
-            o, lse = attn_fwd(qkv, key_pad, B, S, H, dh)
+            o, lse = attn_fwd(qkv, key_pad, B, S, H, dh, cu)
         if gemm_ln_supported(o, d):
             z, out, stats = gemm_nt_add_ln(o, wt_o, b_o, x, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
                                            save=training)
@@ -796,6 +859,7 @@ class AttnBlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, key_pad, qkv, o, lse, z, stats, gamma)
             ctx.pk = (pk_qkv, pk_o)
             ctx.dims = (B, S, H, dh, rate, seed)
+            ctx.cu = cu
             ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta)
         return out
 
@@ -817,7 +881,7 @@ class AttnBlockFn(torch.autograd.Function):
             dWo, dbo = gemm_tn(o, dy, d, d)
         d_o = gemm_nt(dy, wc_o, d)
         with _timed('attn_bwd'):
-            dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh)
+            dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, ctx.cu)
         if inplace:
             queue_dw(x, dqkv, d, 3 * d, [wq.grad, wk.grad, wv.grad], [bq.grad, bk.grad, bv.grad], (wq, bq, wk, bk, wv, bv))
         else:
@@ -826,9 +890,9 @@ class AttnBlockFn(torch.autograd.Function):
         if inplace:
             _ready(gam, bet)
             flush_pending_dw()          # this layer's four weight gradients (two queued by FFNBlockFn.backward) in one launch
-            return (dx,) + (None,) * 19
+            return (dx,) + (None,) * 20
         (gq, gk, gv), (gbq, gbk, gbv) = pk_qkv.split_grads(dWqkv, dbqkv)
-        return (dx, None, gq, gbq, gk, gbk, gv, gbv, dWo, dbo, dgamma, dbeta) + (None,) * 8
+        return (dx, None, gq, gbq, gk, gbk, gv, gbv, dWo, dbo, dgamma, dbeta) + (None,) * 9
 
 
 class FFNBlockFn(torch.autograd.Function):

@@ -353,6 +353,35 @@ int b4c_scatter_add_1d(const float *src, const int64_t *idx, float *dst, int64_t
 int b4c_row_scale_f32(const void *src, int ld, const float *scale, float *out, int ld_out, int64_t R, int width,
                       int dtype, void *stream);
 
+/* ---- packed (padding-free) token layout -------------------------------------------------------------------------------
+ * The reference pads every sequence to the batch maximum and runs the encoder on the pads too (transformer.py:376-402); pad
+ * KEYS are masked out (:38-41, :90-91), pad QUERIES produce rows nobody reads, and under the Cloze loss their gradient is
+ * exactly zero.  The throughput path therefore drops the pad positions: the encoder runs on the T_real real tokens only,
+ * every row-wise kernel (GEMM, LayerNorm, embedding, Adam) unchanged on [T_real][d] tensors, attention per sequence through
+ * cu_seqlens.  Results at real positions are those of the dense layout.
+ * b4c_nonpad_positions: counts[B] real tokens per sequence, cu_seqlens[B+1] (exclusive scan, cu[B] = T_real),
+ *   token_src[cap] = b*S + s of every real token in row-major order, packed_of[B*S] = packed row of a dense position or -1
+ *   (may be NULL), maxcount[1] = longest sequence (may be NULL).
+ * b4c_remap_index: out[i] = idx[i] >= 0 ? map[idx[i]] : -1 ([MASK] positions of the dense layout -> packed rows).
+ * b4c_embed_concat_pe_fwd_packed: b4c_embed_concat_pe_fwd writing only rows t < n_tokens, row t taken from dense position
+ *   token_src[t] (ids and positional row s = token_src[t] % S); the dropout counter is the packed element index.
+ * b4c_attn_{fwd,bwd}_varlen: attention with sequence b in rows cu_seqlens[b] .. cu_seqlens[b+1] (bf16, head depth 32 / 64,
+ *   max_len <= 512); lse / delta keep the shape [B][H][max_len]; workspace as b4c_attn_bwd_ws (max_len > 256). */
+int b4c_nonpad_positions(const int64_t *ids, int B, int S, int64_t pad_value, int32_t *counts, int32_t *cu_seqlens,
+                         int32_t *token_src, int32_t cap, int32_t *packed_of, int32_t *maxcount, void *stream);
+int b4c_remap_index(const int32_t *idx, const int32_t *map, int32_t *out, int64_t n, void *stream);
+int b4c_embed_concat_pe_fwd_packed(int n_feat, const int64_t *const *h_ids, const float *const *h_tables,
+                                   const int *h_dims, const int64_t *h_rows, const float *pe, float scale,
+                                   void *out, int ld_out, uint8_t *key_pad, int B, int S, int d_model,
+                                   float dropout_rate, uint64_t seed, const int32_t *token_src, int64_t n_tokens,
+                                   int dtype, void *stream);
+int b4c_attn_fwd_varlen(const void *qkv, int ld_qkv, const uint8_t *key_pad, const int32_t *cu_seqlens, void *o, int ld_o,
+                        float *lse, int B, int max_len, int H, int dh, int dtype, void *stream);
+int b4c_attn_bwd_varlen(const void *qkv, int ld_qkv, const uint8_t *key_pad, const int32_t *cu_seqlens, const void *o,
+                        int ld_o, const void *d_o, int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv,
+                        int B, int max_len, int H, int dh, void *workspace, int64_t workspace_bytes, int dtype,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,8 @@ HBM bytes per launch for each launch family, corrected as MI355X_MICROARCH.md pr
 (FETCH_SIZE counts 64 B per 128-B request of a wide streaming read -> x2; WRITE_SIZE is exact; both in KiB)."""
 import csv, glob, json, sys, collections
 # (family, kernels whose traffic counts, the kernel that marks ONE launch of the family)
-FAM = [('gemm_nt_ln', ('gemm_nt_ln_kernel',), None), ('gemm_nt', ('gemm_nt_kernel', 'gemm_nt_wide_kernel'), None), ('gemm_tn', ('gemm_tn_', 'tn_reduce_kernel'), 'gemm_tn_'),
+FAM = [('gemm_nt_ln', ('gemm_nt_ln_kernel', 'gemm_nt_ln256_kernel'), None), ('vocab_proj', ('gemm_nt_wide',), None), ('gemm_nt', ('gemm_nt_kernel',), None),
+       ('softmax_rows', ('softmax_rows',), None), ('topk_rows', ('topk_rows',), None), ('gemm_tn', ('gemm_tn_', 'tn_reduce_kernel'), 'gemm_tn_'),
        ('attn_bwd', ('attn_bwd',), None), ('attn_fwd', ('attn_fwd',), None), ('softmax_ce', ('softmax_ce',), None),
        ('add_ln_fwd', ('add_ln_fwd',), None), ('add_ln_bwd', ('add_ln_bwd',), None), ('embed_bwd', ('embed_bwd',), None),
        ('embed_fwd', ('embed_fwd',), None), ('adam', ('adam_kernel',), None),
@@ -30,5 +31,8 @@ for fam in fetch:
     out[fam] = {'hbm_bytes_per_launch': (2.0 * fs / n + ws / max(n2, 1)) * 1024.0, 'fetch_bytes_per_launch_x2': 2.0 * fs / n * 1024.0,
                 'write_bytes_per_launch': ws / max(n2, 1) * 1024.0, 'launches_sampled': n,
                 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md gfx950 note, KiB -> bytes'}
+if len(sys.argv) > 4: out['_config'] = json.loads(sys.argv[4])
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
-for k, v in out.items(): print('%-12s %8.1f MB/launch (fetch x2 %8.1f, write %8.1f) n=%d' % (k, v['hbm_bytes_per_launch']/1e6, v['fetch_bytes_per_launch_x2']/1e6, v['write_bytes_per_launch']/1e6, v['launches_sampled']))
+for k, v in out.items():
+    if k.startswith('_'): continue
+    print('%-12s %8.1f MB/launch (fetch x2 %8.1f, write %8.1f) n=%d' % (k, v['hbm_bytes_per_launch']/1e6, v['fetch_bytes_per_launch_x2']/1e6, v['write_bytes_per_launch']/1e6, v['launches_sampled']))
