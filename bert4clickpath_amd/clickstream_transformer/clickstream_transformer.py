@@ -180,8 +180,6 @@ class ClickstreamTransformer(nn.Module):
         if packed is None and n_real_tokens is None:
             return False
         first_in = self.sequential_input_config[list(self.sequential_input_config.keys())[0]]
-        x = inputs[first_in[0]]
-        L0 = (x.shape[1] if isinstance(x, torch.Tensor) else np.asarray(x, dtype=object).shape[1])
         S = sum((inputs[n].shape[1] if isinstance(inputs[n], torch.Tensor) else np.asarray(inputs[n], dtype=object).shape[1])
                 for n in first_in) + len(first_in) + 2
         ok = self.transformer.packed_supported(S)
