@@ -166,9 +166,15 @@ class ClickstreamTransformer(nn.Module):
             ids0 = seq[first].contiguous()
             B, S = ids0.shape
             cap = int(n_real_tokens) if n_real_tokens is not None else B * S
-            _, cu, tok_src, packed_of, _ = ops.nonpad_positions(ids0, cap)
-            T_real = cap if n_real_tokens is not None else int(cu[-1].item())       # the caller's count avoids the read-back
+            counts, cu, tok_src, packed_of, mx = ops.nonpad_positions(ids0, cap)
+            if n_real_tokens is not None:
+                T_real = cap                      # the caller's count avoids the read-back
+            else:
+                T_real = int(counts.sum().item())
+                if T_real != cap:                 # (every position real is the only case where they agree)
+                    counts, cu, tok_src, packed_of, mx = ops.nonpad_positions(ids0, T_real)
             self._packed = ops.Packed(cu, tok_src, packed_of, B, S, T_real, S)
+            self._packed.ids_packed = mx          # < 0: the given n_real_tokens was wrong (poisons the loss, see cloze_loss)
         enc, key_pad = self.transformer(seq, training, None, return_key_pad=True, packed=self._packed)
         return enc, seq[first], raw_features[first], seg_starts, seg_ends
 
@@ -279,8 +285,13 @@ class ClickstreamTransformer(nn.Module):
                 raise ValueError('%d labels for %d masked positions' % (lab.shape[0], rows.shape[0]))
         code = CE_TF if variant == 'tf' else CE_PLAIN
         if hasattr(self.head, 'cloze_ce'):
-            return self.head.cloze_ce(rows, lab, code, unit_grad)
-        return ops.FusedSoftmaxCEFn.apply(self.head.logits(rows), lab, self.head.output_vocab_size, code, unit_grad)
+            loss = self.head.cloze_ce(rows, lab, code, unit_grad)
+        else:
+            loss = ops.FusedSoftmaxCEFn.apply(self.head.logits(rows), lab, self.head.output_vocab_size, code, unit_grad)
+        if self._packed is not None and n_real_tokens is not None:
+            # a wrong n_real_tokens would silently drop or invent tokens: the device-side count disagrees -> NaN loss
+            loss = loss + torch.where(self._packed.ids_packed[0] < 0, float('nan'), 0.0).to(loss.dtype)
+        return loss
 
     @torch.no_grad()
     def predict_topk(self, inputs, k, labels=None, flat_idx=None, packed=None, n_real_tokens=None):

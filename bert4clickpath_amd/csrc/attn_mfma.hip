@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(512, (QPW == 1 ? 4 : 2)) attn_fwd_mfma_kernel(
 
     // every global load of the workgroup is issued up front: the key-padding byte (unconditional on a clamped index: a
     // conditional load behind the staging barrier was an exposed round trip), Q fragments, then K / V rows
-    const uint8_t r_padk = key_pad[tok0 + (tid < S ? tid : S - 1)];       // S_pad <= 512 = threads
+    const uint8_t r_padk = key_pad[tok0 + (tid < S ? tid : S - 1)];       // S_pad <= 512 = threads (S > 0 here)
     bf16x8 qf[QPW][NKS];
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(512) attn_bwd_resident_kernel(const bf16_t *__
     // the spot; behind the staging they were two exposed round trips per item)
     const float r_lse = lbase[tid < S ? tid : (S > 0 ? S - 1 : 0)];      // S_pad <= 256 < 512 threads
     const int key_c = wave * 32 + r;
-    const uint8_t r_pad = key_pad[tok0 + (key_c < S ? key_c : (S > 0 ? S - 1 : 0))];
+    const uint8_t r_pad = key_pad[S > 0 ? tok0 + (key_c < S ? key_c : S - 1) : 0];      // (an empty sequence owns no row)
     {   // all global loads of the workgroup are issued before the first LDS write (one latency, not one per pass)
         constexpr int NIT = (256 * CH + 511) / 512;
         u32x4 rk[NIT], rv[NIT], rq[NIT], rg[NIT], ro[NIT];

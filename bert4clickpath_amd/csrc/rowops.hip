@@ -582,8 +582,12 @@ __global__ void __launch_bounds__(256) mask_count_kernel(const int64_t *__restri
     if (lane == 0) counts[wave] = c;
 }
 
+// clamp >= 0: offsets are clamped to it (the packed layout's caller-given token count: a wrong count must never index past
+// the tensors that were sized by it) and maxcount[0] is NEGATED when the true total differs from it (a poison flag the host
+// folds into the loss without a read-back)
 __global__ void __launch_bounds__(1024) mask_scan_kernel(const int32_t *__restrict__ counts, int B,
-                                                         int32_t *__restrict__ offsets, int32_t *__restrict__ maxcount) {
+                                                         int32_t *__restrict__ offsets, int32_t *__restrict__ maxcount,
+                                                         int32_t clamp = -1) {
     __shared__ int32_t part[1024];
     __shared__ int32_t pmax[1024];
     const int tid = threadIdx.x;
@@ -601,8 +605,12 @@ __global__ void __launch_bounds__(1024) mask_scan_kernel(const int32_t *__restri
         __syncthreads();
     }
     int32_t run = part[tid] - s;
-    for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
-    if (tid == 1023) { offsets[B] = part[1023]; if (maxcount) maxcount[0] = pmax[1023]; }
+    for (int i = lo; i < hi; ++i) { offsets[i] = (clamp >= 0 && run > clamp) ? clamp : run; run += counts[i]; }
+    if (tid == 1023) {
+        const int32_t total = part[1023];
+        offsets[B] = (clamp >= 0 && total > clamp) ? clamp : total;
+        if (maxcount) maxcount[0] = (clamp >= 0 && total != clamp) ? -pmax[1023] - 1 : pmax[1023];
+    }
 }
 
 // `inverse` (optional, int32 [B*S]): inverse[b*S + s] = rank of the hit in row-major order, -1 elsewhere
@@ -646,7 +654,7 @@ extern "C" int b4c_nonpad_positions(const int64_t *ids, int B, int S, int64_t pa
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)ceil_div64((int64_t)B * 64, 256);
     mask_count_kernel<true><<<grid, 256, 0, st>>>(ids, B, S, pad_value, counts);
-    mask_scan_kernel<<<1, 1024, 0, st>>>(counts, B, cu_seqlens, maxcount);
+    mask_scan_kernel<<<1, 1024, 0, st>>>(counts, B, cu_seqlens, maxcount, cap);
     mask_write_kernel<true><<<grid, 256, 0, st>>>(ids, B, S, pad_value, cu_seqlens, token_src, cap, packed_of);
     return b4c_check_launch("nonpad_positions");
 }

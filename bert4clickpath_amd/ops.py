@@ -159,7 +159,7 @@ def nonpad_positions(ids, cap, pad_value=0):
     dev = ids.device
     counts = torch.empty(B, dtype=torch.int32, device=dev)
     cu = torch.empty(B + 1, dtype=torch.int32, device=dev)
-    tok_src = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+    tok_src = torch.zeros(max(cap, 1), dtype=torch.int32, device=dev)      # rows past the true count (wrong cap) read token 0
     packed_of = torch.empty(B * S, dtype=torch.int32, device=dev)
     mx = torch.empty(1, dtype=torch.int32, device=dev)
     L.check(L.lib().b4c_nonpad_positions(_p(ids), B, S, pad_value, _p(counts), _p(cu), _p(tok_src), cap, _p(packed_of), _p(mx),

@@ -361,7 +361,9 @@ int b4c_row_scale_f32(const void *src, int ld, const float *scale, float *out, i
  * cu_seqlens.  Results at real positions are those of the dense layout.
  * b4c_nonpad_positions: counts[B] real tokens per sequence, cu_seqlens[B+1] (exclusive scan, cu[B] = T_real),
  *   token_src[cap] = b*S + s of every real token in row-major order, packed_of[B*S] = packed row of a dense position or -1
- *   (may be NULL), maxcount[1] = longest sequence (may be NULL).
+ *   (may be NULL), maxcount[1] = longest sequence (may be NULL).  `cap` is the caller's token count: cu_seqlens are
+ *   clamped to it (a wrong count can truncate sequences but never index past tensors sized by it), and when the true total
+ *   differs from it maxcount[0] is written as -(longest) - 1: a poison flag.
  * b4c_remap_index: out[i] = idx[i] >= 0 ? map[idx[i]] : -1 ([MASK] positions of the dense layout -> packed rows).
  * b4c_embed_concat_pe_fwd_packed: b4c_embed_concat_pe_fwd writing only rows t < n_tokens, row t taken from dense position
  *   token_src[t] (ids and positional row s = token_src[t] % S); the dropout counter is the packed element index.

@@ -166,6 +166,10 @@ def test_model_packed_equals_dense_and_oracle(gpu, two_features):
         t_dense, h_dense, _ = model.predict_topk(feats, 10, labels, packed=False)
         t_pack, h_pack, _ = model.predict_topk(feats, 10, labels, n_real_tokens=n_real)
         assert float((t_dense[:, 0] == t_pack[:, 0]).float().mean()) > 0.9
+    # a wrong token count poisons the loss instead of corrupting gradients silently (and never indexes out of bounds)
+    for wrong in (n_real - 7, n_real + 5):
+        bad = model.cloze_loss(feats, labels, training=False, max_masked_per_row=10, n_real_tokens=wrong)
+        assert bool(torch.isnan(bad))
     # the fp32 parity path refuses the packed layout instead of silently doing something else
     m32 = _model(V, dims, 1, 2, (32, 64), torch.float32)
     from bert4clickpath_amd._lib import B4CError
