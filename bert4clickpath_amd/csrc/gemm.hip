@@ -1016,7 +1016,11 @@ __global__ void __launch_bounds__(512) gemm_nt_wide_kernel(const bf16_t *__restr
 #undef AF
 }
 
-// Second form of the materialised vocabulary projection: 256-thread workgroups, TWO per CU (69 KB of LDS each), every wave
+// Second form of the materialised vocabulary projection (the DEFAULT since the logits live on a 256-B aligned row pitch,
+// ops.row_pitch: with V = 50,000 on its natural 100,000-B pitch both forms sat at 3.1 - 3.3 TB/s because every 256-B row
+// piece straddled 128-B lines; aligned, this form writes 4.8 - 4.9 TB/s = 0.60 of the HBM spec, the two-role form 3.3 - 3.5).
+// It is sensitive to code generation: a wave-uniform `if (plain) store else nontemporal store` in the store loop cost 17 %.
+// 256-thread workgroups, TWO per CU (69 KB of LDS each), every wave
 // computes AND moves; the phases of the two co-resident workgroups overlap (one stores its tile while the other
 // multiplies) instead of two wave roles inside one workgroup.  A fragments stay in registers for the workgroup's
 // whole chunk of N tiles, the next W tile is in flight in registers during the current tile's MFMAs and stores.
@@ -1121,7 +1125,7 @@ static int g_wide_form = -1;
 static int wide_form() {
     if (g_wide_form < 0) {
         const char *e = getenv("B4C_WIDE_FORM");
-        g_wide_form = e ? atoi(e) : 1;
+        g_wide_form = e ? atoi(e) : 2;
     }
     return g_wide_form;
 }

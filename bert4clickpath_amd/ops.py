@@ -237,6 +237,31 @@ def embed_concat_pe_bwd(ids_list, tables, dout, scale, rate, seed, into=None, or
     return dtabs
 
 
+def row_pitch(n):
+    """Row pitch (elements) of a materialised [rows, n] vocabulary-wide tensor: n rounded up to 128 elements, so that every
+    row starts on a 256-B boundary.  With V = 50,000 a bf16 row is 100,000 B and starts 32 B further into a 128-B line
+    than the row above it: a pure store kernel with the projection's tile shape then writes 3.8 TB/s, with aligned rows
+    5.5 TB/s (scratch/store_bw2.hip).  Narrow outputs keep their natural pitch."""
+    return n if n < 2048 else (n + 127) // 128 * 128
+
+
+def empty_rows(R, n, dtype, device):
+    """An uninitialised [R, n] tensor on the row_pitch(n) pitch (a view of a [R, pitch] allocation; contiguous when the
+    pitch is n)."""
+    ld = row_pitch(n)
+    buf = torch.empty(R, ld, dtype=dtype, device=device)
+    return buf if ld == n else buf[:, :n]
+
+
+def _rows_ok(g, dtype):
+    """g as the kernels take it: `dtype`, unit column stride, 16-B aligned rows -- copied only when it is not"""
+    if g.dtype != dtype:
+        g = g.to(dtype)
+    if g.dim() != 2 or g.stride(1) != 1 or (g.stride(0) * g.element_size()) % 16 or g.data_ptr() % 16:
+        g = g.contiguous()
+    return g
+
+
 def gemm_nt(a, bt, n, bias=None, act=L.ACT_NONE, gate=None, residual=None, out_dtype=None, out=None):
     """a: [M, Kp], bt: [>=n, Kp] -> [M, n] (written into `out`, a row-pitched [M, n] view, when given)"""
     M, K = a.shape
@@ -551,8 +576,11 @@ def scatter_rows(src, idx, n_dst):
 
 
 def softmax_rows(logits, V):
+    """probabilities with the shape and the row pitch of `logits` ([R, W >= V], pad columns are not written)"""
     R, ld = logits.shape[0], logits.stride(0)
     probs = torch.empty(R, ld, dtype=logits.dtype, device=logits.device)
+    if ld != logits.shape[1]:
+        probs = probs[:, :logits.shape[1]]
     if R == 0:
         return probs
     with _record('softmax_rows', 2 * R * ld * logits.element_size()):
@@ -1067,9 +1095,10 @@ class MLPFn(torch.autograd.Function):
             a = acts[-1]
             wt, _, bias = pk.get(x.dtype, a.shape[1], training)
             last = i == n - 1
+            odt = torch.float32 if (last and out_fp32 is True) else a.dtype
             with _timed('vocab_proj_fwd' if last else 'head_mlp_fwd'):
                 acts.append(gemm_nt(a, wt, pk.Np, bias, act=L.ACT_RELU if (relu_last or not last) else L.ACT_NONE,
-                                    out_dtype=torch.float32 if (last and out_fp32 is True) else None))
+                                    out_dtype=odt, out=empty_rows(a.shape[0], pk.Np, odt, a.device)))
         if training:
             ctx.save_for_backward(*(acts if relu_last else acts[:-1]))
             ctx.packs = packs
@@ -1086,7 +1115,7 @@ class MLPFn(torch.autograd.Function):
             g = g.to(acts[0].dtype)
         if ctx.relu_last:
             g = g * (acts[-1] > 0).to(g.dtype)
-        g = g.contiguous()
+        g = _rows_ok(g, acts[0].dtype)      # a pitched [R, Vp] view (empty_rows) is taken as it is
         grads = [None] * (2 * len(packs))
         dx = None
         inplace = _inplace_ok(*ctx.params)
@@ -1227,6 +1256,8 @@ class DropoutFn(torch.autograd.Function):
 def softmax_rows_bwd(probs, g, V):
     R, ld = probs.shape[0], probs.stride(0)
     dx = torch.empty(R, ld, dtype=probs.dtype, device=probs.device)
+    if ld != probs.shape[1]:
+        dx = dx[:, :probs.shape[1]]
     if R == 0:
         return dx
     L.check(L.lib().b4c_softmax_rows_bwd(_p(probs), ld, _p(g), g.stride(0), _p(dx), ld, R, V, dt_code(probs.dtype), _st()),
@@ -1472,14 +1503,15 @@ class TiedLogitsFn(torch.autograd.Function):
         wt, _, b = pack.get(h.dtype, h.shape[1], True)
         ctx.save_for_backward(h)
         ctx.pack, ctx.params = pack, (table, bias)
-        return gemm_nt(h, wt, pack.Np, b, out_dtype=torch.float32 if out_fp32 else None)
+        odt = torch.float32 if out_fp32 else h.dtype
+        return gemm_nt(h, wt, pack.Np, b, out_dtype=odt, out=empty_rows(h.shape[0], pack.Np, odt, h.device))
 
     @staticmethod
     def backward(ctx, g):
         (h,) = ctx.saved_tensors
         pack = ctx.pack
         table, bias = ctx.params
-        g = g.to(h.dtype).contiguous()
+        g = _rows_ok(g, h.dtype)
         _, wc, _ = pack.get(h.dtype, h.shape[1], True)
         dWt, db = gemm_tn(h, g, pack.K, pack.N)                 # [K, V] fp32, [V]
         dh = gemm_nt(g, wc, h.shape[1])

@@ -16,12 +16,13 @@ res = {1: [], 2: [], 3: []}
 for rnd in range(6):
     for form in (1, 2, 3):
         L.b4c_set_wide_form(form)
-        ops.gemm_nt(h, w, V, b)
+        buf = ops.empty_rows(R, V, torch.bfloat16, 'cuda')
+        ops.gemm_nt(h, w, V, b, out=buf)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            o = ops.gemm_nt(h, w, V, b)
+            o = ops.gemm_nt(h, w, V, b, out=buf)
         e1.record()
         torch.cuda.synchronize()
         res[form].append(e0.elapsed_time(e1) / 5)
