@@ -5,7 +5,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libb4c_hip.so')
+LIB_PATH = os.environ.get('B4C_LIB_PATH') or os.path.join(_HERE, 'libb4c_hip.so')     # override: A/B of two builds (scratch)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'b4c.h')
 
 F32, BF16 = 0, 1

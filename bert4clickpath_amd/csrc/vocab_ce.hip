@@ -396,7 +396,8 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e) dh[lane * E + e] = (bf16_t)0.f;
         if (lane == 0) {
-            a.item_loss[row] = (y >= a.V) ? NAN : 0.f;
+            // the NaN goes out as an integer pattern (it survives any floating-point option the file is compiled with)
+            reinterpret_cast<uint32_t *>(a.item_loss)[row] = (y >= a.V) ? 0x7fc00000u : 0u;
             *reinterpret_cast<f32x4 *>(rs) = (f32x4){INFINITY, 0.f, 0.f, -INFINITY};     // lse2 = +inf: p = 0
             *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){0.f, INFINITY, 0.f, 0.f};
         }

@@ -3,6 +3,7 @@
 memory, streams and the autograd tape only -- every FLOP and byte below runs in the
 hand-written HIP kernels.  No CPU path exists: CPU tensors raise ``B4CError``."""
 import ctypes
+import os
 
 import torch
 
@@ -1139,6 +1140,33 @@ class MLPFn(torch.autograd.Function):
         return (dx, None, None, None) + tuple(grads)
 
 
+# Vocabulary-head weight gradient on a side stream, under the encoder backward.  OFF by default: measured 10.78 -> 10.71 ms
+# per step only (the sweep's waves hold 212 registers each, two per SIMD: nothing else fits beside them, so the two kernels
+# time-slice the CUs instead of sharing them; the sweep stretches from 1.38 to 1.76 ms), and with a reducer the head's
+# bucket would become ready last.  B4C_OVERLAP_DW=1 switches it on.
+overlap_vocab_dw = os.environ.get('B4C_OVERLAP_DW', '0') == '1'
+_side_streams = {}
+_side_pending = []          # (event recorded on the side stream, parameters whose gradient it completes)
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _side_streams[device] = s
+    return s
+
+
+def join_side_work():
+    """The current stream waits for everything issued on the side stream; the gradients that work produced are then
+    announced (grad-ready callback).  Runs at the end of every backward pass that used the side stream (autograd engine
+    callback); optimizers and reducers call it too -- it is a no-op when nothing is pending."""
+    while _side_pending:
+        ev, params = _side_pending.pop(0)
+        torch.cuda.current_stream().wait_event(ev)
+        _ready(*params)
+
+
 class VocabCEFn(torch.autograd.Function):
     """R12 + R13 + R14 for training without the (R x V) logits: vocabulary projection, softmax, masked sparse
     CE (mean over valid rows) and their backward, logits recomputed in MFMA accumulators (csrc/vocab_ce.hip).
@@ -1178,8 +1206,22 @@ class VocabCEFn(torch.autograd.Function):
                 return dh, None, None, None, None, None, None, None
             return dh, None, None, None, None, None, dtab, db
         if _inplace_ok(kernel, bias):
-            vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel.grad, bias.grad)
-            _ready(kernel, bias)
+            if overlap_vocab_dw and h.is_cuda:
+                # The dW sweep is MFMA / VALU bound and leaves HBM idle; nothing in backward consumes its result.  It goes
+                # out on a side stream and runs UNDER the HBM-bound encoder backward; the main stream joins (and the
+                # gradient is announced to the reducer) when the backward pass ends (join_side_work).
+                main, side = torch.cuda.current_stream(h.device), _side_stream(h.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel.grad, bias.grad)
+                    ev = side.record_event()
+                for t in (h, rowscal, labels_i32, wt, b):
+                    t.record_stream(side)
+                _side_pending.append((ev, (kernel, bias)))
+                torch.autograd.Variable._execution_engine.queue_callback(join_side_work)
+            else:
+                vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel.grad, bias.grad)
+                _ready(kernel, bias)
             dW = db = None
         else:
             dW = torch.zeros(kernel.shape, dtype=torch.float32, device=h.device)

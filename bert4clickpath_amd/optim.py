@@ -64,6 +64,7 @@ class Adam:
         if not a.flat.is_cuda:
             raise ops.B4CError('Adam.step runs on the HIP device only')
         ops.flush_pending_dw()
+        ops.join_side_work()
         self.iterations += 1
         t = self.iterations
         lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)

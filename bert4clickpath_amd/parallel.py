@@ -153,6 +153,7 @@ class GradReducer:
         """Call after loss.backward(): reduces whatever has not been launched and waits."""
         from . import ops
         ops.flush_pending_dw()          # queued weight-gradient GEMMs (ops.queue_dw) must land before their bucket is reduced
+        ops.join_side_work()            # and so must what runs on the side stream (the vocabulary head's dW sweep)
         if self.world <= 1:
             self._touched.clear()
             return
