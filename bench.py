@@ -178,9 +178,10 @@ KERNEL_OF = {   # launch family (ops recorder) -> kernel symbol(s) in the rocpro
     'attn_fwd': 'attn_fwd_mfma_kernel', 'attn_bwd': 'attn_bwd_resident_kernel', 'softmax_ce': 'softmax_ce_bf16_kernel',
     'add_ln_fwd': 'add_ln_fwd_kernel', 'gemm_nt_ln': 'gemm_nt_ln_kernel (out-proj / FFN2 GEMM + residual + dropout + LayerNorm)', 'add_ln_bwd': 'add_ln_bwd_kernel', 'embed_fwd': 'embed_fwd_kernel',
     'embed_bwd': 'embed_bwd_kernel', 'adam': 'adam_kernel',
-    'vocab_ce_fwd': 'vce_token_kernel<128,0|1|2> + vce_combine_kernel (projection + softmax CE + dX, logits in registers)',
+    'vocab_ce_fwd': 'vce_token_kernel<128,1|2> + vce_combine_kernel (projection + softmax CE + dX, logits in registers)',
     'vocab_ce_dw': 'vce_dw_kernel + vce_label_kernel (projection dW / db, logits recomputed)',
-    'vocab_proj': 'gemm_nt_wide2_kernel (materialised vocabulary projection, R x V out)',
+    'vocab_proj': 'gemm_nt_wide2_kernel<true> (vocabulary projection with the softmax epilogue: probabilities R x V out)',
+    'vocab_lse': 'vce_token_kernel<128,0> + vce_lse_kernel (row lse of the logits, recomputed in registers)',
     'softmax_rows': 'softmax_rows_bf16_kernel (row in registers: one read, one write)', 'topk_rows': 'topk_rows_kernel'}
 
 

@@ -84,9 +84,20 @@ class SoftMaxHead(nn.Module):
     def forward(self, inputs, **kwargs):
         """inputs (B, M, d) -> probabilities (B, M, V), materialised as the reference does."""
         shp = inputs.shape
-        lg = self.logits(inputs.reshape(-1, shp[-1]))
+        x2d = inputs.reshape(-1, shp[-1])
         V = self.output_vocab_size
-        probs = ops.SoftmaxRowsFn.apply(lg, V)
+        probs = None
+        if ops.fused_softmax_proj and x2d.dtype == torch.bfloat16:
+            if not self._built():
+                self.build(x2d.shape[-1])
+                self.to(x2d.device)
+            K, kernel, bias = self._proj()
+            pack = self._packs[-1]
+            if getattr(pack, 'tied_offset', None) is None and K in (64, 128) and pack.Np >= 2048:
+                # one pass over the (R x V) tensor: the logits are recomputed for the row lse, never stored
+                probs = ops.VocabSoftmaxFn.apply(self.trunk(x2d), pack, V, kernel, bias)
+        if probs is None:
+            probs = ops.SoftmaxRowsFn.apply(self.logits(x2d), V)
         return probs.view(*shp[:-1], probs.shape[-1])[..., :V]
 
 

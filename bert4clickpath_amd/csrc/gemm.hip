@@ -1024,9 +1024,13 @@ __global__ void __launch_bounds__(512) gemm_nt_wide_kernel(const bf16_t *__restr
 // computes AND moves; the phases of the two co-resident workgroups overlap (one stores its tile while the other
 // multiplies) instead of two wave roles inside one workgroup.  A fragments stay in registers for the workgroup's
 // whole chunk of N tiles, the next W tile is in flight in registers during the current tile's MFMAs and stores.
+// SM: the epilogue writes softmax probabilities 2^((x + b) log2 e - lse2[row]) instead of logits (lse2 from b4c_vocab_lse):
+// Dense(V, softmax) of head.py:36 in one pass over the (R x V) tensor instead of three.
+template <bool SM>
 __global__ void __launch_bounds__(256, 2) gemm_nt_wide2_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ Bt, int ldb,
                                                             bf16_t *__restrict__ C, int ldc, int M, int N, int K,
-                                                            const float *__restrict__ bias, int mt, int tiles_per_chunk) {
+                                                            const float *__restrict__ bias, int mt, int tiles_per_chunk,
+                                                            const float *__restrict__ lse2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *sW = smem;
     char *sOut = smem + WIDE_TILE_BYTES;
@@ -1049,6 +1053,14 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_wide2_kernel(const bf16_t *__r
                 const int row = wm * 64 + i * 32 + r, col = kk * 16 + h * 8;
                 R[i * 8 + kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((row * lda + col) * 2) | oob_if(col >= K), 0, 0);
             }
+    }
+    float ls[2] = {0.f, 0.f};
+    if (SM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + wm * 64 + i * 32 + r;
+            ls[i] = row < M ? lse2[row] : 0.f;
+        }
     }
     u32x4 pw[8];
     float pb = 0.f;
@@ -1098,7 +1110,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_wide2_kernel(const bf16_t *__r
                     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
                     bf16x4_t w;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) w[k] = (bf16_t)(acc[j][i][4 * tq + k] + b4[k]);
+                    for (int k = 0; k < 4; ++k) {
+                        const float x = acc[j][i][4 * tq + k] + b4[k];
+                        w[k] = (bf16_t)(SM ? __builtin_amdgcn_exp2f(__builtin_fmaf(x, 1.4426950408889634f, -ls[i])) : x);
+                    }
                     *reinterpret_cast<bf16x4_t *>(sOut + (wm * 64 + i * 32 + r) * WOUT_STR + nl * 2) = w;
                 }
             }
@@ -1135,6 +1150,27 @@ static bool vec_ok_wide(const void *C, int ldc, int N, const float *bias) {
     return (N % 8 == 0) && (ldc % 8 == 0) && (((uintptr_t)C & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
 }
 
+// probabilities [M][N] (bf16) = softmax over N of (A Bt^T + bias), given lse2[row] = log2 sum_j 2^(x_j log2 e) (b4c_vocab_lse)
+extern "C" int b4c_gemm_nt_softmax(const void *A, int lda, const void *Bt, int ldb, void *C, int ldc, int M, int N, int K,
+                                   const float *bias, const float *lse2, void *stream) {
+    B4C_REQUIRE(A && Bt && C && lse2 && M > 0 && N > 0 && K > 0, "gemm_nt_softmax: null pointer / empty (M=%d N=%d K=%d)", M, N, K);
+    B4C_REQUIRE(K % 8 == 0 && K <= 128 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K,
+                "gemm_nt_softmax: K=%d (<= 128) lda=%d ldb=%d must be multiples of 8 with ld >= K", K, lda, ldb);
+    B4C_REQUIRE(ldc >= N && vec_ok_wide(C, ldc, N, bias), "gemm_nt_softmax: N=%d ldc=%d must be multiples of 8, C / bias 16-byte aligned", N, ldc);
+    B4C_REQUIRE((((uintptr_t)A | (uintptr_t)Bt) & 15) == 0, "gemm_nt_softmax: operands must be 16-byte aligned");
+    const int mt = (int)ceil_div64(M, TILE), ntn = (int)ceil_div64(N, TILE);
+    int chunks = (int)ceil_div64(512 * 5, mt);       // two workgroups per CU resident, ~5 rounds over the launch
+    if (chunks > ntn) chunks = ntn;
+    if (chunks < 1) chunks = 1;
+    const int tpc = (int)ceil_div64(ntn, chunks);
+    chunks = (int)ceil_div64(ntn, tpc);
+    const size_t shm = WIDE_TILE_BYTES + WOUT_BYTES + 128 * sizeof(float);
+    allow_lds(gemm_nt_wide2_kernel<true>, shm);
+    gemm_nt_wide2_kernel<true><<<mt * chunks, 256, shm, (hipStream_t)stream>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc,
+                                                                           M, N, K, bias, mt, tpc, lse2);
+    return b4c_check_launch("gemm_nt_softmax");
+}
+
 extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void *C, int ldc, int M, int N, int K,
                            const float *bias, int act, const void *gate, int ldg, const void *residual, int ldr,
                            int dtype, int out_dtype, void *stream) {
@@ -1163,8 +1199,8 @@ extern "C" int b4c_gemm_nt(const void *A, int lda, const void *Bt, int ldb, void
             const int tpc2 = (int)ceil_div64(ntn, chunks2);
             chunks2 = (int)ceil_div64(ntn, tpc2);
             const size_t shm2 = WIDE_TILE_BYTES + WOUT_BYTES + 128 * sizeof(float);
-            allow_lds(gemm_nt_wide2_kernel, shm2);
-            gemm_nt_wide2_kernel<<<mt * chunks2, 256, shm2, st_w>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, mt, tpc2);
+            allow_lds(gemm_nt_wide2_kernel<false>, shm2);
+            gemm_nt_wide2_kernel<false><<<mt * chunks2, 256, shm2, st_w>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (bf16_t *)C, ldc, M, N, K, bias, mt, tpc2, nullptr);
             return b4c_check_launch("gemm_nt_wide2");
         }
         const size_t shm_w = 2 * WIDE_TILE_BYTES + 2 * WOUT_BYTES + 2 * 128 * sizeof(float);

@@ -159,6 +159,8 @@ __device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, flo
 //           per-token reference m2 (raised, with U and l rescaled, only when a logit exceeds it by 2^12), P'^T
 //           feeds U += W^T P'^T from the accumulator registers.  One sweep gives lse and P W.
 //   MODE 2: second sweep for the tokens whose probabilities leave [1e-7, 1 - 1e-7]: Ud = P (1 - u) W, S, Pu.
+//   MODE 0: the statistics of MODE 1 alone (m2, l -> lse; no U, no min / max): the lse sweep in front of the
+//           materialised softmax projection (b4c_vocab_lse).
 // ------------------------------------------------------------------------------------------
 #define VCE_LAZY 12.0f
 
@@ -240,13 +242,14 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
         }
         const bool tail = (vt + 1) * 128 > a.V;      // some rows of this tile are past V (their logit is -inf)
         float e2 = lse2;                             // the exponent reference of this tile
-        if (MODE == 1) {
+        if (MODE != 2) {
             float tm = -INFINITY;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int t = 0; t < 16; ++t) tm = fmaxf(tm, acc[rt][t]);
-            if (!tail) {
+            if (MODE == 0) {
+            } else if (!tail) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -267,10 +270,12 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
                     const float al = __builtin_amdgcn_exp2f(m2 - tm2);     // 0 on the first tile (m2 = -inf)
                     m2 = tm2;
                     l *= al;
+                    if (MODE == 1) {
 #pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt)
+                        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) U[dt][t] *= al;
+                            for (int t = 0; t < 16; ++t) U[dt][t] *= al;
+                    }
                 }
             }
             e2 = (m2 == -INFINITY) ? 0.f : m2;      // no finite logit seen yet (a tail half-tile past V): p = 2^(-inf) = 0
@@ -293,7 +298,7 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -e2));
-                    if (MODE == 1) {
+                    if (MODE != 2) {
                         l += pv;
                         p[t] = pv;
                     } else {
@@ -307,6 +312,7 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
                     }
                 }
             }
+            if (MODE != 0)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pf = vce_pack8(p + 8 * s2);
@@ -333,6 +339,7 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
     // lanes of each token) are merged and stored row-major
     constexpr int USTR = KD + 4;                         // floats per token row
     float *sU = reinterpret_cast<float *>(smem) + wave * 32 * USTR;
+    if (MODE != 0)
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -341,10 +348,11 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
             *reinterpret_cast<f32x4 *>(sU + r * USTR + dt * 32 + 8 * tq + 4 * hf) = v;
         }
     f32x4 *sS = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(smem) + 8 * 32 * USTR);   // [wave][lane]
-    sS[wave * 64 + lane] = (MODE == 1) ? (f32x4){m2, l, mn, mx} : (f32x4){S, Pu, 0.f, 0.f};
+    sS[wave * 64 + lane] = (MODE != 2) ? (f32x4){m2, l, mn, mx} : (f32x4){S, Pu, 0.f, 0.f};
     __syncthreads();
     // token t of the tile: waves (t >> 5) and (t >> 5) + 4, lanes (t & 31) and (t & 31) + 32
     float *dst = (MODE == 1 ? a.u : a.ud) + (int64_t)part * a.R * KD;
+    if (MODE != 0)
     for (int c = tid; c < 128 * (KD / 4); c += 512) {
         const int t = c / (KD / 4), q = c % (KD / 4);
         if (tok0 + t < a.R) {
@@ -363,7 +371,7 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
     if (tid < 128 && tok0 + tid < a.R) {
         const int tgi = tid >> 5, ri = tid & 31;
         const f32x4 a0 = sS[tgi * 64 + ri], a1 = sS[tgi * 64 + ri + 32], b0 = sS[(tgi + 4) * 64 + ri], b1 = sS[(tgi + 4) * 64 + ri + 32];
-        if (MODE == 1) {
+        if (MODE != 2) {
             const float M = fmaxf(a0[0], b0[0]);     // the two lanes of a token share m2
             const float fa = __builtin_amdgcn_exp2f(a0[0] - M), fb = __builtin_amdgcn_exp2f(b0[0] - M);
             *reinterpret_cast<f32x4 *>(a.st1 + ((int64_t)part * a.R + tok0 + tid) * 4) =
@@ -678,6 +686,20 @@ __global__ void __launch_bounds__(256) vce_label_add_kernel(float *__restrict__ 
     }
 }
 
+// lse2[row] = log2 sum_j 2^(x_j log2 e) from the per-part statistics of vce_token_kernel<KD, 0>
+__global__ void __launch_bounds__(256) vce_lse_kernel(VceArgs a, float *__restrict__ lse2) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.R) return;
+    float M = -INFINITY, l = 0.f;
+    for (int p = 0; p < a.parts; ++p) {
+        const f32x4 s = *reinterpret_cast<const f32x4 *>(a.st1 + ((int64_t)p * a.R + row) * 4);
+        const float M2 = fmaxf(M, s[0]);
+        l = l * __builtin_amdgcn_exp2f(M - M2) + s[1] * __builtin_amdgcn_exp2f(s[0] - M2);
+        M = M2;
+    }
+    lse2[row] = M + __log2f(l);
+}
+
 // ------------------------------------------------------------------------------------------
 // Split `units` workgroup-sized pieces of work into units * p workgroups for 256 CUs (one workgroup per CU at a time):
 // time ~ rounds(p) / p, plus a cost per extra split (partial results to combine: `penalty`, in units of one
@@ -771,6 +793,34 @@ extern "C" int b4c_vocab_ce_fwd(const void *h, int ld_h, const void *wt, int ld_
     a.st1 = (float *)workspace; a.rowscal = rowscal; a.item_loss = item_loss; a.dh = (bf16_t *)dh;
     a.ld_h = ld_h; a.ld_w = ld_w; a.ld_dh = ld_dh; a.R = R; a.V = V; a.variant = variant;
     return K == 128 ? vce_fwd_launch<128>(a, (hipStream_t)stream) : vce_fwd_launch<64>(a, (hipStream_t)stream);
+}
+
+template <int KD>
+static int vce_lse_launch(VceArgs a, float *lse2, hipStream_t st) {
+    const int64_t ntt = ceil_div64(a.R, 128);
+    const int nvt = (a.V + 127) / 128;
+    a.parts = vce_pick_split(ntt, nvt, 0.005);
+    const size_t lds = vce_token_lds<KD>();
+    static thread_local bool done = false;
+    if (!done) { vce_allow_lds(vce_token_kernel<KD, 0>, lds); done = true; }
+    vce_token_kernel<KD, 0><<<dim3((unsigned)ntt, (unsigned)a.parts), 512, lds, st>>>(a);
+    vce_lse_kernel<<<(unsigned)ceil_div64(a.R, 256), 256, 0, st>>>(a, lse2);
+    return b4c_check_launch("vocab_lse");
+}
+
+extern "C" int b4c_vocab_lse(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, float *lse2, void *workspace,
+                             int64_t workspace_bytes, int64_t R, int V, int K, void *stream) {
+    B4C_REQUIRE(h && wt && lse2 && workspace, "vocab_lse: null pointer");
+    B4C_REQUIRE(vce_shape_ok(K), "vocab_lse: K=%d unsupported (64 or 128)", K);
+    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K, "vocab_lse: shape");
+    B4C_REQUIRE(ld_h % 8 == 0 && ld_w % 8 == 0 && ((((uintptr_t)h | (uintptr_t)wt | (uintptr_t)workspace) & 15) == 0),
+                "vocab_lse: operands must be 16-byte aligned with pitches % 8 == 0");
+    B4C_REQUIRE(workspace_bytes >= b4c_vocab_ce_workspace_bytes(R, V, K), "vocab_lse: workspace too small");
+    if (R == 0) return B4C_OK;
+    VceArgs a = {};
+    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.st1 = (float *)workspace;
+    a.ld_h = ld_h; a.ld_w = ld_w; a.R = R; a.V = V; a.variant = B4C_CE_PLAIN;
+    return K == 128 ? vce_lse_launch<128>(a, lse2, (hipStream_t)stream) : vce_lse_launch<64>(a, lse2, (hipStream_t)stream);
 }
 
 template <int KD>

@@ -659,6 +659,65 @@ def vocab_ce_dw(h, wt, bias, labels_i32, rowscal, V, dW, db):
                                         _p(dW), dW.stride(0), _p(db), ws.data_ptr(), ws.numel(), R, V, K, _st()), 'vocab_ce_dw')
 
 
+fused_softmax_proj = True      # Dense(V, softmax) of the bf16 path in one pass over (R x V): lse sweep + softmax epilogue
+
+
+def vocab_softmax(h, wt, bias, Np, V):
+    """probs [R, Np] (bf16, row_pitch(Np) pitch) = softmax over the first V columns of h wt^T + bias; columns V.. are 0.
+    The logits never reach HBM: b4c_vocab_lse recomputes them for the row lse, b4c_gemm_nt_softmax writes probabilities."""
+    R, K = h.shape
+    probs = empty_rows(R, Np, h.dtype, h.device)
+    if R == 0:
+        return probs
+    ws = _vce_workspace(h, R, V, K)
+    lse2 = torch.empty(R, dtype=torch.float32, device=h.device)
+    with _record('vocab_lse', R * K * 2 + V * K * 2, 2 * R * V * K):
+        L.check(L.lib().b4c_vocab_lse(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(lse2), ws.data_ptr(), ws.numel(),
+                                      R, V, K, _st()), 'vocab_lse')
+    with _record('vocab_proj', R * K * 2 + Np * K * 2 + R * Np * 2, 2 * R * Np * K):
+        L.check(L.lib().b4c_gemm_nt_softmax(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(probs), probs.stride(0), R, Np, K,
+                                            _p(bias), _p(lse2), _st()), 'gemm_nt_softmax')
+    if Np != V:
+        probs[:, V:].zero_()
+    return probs
+
+
+class VocabSoftmaxFn(torch.autograd.Function):
+    """Dense(V, softmax) (head.py:36) on the head's trunk output, probabilities materialised once, logits never:
+    apply(h [R, K] bf16, pack, V, kernel, bias) -> probs [R, Np].  Backward: the softmax Jacobian on the saved
+    probabilities (b4c_softmax_rows_bwd), then the projection's dW / db / dh as MLPFn does."""
+
+    @staticmethod
+    def forward(ctx, h, pack, V, kernel, bias):
+        h = h.contiguous()
+        training = any(ctx.needs_input_grad)       # (grad mode is off inside forward: ask what autograd will want)
+        wt, _, b = pack.get(h.dtype, h.shape[1], training)
+        probs = vocab_softmax(h, wt, b, pack.Np, V)
+        if training:
+            ctx.save_for_backward(h, probs)
+            ctx.pack, ctx.V, ctx.params = pack, V, (kernel, bias)
+        return probs
+
+    @staticmethod
+    def backward(ctx, g):
+        h, probs = ctx.saved_tensors
+        pack = ctx.pack
+        kernel, bias = ctx.params
+        g = _rows_ok(g, probs.dtype)
+        dlogits = softmax_rows_bwd(probs, g, ctx.V)
+        _, wc, _ = pack.get(h.dtype, h.shape[1], True)
+        if _inplace_ok(kernel, bias):
+            queue_dw(h, dlogits, pack.K, pack.N, [kernel.grad], [bias.grad], (kernel, bias))
+            dW = db = None
+        else:
+            dW, db = gemm_tn(h, dlogits, pack.K, pack.N)
+        with _timed('vocab_proj_dx'):
+            dh = gemm_nt(dlogits, wc, h.shape[1])
+        if dW is None:
+            flush_pending_dw()
+        return dh, None, None, dW, db
+
+
 topk_threshold = True     # threshold-selection kernel (one HBM read per row); False: per-thread sorted lists only
 
 

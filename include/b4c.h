@@ -251,6 +251,17 @@ int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const flo
                     const float *rowscal, float *dW, int ldw, float *db, void *workspace, int64_t workspace_bytes,
                     int64_t R, int V, int K, void *stream);
 
+/* ---- (ABI version 4) R12 for scoring: Dense(V, softmax) (head.py:36) with ONE pass over the (R x V) tensor ------------------
+ * replaces the materialised projection + softmax (b4c_gemm_nt + b4c_softmax_rows: write, read, write) of the
+ * bf16 path: b4c_vocab_lse recomputes the logits in MFMA accumulators (nothing reaches HBM) and leaves
+ * lse2[row] = log2 sum_j 2^(x_j log2 e); b4c_gemm_nt_softmax then writes probs [R][ldc] bf16 =
+ * 2^((h wt^T + bias) log2 e - lse2[row]) straight from its accumulators.  K in {64, 128} (lse) / K <= 128 (projection),
+ * N and ldc multiples of 8, operands 16-B aligned; workspace >= b4c_vocab_ce_workspace_bytes(R, V, K). */
+int b4c_vocab_lse(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, float *lse2, void *workspace,
+                  int64_t workspace_bytes, int64_t R, int V, int K, void *stream);
+int b4c_gemm_nt_softmax(const void *A, int lda, const void *Bt, int ldb, void *C, int ldc, int M, int N, int K,
+                        const float *bias, const float *lse2, void *stream);
+
 /* ---- R15: top-k ids, HitRate@k / NDCG@k -------------------------------------------------
  * replaces tf.math.top_k + the Recall / NDCG update_state arithmetic (utils.py:161-190, 225-255).
  * topk_idx[R][k] int32, largest first, ties -> lower index.  labels (int32, may be NULL):

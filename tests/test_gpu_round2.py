@@ -649,3 +649,69 @@ def test_sampled_head_in_the_model_trains(gpu):
     assert top.shape[1] == 10 and float(hit.mean()) > 0.3        # it memorises the one batch it saw
     from bert4clickpath_amd import ops
     ops.inplace_grads = False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('V,K,R', [(5000, 128, 300), (2048, 64, 257), (50000, 128, 1024), (2500, 128, 64)])
+def test_vocab_softmax_one_pass(V, K, R):
+    """b4c_vocab_lse + b4c_gemm_nt_softmax (Dense(V, softmax), head.py:36, logits never stored) against the fp64 softmax of
+    the same bf16 operands, and against the two-kernel form (projection + softmax_rows) it replaces."""
+    import torch
+    from bert4clickpath_amd import ops
+    torch.manual_seed(V + K)
+    dev = 'cuda'
+    h = (torch.randn(R, K, device=dev) * 0.7).bfloat16()
+    Np = ops.rup8(V)
+    w = torch.zeros(Np, K, device=dev)
+    w[:V] = torch.randn(V, K, device=dev) * 0.2
+    w = w.bfloat16()
+    b = torch.zeros(Np, device=dev)
+    b[:V] = torch.randn(V, device=dev)
+    probs = ops.vocab_softmax(h, w, b, Np, V)
+    assert probs.shape == (R, Np) and probs.stride(0) == ops.row_pitch(Np)
+    x = h.double() @ w[:V].double().t() + b[:V].double()
+    ref = torch.softmax(x, dim=1)
+    got = probs[:, :V].double()
+    # bf16 output: half an ulp = 2^-9 relative; the logits themselves are exact fp32 accumulations of bf16 products
+    assert float(((got - ref).abs() / (ref + 1e-30)).max()) < 6e-3
+    assert float((got.sum(1) - 1).abs().max()) < 4e-3
+    if Np != V:
+        assert float(probs[:, V:].abs().max()) == 0.0
+    two = ops.softmax_rows(ops.gemm_nt(h, w, Np, b, out=ops.empty_rows(R, Np, torch.bfloat16, dev)), V)
+    # the two-kernel form rounds the logits to bf16 first: 2^-9 of |x| <= ~8 in the exponent
+    assert float(((two[:, :V].double() - got).abs() / (ref + 1e-30)).max()) < 5e-2
+    assert (probs[:, :V].float().argmax(1) == ref.argmax(1)).float().mean() > 0.99
+
+
+@pytest.mark.gpu
+def test_softmax_head_one_pass_backward_matches_two_kernel_route():
+    """SoftMaxHead.forward through the one-pass kernels: probabilities and every gradient agree with the materialised
+    logits + softmax_rows route (ops.fused_softmax_proj = False) to bf16 rounding."""
+    import torch
+    from bert4clickpath_amd import ops
+    from bert4clickpath_amd.clickstream_transformer.head import SoftMaxHead
+    torch.manual_seed(5)
+    dev = 'cuda'
+    V, d, R = 3000, 64, 96
+    head = SoftMaxHead([128], V, input_dim=d).to(dev)
+    x = (torch.randn(2, R // 2, d, device=dev) * 0.5).bfloat16()
+    gsel = torch.randn(2, R // 2, V, device=dev).bfloat16()
+    res = {}
+    for fused in (True, False):
+        ops.fused_softmax_proj = fused
+        try:
+            for p in head.parameters():
+                p.grad = None
+            xx = x.clone().requires_grad_(True)
+            probs = head(xx)
+            (probs.float() * gsel.float()).sum().backward()
+            res[fused] = (probs.detach().float().clone(), xx.grad.float().clone(),
+                          {n: p.grad.detach().float().clone() for n, p in head.named_parameters()})
+        finally:
+            ops.fused_softmax_proj = True
+    pa, xa, ga = res[True]
+    pb, xb, gb = res[False]
+    assert float((pa - pb).abs().max()) < 2e-2 * float(pb.max())
+    assert float((xa - xb).abs().max()) < 3e-2 * float(xb.abs().max()) + 1e-6
+    for n in ga:
+        assert float((ga[n] - gb[n]).abs().max()) < 3e-2 * float(gb[n].abs().max()) + 1e-6, n
