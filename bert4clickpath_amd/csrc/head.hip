@@ -712,13 +712,14 @@ __global__ void __launch_bounds__(256) topk_rows_lists_kernel(const T *__restric
 }
 
 // Fast path: threshold selection.  Pass 1 finds every thread's best element; k rounds of block arg-max over those 256
-// values give T = the k-th best of them, a lower bound of the row's k-th best (at least k elements are >= T).  Pass 2
-// re-reads the row (it is 100 - 260 KB and was just read: served by L2) and collects the elements that are not worse than T
-// into LDS -- about k of them for continuous data -- and wave 0 picks the k best in order.  HBM sees the row once; the
+// values give T = the k-th best of them, a lower bound of the row's k-th best (at least k elements are >= T).  Pass 2:
+// the threads whose own maximum reaches T (about k of them) read their chunks again and put the elements that are not worse
+// than T into LDS -- about k for continuous data -- and wave 0 picks the k best in order.  The row is read once; the
 // per-thread sorted lists of the kernel above cost ~5,000 instructions per thread and row at k = 10 (562 GB/s).
 // Rows with more than TOPK_CAP candidates (massive ties) are flagged in `redo` and handled by the list kernel.
 #define TOPK_CAP 1024
 #define TOPK_THREADS 512
+#define TOPK_SLOTS 64          // threads per row that may hold candidates in the register-resident form
 // lane-strided arg-max over n (value, index) pairs in LDS by ONE wave; taken entries carry the sentinel index
 __device__ __forceinline__ void wave_argmax_lds(const float *v, const int *ix, int n, int lane, float &bv, int &bi, int &bp) {
     bv = -INFINITY; bi = 0x7fffffff; bp = -1;
@@ -744,6 +745,53 @@ __device__ __forceinline__ int wave_rank(float v, int j, int n) {
         rank += better(ov, oj, v, j) ? 1 : 0;
     }
     return rank;
+}
+
+// the k best of the cnt candidates in LDS, in order (wave 0), with the HitRate / NDCG terms of the row
+__device__ __forceinline__ void topk_select(float *cv, int *ci, int cnt, int k, int64_t row, int tid, int lane, int wave,
+                                            int32_t *__restrict__ topk_idx, const int32_t *__restrict__ labels,
+                                            float *__restrict__ hit, float *__restrict__ ndcg, int32_t *__restrict__ redo) {
+    if (cnt > TOPK_CAP) {
+        if (tid == 0) redo[row] = 1;
+    } else if (wave == 0) {
+        if (lane == 0) redo[row] = 0;
+        const int lab = labels ? labels[row] : -1;
+        if (cnt <= 64) {        // the usual case: one candidate per lane, ordered by rank counting
+            const float v = lane < cnt ? cv[lane] : -INFINITY;
+            const int j = lane < cnt ? ci[lane] : 0x7fffffff;
+            const int rank = wave_rank(v, j, cnt);
+            if (lane < cnt && rank < k) topk_idx[row * k + rank] = j;
+            if (lane >= cnt && lane < k) topk_idx[row * k + lane] = -1;          // fewer than k candidates (NaN rows)
+            const bool found = labels && lane < cnt && rank < k && j == lab;
+            const unsigned long long fb = __ballot(found);
+            if (found) {
+                if (hit) hit[row] = 1.f;
+                if (ndcg) ndcg[row] = 1.0f / (logf((float)(rank + 2)) / logf(2.0f));
+            } else if (fb == 0ull && lane == 0) {
+                if (hit) hit[row] = 0.f;
+                if (ndcg) ndcg[row] = 0.f;
+            }
+        } else {
+            float h_acc = 0.f, n_acc = 0.f;
+            for (int kk = 0; kk < k; ++kk) {
+                float bv; int bi, bp;
+                wave_argmax_lds(cv, ci, cnt, lane, bv, bi, bp);
+                if (lane == 0) {
+                    if (bp >= 0) ci[bp] = 0x7fffffff;
+                    topk_idx[row * k + kk] = bi == 0x7fffffff ? -1 : bi;
+                    if (labels && bi == lab) {
+                        h_acc += 1.f;
+                        n_acc += 1.0f / (logf((float)(kk + 2)) / logf(2.0f));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) {
+                if (hit) hit[row] = h_acc;
+                if (ndcg) ndcg[row] = n_acc;
+            }
+        }
+    }
 }
 
 template <typename T>
@@ -796,7 +844,10 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const T *__rest
         }
         __syncthreads();
         const float tv = s_tv;
-        for (int c0 = tid; c0 < nch; c0 += 4 * TOPK_THREADS) {      // second read of the row: L2 / Infinity Cache
+        // Candidates = the elements >= tv.  A thread whose own maximum is below tv holds none, so only the few threads
+        // with m >= tv (about k of the 512) read their chunks again: the row is NOT read a second time.
+        if (m >= tv)
+        for (int c0 = tid; c0 < nch; c0 += 4 * TOPK_THREADS) {
             float v[4][8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -817,48 +868,94 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const T *__rest
             }
         }
         __syncthreads();
-        const int cnt = s_cnt;
-        if (cnt > TOPK_CAP) {
-            if (tid == 0) redo[row] = 1;
-        } else if (wave == 0) {
-            if (lane == 0) redo[row] = 0;
-            const int lab = labels ? labels[row] : -1;
-            if (cnt <= 64) {        // the usual case: one candidate per lane, ordered by rank counting
-                const float v = lane < cnt ? cv[lane] : -INFINITY;
-                const int j = lane < cnt ? ci[lane] : 0x7fffffff;
-                const int rank = wave_rank(v, j, cnt);
-                if (lane < cnt && rank < k) topk_idx[row * k + rank] = j;
-                if (lane >= cnt && lane < k) topk_idx[row * k + lane] = -1;          // fewer than k candidates (NaN rows)
-                const bool found = labels && lane < cnt && rank < k && j == lab;
-                const unsigned long long fb = __ballot(found);
-                if (found) {
-                    if (hit) hit[row] = 1.f;
-                    if (ndcg) ndcg[row] = 1.0f / (logf((float)(rank + 2)) / logf(2.0f));
-                } else if (fb == 0ull && lane == 0) {
-                    if (hit) hit[row] = 0.f;
-                    if (ndcg) ndcg[row] = 0.f;
-                }
+        topk_select(cv, ci, s_cnt, k, row, tid, lane, wave, topk_idx, labels, hit, ndcg, redo);
+        __syncthreads();
+    }
+}
+
+// bf16, V <= 65536: the row stays in registers as raw bf16 pairs (NCH x 16 B per thread, all loads in flight at once), so the
+// candidate pass reads nothing: per row one sweep of loads, the threshold (wave 0), a register scan by the ~k threads whose
+// maximum reaches it, the selection (wave 0).  Against the re-reading form above the fixed cost per row drops from ~11 us
+// to the two serial sections.
+template <int NCH>
+__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_bf16_reg_kernel(const bf16_t *__restrict__ x, int ld, int64_t R, int V, int k,
+                                                                          int32_t *__restrict__ topk_idx, const int32_t *__restrict__ labels,
+                                                                          float *__restrict__ hit, float *__restrict__ ndcg,
+                                                                          int32_t *__restrict__ redo) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    __shared__ float cv[TOPK_CAP];
+    __shared__ int ci[TOPK_CAP];
+    __shared__ float mv[TOPK_THREADS];
+    __shared__ u32x4 stage[TOPK_SLOTS * NCH];
+    __shared__ int stage_tid[TOPK_SLOTS];
+    __shared__ int s_cnt, s_nslot;
+    __shared__ float s_tv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = (V + 7) >> 3;
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        const bf16_t *xr = x + row * ld;
+        u32x4 raw[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * TOPK_THREADS + tid;
+            // chunks past the row read as the most negative bf16 pattern (-inf): never a candidate
+            raw[i] = (c < nch) ? *reinterpret_cast<const u32x4 *>(xr + c * 8) : (u32x4){0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u};
+        }
+#define TK_ELEM(i, e) __uint_as_float(((e) & 1) ? (raw[i][(e) >> 1] & 0xFFFF0000u) : (raw[i][(e) >> 1] << 16))
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int base = (i * TOPK_THREADS + tid) * 8;
+            if (base + 8 <= V) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, TK_ELEM(i, e));
             } else {
-                float h_acc = 0.f, n_acc = 0.f;
-                for (int kk = 0; kk < k; ++kk) {
-                    float bv; int bi, bp;
-                    wave_argmax_lds(cv, ci, cnt, lane, bv, bi, bp);
-                    if (lane == 0) {
-                        if (bp >= 0) ci[bp] = 0x7fffffff;
-                        topk_idx[row * k + kk] = bi == 0x7fffffff ? -1 : bi;
-                        if (labels && bi == lab) {
-                            h_acc += 1.f;
-                            n_acc += 1.0f / (logf((float)(kk + 2)) / logf(2.0f));
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (lane == 0) {
-                    if (hit) hit[row] = h_acc;
-                    if (ndcg) ndcg[row] = n_acc;
-                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (base + e < V) m = fmaxf(m, TK_ELEM(i, e));
             }
         }
+        mv[tid] = m;
+        if (tid == 0) { s_cnt = 0; s_nslot = 0; }
+        __syncthreads();
+        if (wave == 0) {
+            float g = mv[lane];
+#pragma unroll
+            for (int w = 1; w < TOPK_THREADS / 64; ++w) g = fmaxf(g, mv[lane + 64 * w]);
+            const int rank = wave_rank(g, lane, 64);
+            if (rank == k - 1) s_tv = g;
+        }
+        __syncthreads();
+        const float tv = s_tv;
+        // the ~k threads whose maximum reaches tv park their registers in LDS; everybody then scans those few hundred
+        // elements with an ordinary loop (a fully unrolled per-element branch over the registers costs 249 VGPRs)
+        if (m >= tv) {
+            const int slot = atomicAdd(&s_nslot, 1);
+            if (slot < TOPK_SLOTS) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) stage[slot * NCH + i] = raw[i];
+                stage_tid[slot] = tid;
+            }
+        }
+        __syncthreads();
+        const int nslot = s_nslot;
+        if (nslot <= TOPK_SLOTS) {
+            const unsigned short *st16 = reinterpret_cast<const unsigned short *>(stage);
+            for (int q = tid; q < nslot * NCH * 8; q += TOPK_THREADS) {
+                const int slot = q / (NCH * 8), rr = q - slot * (NCH * 8);
+                const int j = ((rr >> 3) * TOPK_THREADS + stage_tid[slot]) * 8 + (rr & 7);
+                const float v = __uint_as_float((unsigned)st16[q] << 16);
+                if (j < V && v >= tv) {
+                    const int pos = atomicAdd(&s_cnt, 1);
+                    if (pos < TOPK_CAP) { cv[pos] = v; ci[pos] = j; }
+                }
+            }
+        } else if (tid == 0) {
+            s_cnt = TOPK_CAP + 1;        // more threads at the threshold than slots (mass ties): the list kernel redoes the row
+        }
+#undef TK_ELEM
+        __syncthreads();
+        topk_select(cv, ci, s_cnt, k, row, tid, lane, wave, topk_idx, labels, hit, ndcg, redo);
         __syncthreads();
     }
 }
@@ -881,7 +978,17 @@ extern "C" int b4c_topk_rows_ws(const void *scores, int ld, int64_t R, int V, in
     if (redo) {
         const int g2 = (int)(R < 2048 ? R : 2048);
         if (dtype == B4C_F32) topk_rows_kernel<float><<<g2, TOPK_THREADS, 0, st>>>((const float *)scores, ld, R, V, k, topk_idx, labels, hit, ndcg, redo);
-        else if (dtype == B4C_BF16) topk_rows_kernel<bf16_t><<<g2, TOPK_THREADS, 0, st>>>((const bf16_t *)scores, ld, R, V, k, topk_idx, labels, hit, ndcg, redo);
+        else if (dtype == B4C_BF16) {
+            const int per_thread = ((V + 7) / 8 + TOPK_THREADS - 1) / TOPK_THREADS;      // 16-B chunks per thread
+            const bool al = (((uintptr_t)scores) & 15) == 0;
+#define TOPK_REG(N) topk_rows_bf16_reg_kernel<N><<<g2, TOPK_THREADS, 0, st>>>((const bf16_t *)scores, ld, R, V, k, topk_idx, labels, hit, ndcg, redo)
+            if (al && per_thread <= 4) TOPK_REG(4);
+            else if (al && per_thread <= 8) TOPK_REG(8);
+            else if (al && per_thread <= 13) TOPK_REG(13);
+            else if (al && per_thread <= 16) TOPK_REG(16);
+            else topk_rows_kernel<bf16_t><<<g2, TOPK_THREADS, 0, st>>>((const bf16_t *)scores, ld, R, V, k, topk_idx, labels, hit, ndcg, redo);
+#undef TOPK_REG
+        }
         else B4C_REQUIRE(false, "topk_rows: dtype %d", dtype);
     }
 #define TOPK_LAUNCH(T, KM) topk_rows_lists_kernel<T, KM><<<grid, 256, 0, st>>>((const T *)scores, ld, R, V, k, topk_idx, labels, hit, ndcg, redo)

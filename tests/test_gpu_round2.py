@@ -715,3 +715,25 @@ def test_softmax_head_one_pass_backward_matches_two_kernel_route():
     assert float((xa - xb).abs().max()) < 3e-2 * float(xb.abs().max()) + 1e-6
     for n in ga:
         assert float((ga[n] - gb[n]).abs().max()) < 3e-2 * float(gb[n].abs().max()) + 1e-6, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('V', [1000, 5000, 30000, 65536, 70000])
+def test_topk_register_resident_widths(V):
+    """Every chunk count of the register-resident bf16 top-k (4 / 8 / 13 / 16 chunks per thread, and the re-reading form
+    beyond 65,536 columns) on a pitched view, against the stable-argsort restatement: indices bit-exact."""
+    from bert4clickpath_amd import ops
+    g = torch.Generator().manual_seed(V)
+    R, k = 24, 10
+    s = torch.randn(R, V, generator=g).bfloat16()
+    s[1, V - 1] = 9.0                                   # the very last column wins
+    s[2, :7] = 8.0                                      # ties -> lower index first
+    buf = ops.empty_rows(R, ops.rup8(V), torch.bfloat16, 'cuda')
+    buf.zero_()
+    buf[:, :V] = s.cuda()
+    labels = torch.randint(0, V, (R,), generator=g).int().cuda()
+    idx, hit, ndcg = ops.topk_rows(buf, V, k, labels)
+    _, want = nr.top_k(s.float().numpy(), k)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    h_want = (want == labels.cpu().numpy()[:, None]).any(1).astype(np.float32)
+    assert np.array_equal(hit.cpu().numpy(), h_want)
