@@ -284,13 +284,19 @@ class ClickstreamTransformer(nn.Module):
             if lab.shape[0] != rows.shape[0]:
                 raise ValueError('%d labels for %d masked positions' % (lab.shape[0], rows.shape[0]))
         code = CE_TF if variant == 'tf' else CE_PLAIN
+        # a wrong n_real_tokens would silently drop or invent tokens: the device-side count disagrees -> NaN loss
+        poison = self._packed.ids_packed if (self._packed is not None and n_real_tokens is not None) else None
         if hasattr(self.head, 'cloze_ce'):
-            loss = self.head.cloze_ce(rows, lab, code, unit_grad)
+            if poison is not None and getattr(self.head, 'accepts_poison', False):
+                loss = self.head.cloze_ce(rows, lab, code, unit_grad, poison=poison)      # folded into the loss kernel
+                poison = None
+            else:
+                loss = self.head.cloze_ce(rows, lab, code, unit_grad)
         else:
-            loss = ops.FusedSoftmaxCEFn.apply(self.head.logits(rows), lab, self.head.output_vocab_size, code, unit_grad)
-        if self._packed is not None and n_real_tokens is not None:
-            # a wrong n_real_tokens would silently drop or invent tokens: the device-side count disagrees -> NaN loss
-            loss = loss + torch.where(self._packed.ids_packed[0] < 0, float('nan'), 0.0).to(loss.dtype)
+            loss = ops.FusedSoftmaxCEFn.apply(self.head.logits(rows), lab, self.head.output_vocab_size, code, unit_grad, poison)
+            poison = None
+        if poison is not None:
+            loss = loss + torch.where(poison[0] < 0, float('nan'), 0.0).to(loss.dtype)
         return loss
 
     @torch.no_grad()

@@ -65,7 +65,9 @@ class SoftMaxHead(nn.Module):
             return x2d
         return ops.MLPFn.apply(x2d, self._packs[:-1], torch.is_grad_enabled(), 'relu_last', *self._params()[:-2])
 
-    def cloze_ce(self, x2d, labels_i32, variant, unit_grad=False):
+    accepts_poison = True      # cloze_ce(..., poison=): an int32 device flag whose negative value turns the loss into NaN
+
+    def cloze_ce(self, x2d, labels_i32, variant, unit_grad=False, poison=None):
         """Mean over valid rows of the sparse CE of softmax(Dense(V)(trunk(x))) -- loss only, for training.
         bf16 with a 64 / 128-wide projection input: the logits are never materialised (ops.VocabCEFn);
         otherwise logits + fused softmax / CE (ops.FusedSoftmaxCEFn)."""
@@ -73,8 +75,8 @@ class SoftMaxHead(nn.Module):
         h = self.trunk(x2d)
         K, kernel, bias = self._proj()
         if ops.flash_ce and ops.vocab_ce_supported(h, K):
-            return ops.VocabCEFn.apply(h, self._packs[-1], labels_i32, V, variant, unit_grad, kernel, bias)
-        return ops.FusedSoftmaxCEFn.apply(self._project(h), labels_i32, V, variant, unit_grad)
+            return ops.VocabCEFn.apply(h, self._packs[-1], labels_i32, V, variant, unit_grad, kernel, bias, poison)
+        return ops.FusedSoftmaxCEFn.apply(self._project(h), labels_i32, V, variant, unit_grad, poison)
 
     def _project(self, h, out_fp32=False):
         """Vocabulary projection alone: trunk output [R, K] -> logits [R, round_up(V, 8)]."""
@@ -286,6 +288,8 @@ class SampledSoftmaxHead(SoftMaxHead):
         """Rows of ``output_embedding`` the latest sampled training step touched (for GradReducer.set_touched_rows)."""
         s, y = self.last_samples
         return torch.cat([s, y.to(torch.int64).clamp(min=0)])
+
+    accepts_poison = False
 
     def cloze_ce(self, x2d, labels_i32, variant, unit_grad=False, samples=None):
         if not (torch.is_grad_enabled() and self.num_sampled > 0):

@@ -662,3 +662,118 @@ extern "C" int b4c_row_scale_f32(const void *src, int ld, const float *scale, fl
     else B4C_REQUIRE(false, "row_scale_f32: dtype %d", dtype);
     return b4c_check_launch("row_scale_f32");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small fused helpers of the loss's scalar bookkeeping (losses.py:80-98: mean over the non-pad rows).  Each replaces a
+// chain of 3-12 one-element PyTorch kernels (~5 us apiece on the step's critical path).
+// ------------------------------------------------------------------------------------------------------------------
+// out[0] = 1 / n_valid (0 when no row is valid), out[1] = n_valid;  valid = 0 <= label < V.  One workgroup, fixed order.
+__global__ void __launch_bounds__(1024) label_scale_kernel(const int32_t *__restrict__ labels, int64_t R, int V, float *__restrict__ out) {
+    __shared__ int part[16];
+    int c = 0;
+    for (int64_t i = threadIdx.x; i < R; i += 1024) {
+        const int y = labels[i];
+        c += (y >= 0 && y < V) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int w = 0; w < 16; ++w) n += part[w];
+        out[0] = n > 0 ? 1.0f / (float)n : 0.f;
+        out[1] = (float)n;
+    }
+}
+
+extern "C" int b4c_label_scale(const int32_t *labels, int64_t R, int V, float *out, void *stream) {
+    B4C_REQUIRE(out && R >= 0 && V > 0 && (labels || R == 0), "label_scale: bad argument");
+    label_scale_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(labels, R, V, out);
+    return b4c_check_launch("label_scale");
+}
+
+// out[0] = scale[0] * sum_r item[r]  (one workgroup, fixed order: repeatable); NaN when *poison < 0 (a device-side
+// consistency flag, e.g. the token count of the packed layout)
+__global__ void __launch_bounds__(1024) sum_scaled_kernel(const float *__restrict__ item, int64_t R, const float *__restrict__ scale,
+                                                          const int32_t *__restrict__ poison, float *__restrict__ out) {
+    __shared__ float part[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < R; i += 1024) s += item[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        t *= scale[0];
+        if (poison && poison[0] < 0) t = __uint_as_float(0x7fc00000u);
+        out[0] = t;
+    }
+}
+
+extern "C" int b4c_sum_scaled(const float *item, int64_t R, const float *scale, const int32_t *poison, float *out, void *stream) {
+    B4C_REQUIRE(scale && out && R >= 0 && (item || R == 0), "sum_scaled: bad argument");
+    sum_scaled_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(item, R, scale, poison, out);
+    return b4c_check_launch("sum_scaled");
+}
+
+// dh_out = g * dh (bf16 rows of K), rowscal_out = rowscal with its gradient-linear columns (c, nb, yd) times g: the upstream gradient folded into what
+// b4c_vocab_ce_fwd left for the backward (both are linear in it), in one launch; the inputs stay as they are.
+__global__ void __launch_bounds__(256) vce_apply_grad_kernel(const bf16_t *__restrict__ dh, int ld, const float *__restrict__ rowscal,
+                                                             const float *__restrict__ g, bf16_t *__restrict__ dh_out, int ld_out,
+                                                             float *__restrict__ rowscal_out, int64_t R, int K) {
+    const float gv = g[0];
+    const int cpr = K >> 3;
+    const int64_t total = R * (cpr + 1);
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (cpr + 1);
+        const int c = (int)(i - r * (cpr + 1));
+        if (c < cpr) {
+            float v[8];
+            Vec8<bf16_t>::load(dh + r * ld + c * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= gv;
+            Vec8<bf16_t>::store(dh_out + r * ld_out + c * 8, v);
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(rowscal + r * 8), b = *reinterpret_cast<const f32x4 *>(rowscal + r * 8 + 4);
+            // [lse2, c, nb, lo | yd, hi, -, -]: c, nb, yd are linear in the gradient scale; lo / hi are the clip range
+            *reinterpret_cast<f32x4 *>(rowscal_out + r * 8) = (f32x4){a[0], a[1] * gv, a[2] * gv, a[3]};
+            *reinterpret_cast<f32x4 *>(rowscal_out + r * 8 + 4) = (f32x4){b[0] * gv, b[1], b[2], b[3]};
+        }
+    }
+}
+
+extern "C" int b4c_vocab_ce_apply_grad(const void *dh, int ld, const float *rowscal, const float *g, void *dh_out, int ld_out,
+                                       float *rowscal_out, int64_t R, int K, void *stream) {
+    B4C_REQUIRE(dh && rowscal && g && dh_out && rowscal_out && R >= 0 && K > 0 && K % 8 == 0 && ld % 8 == 0 && ld_out % 8 == 0,
+                "vocab_ce_apply_grad: bad argument");
+    if (R == 0) return B4C_OK;
+    vce_apply_grad_kernel<<<ew_grid(R * (K / 8 + 1), 256), 256, 0, (hipStream_t)stream>>>((const bf16_t *)dh, ld, rowscal, g, (bf16_t *)dh_out,
+                                                                                    ld_out, rowscal_out, R, K);
+    return b4c_check_launch("vocab_ce_apply_grad");
+}
+
+// out = act > 0 ? g : 0 (elementwise, n a multiple of 8): the ReLU of the head's trunk output applied to the gradient that
+// arrives from the vocabulary head
+template <typename T>
+__global__ void __launch_bounds__(256) relu_gate_kernel(const T *__restrict__ g, const T *__restrict__ act, T *__restrict__ out, int64_t n8) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float a[8], b[8];
+        Vec8<T>::load(g + i * 8, a);
+        Vec8<T>::load(act + i * 8, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = b[k] > 0.f ? a[k] : 0.f;
+        Vec8<T>::store(out + i * 8, a);
+    }
+}
+
+extern "C" int b4c_relu_gate(const void *g, const void *act, void *out, int64_t n, int dtype, void *stream) {
+    B4C_REQUIRE(g && act && out && n >= 0 && n % 8 == 0, "relu_gate: n=%lld must be a multiple of 8", (long long)n);
+    if (n == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == B4C_F32) relu_gate_kernel<float><<<ew_grid(n / 8, 256), 256, 0, st>>>((const float *)g, (const float *)act, (float *)out, n / 8);
+    else if (dtype == B4C_BF16) relu_gate_kernel<bf16_t><<<ew_grid(n / 8, 256), 256, 0, st>>>((const bf16_t *)g, (const bf16_t *)act, (bf16_t *)out, n / 8);
+    else B4C_REQUIRE(false, "relu_gate: dtype %d", dtype);
+    return b4c_check_launch("relu_gate");
+}

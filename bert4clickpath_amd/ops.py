@@ -612,6 +612,30 @@ def softmax_ce_fwd_bwd_(logits, labels_i32, grad_scale, V, variant=L.CE_TF):
     return item
 
 
+def label_scale(labels_i32, V):
+    """-> fp32 [2]: 1 / n_valid (0 if no row is valid) and n_valid, valid = 0 <= label < V  (one launch)."""
+    out = torch.empty(2, dtype=torch.float32, device=labels_i32.device)
+    L.check(L.lib().b4c_label_scale(_p(labels_i32), labels_i32.shape[0], V, _p(out), _st()), 'label_scale')
+    return out
+
+
+def sum_scaled(item, scale, poison=None):
+    """-> 0-dim fp32: scale[0] * sum(item) in a fixed order; NaN when the int32 flag `poison`[0] is negative."""
+    out = torch.empty((), dtype=torch.float32, device=item.device)
+    L.check(L.lib().b4c_sum_scaled(_p(item), item.shape[0], _p(scale), _p(poison), _p(out), _st()), 'sum_scaled')
+    return out
+
+
+def relu_gate(g, act):
+    """g where act > 0, else 0 (same shape / dtype, contiguous, element count a multiple of 8)."""
+    g, act = g.contiguous(), act.contiguous()
+    out = torch.empty_like(g)
+    if g.numel() == 0:
+        return out
+    L.check(L.lib().b4c_relu_gate(_p(g), _p(act), _p(out), g.numel(), dt_code(g.dtype), _st()), 'relu_gate')
+    return out
+
+
 _vce_ws = {}
 
 
@@ -1174,7 +1198,10 @@ class MLPFn(torch.autograd.Function):
         if g.dtype != acts[0].dtype:
             g = g.to(acts[0].dtype)
         if ctx.relu_last:
-            g = g * (acts[-1] > 0).to(g.dtype)
+            if g.is_cuda and g.numel() % 8 == 0 and g.dtype == acts[-1].dtype:
+                g = relu_gate(g, acts[-1])
+            else:
+                g = g * (acts[-1] > 0).to(g.dtype)
         g = _rows_ok(g, acts[0].dtype)      # a pitched [R, Vp] view (empty_rows) is taken as it is
         grads = [None] * (2 * len(packs))
         dx = None
@@ -1232,25 +1259,26 @@ class VocabCEFn(torch.autograd.Function):
     apply(h, pack, labels_i32, V, variant, unit_grad, kernel, bias)"""
 
     @staticmethod
-    def forward(ctx, h, pack, labels_i32, V, variant, unit_grad, kernel, bias):
+    def forward(ctx, h, pack, labels_i32, V, variant, unit_grad, kernel, bias, poison=None):
         h = h.contiguous()
         wt, _, b = pack.get(h.dtype, h.shape[1], False)
-        valid = ((labels_i32 >= 0) & (labels_i32 < V)).sum().to(torch.float32)
-        scale = torch.where(valid > 0, 1.0 / valid.clamp(min=1.0), torch.zeros_like(valid)).reshape(1)
+        scale = label_scale(labels_i32, V)                    # [1 / n_valid, n_valid]
         item, dh, rowscal = vocab_ce_fwd(h, wt, b, labels_i32, scale, V, variant)
         ctx.save_for_backward(h, dh, rowscal, labels_i32)
         ctx.pack, ctx.V, ctx.unit_grad = pack, V, unit_grad
         ctx.params = (kernel, bias)
-        return item.sum() * scale[0]
+        return sum_scaled(item, scale, poison)
 
     @staticmethod
     def backward(ctx, g):
         h, dh, rowscal, labels_i32 = ctx.saved_tensors
         kernel, bias = ctx.params
         if not ctx.unit_grad:       # the kernels ran at scale 1/valid in forward: fold the upstream gradient in now
-            dh = dh * g.to(dh.dtype)
-            rowscal = rowscal.clone()
-            rowscal[:, 1:5] *= g.to(torch.float32)      # c, +-a, b, yd are linear in the upstream gradient
+            gf = g.to(torch.float32).reshape(1).contiguous()
+            dh_g, rowscal_g = torch.empty_like(dh), torch.empty_like(rowscal)
+            L.check(L.lib().b4c_vocab_ce_apply_grad(_p(dh), dh.stride(0), _p(rowscal), _p(gf), _p(dh_g), dh_g.stride(0),
+                                                    _p(rowscal_g), dh.shape[0], dh.shape[1], _st()), 'vocab_ce_apply_grad')
+            dh, rowscal = dh_g, rowscal_g
         wt, _, b = ctx.pack.get(h.dtype, h.shape[1], False)
         off = getattr(ctx.pack, 'tied_offset', None)
         if off is not None:     # tied head: `kernel` is the (rows, K) embedding table; dW [K, V] is added transposed
@@ -1262,8 +1290,8 @@ class VocabCEFn(torch.autograd.Function):
             transpose_add_(dtab[off:off + ctx.V], dWt)
             if inplace:
                 _ready(bias)        # the table is announced by the embedding backward, which runs last
-                return dh, None, None, None, None, None, None, None
-            return dh, None, None, None, None, None, dtab, db
+                return dh, None, None, None, None, None, None, None, None
+            return dh, None, None, None, None, None, dtab, db, None
         if _inplace_ok(kernel, bias):
             if overlap_vocab_dw and h.is_cuda:
                 # The dW sweep is MFMA / VALU bound and leaves HBM idle; nothing in backward consumes its result.  It goes
@@ -1286,7 +1314,7 @@ class VocabCEFn(torch.autograd.Function):
             dW = torch.zeros(kernel.shape, dtype=torch.float32, device=h.device)
             db = torch.zeros(bias.shape, dtype=torch.float32, device=h.device)
             vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, dW, db)
-        return dh, None, None, None, None, None, dW, db
+        return dh, None, None, None, None, None, dW, db, None
 
 
 class GatherRowsFn(torch.autograd.Function):
@@ -1309,22 +1337,20 @@ class FusedSoftmaxCEFn(torch.autograd.Function):
     rows), and d loss / d logits written in place of the logits (which are consumed)."""
 
     @staticmethod
-    def forward(ctx, logits, labels_i32, V, variant, unit_grad):
-        valid = ((labels_i32 >= 0) & (labels_i32 < V)).sum().to(torch.float32)
-        scale = torch.where(valid > 0, 1.0 / valid.clamp(min=1.0), torch.zeros_like(valid)).reshape(1)
+    def forward(ctx, logits, labels_i32, V, variant, unit_grad, poison=None):
+        scale = label_scale(labels_i32, V)                    # [1 / n_valid, n_valid]
         with _timed('softmax_ce'):
             item = softmax_ce_fwd_bwd_(logits, labels_i32, scale, V, variant)
         ctx.save_for_backward(logits)
         ctx.unit_grad = unit_grad
-        loss = (item.sum() * scale[0])
-        return loss
+        return sum_scaled(item, scale, poison)
 
     @staticmethod
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
         if not ctx.unit_grad:
             dlogits = dlogits * g.to(dlogits.dtype)
-        return dlogits, None, None, None, None
+        return dlogits, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------

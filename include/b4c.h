@@ -262,6 +262,18 @@ int b4c_vocab_lse(const void *h, int ld_h, const void *wt, int ld_w, const float
 int b4c_gemm_nt_softmax(const void *A, int lda, const void *Bt, int ldb, void *C, int ldc, int M, int N, int K,
                         const float *bias, const float *lse2, void *stream);
 
+/* ---- (ABI version 4) scalar bookkeeping of the masked mean (losses.py:80-98) and of the head's backward, fused:
+ * b4c_label_scale: out[0] = 1 / n_valid (0 if none), out[1] = n_valid, valid = 0 <= label < V (the mask of losses.py:80).
+ * b4c_sum_scaled:  out[0] = scale[0] * sum item[0..R) in a fixed order; NaN if poison != NULL and poison[0] < 0.
+ * b4c_vocab_ce_apply_grad: folds the upstream gradient g (device scalar) into what b4c_vocab_ce_fwd left for the
+ *   backward: dh_out = g * dh, rowscal_out = rowscal with its gradient-linear columns times g.
+ * b4c_relu_gate:   out = act > 0 ? g : 0 (n elements, a multiple of 8): relu'(Dense) of head.py:35 on a gradient. */
+int b4c_label_scale(const int32_t *labels, int64_t R, int V, float *out, void *stream);
+int b4c_sum_scaled(const float *item, int64_t R, const float *scale, const int32_t *poison, float *out, void *stream);
+int b4c_vocab_ce_apply_grad(const void *dh, int ld, const float *rowscal, const float *g, void *dh_out, int ld_out,
+                            float *rowscal_out, int64_t R, int K, void *stream);
+int b4c_relu_gate(const void *g, const void *act, void *out, int64_t n, int dtype, void *stream);
+
 /* ---- R15: top-k ids, HitRate@k / NDCG@k -------------------------------------------------
  * replaces tf.math.top_k + the Recall / NDCG update_state arithmetic (utils.py:161-190, 225-255).
  * topk_idx[R][k] int32, largest first, ties -> lower index.  labels (int32, may be NULL):

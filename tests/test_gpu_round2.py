@@ -737,3 +737,34 @@ def test_topk_register_resident_widths(V):
     assert np.array_equal(idx.cpu().numpy(), want)
     h_want = (want == labels.cpu().numpy()[:, None]).any(1).astype(np.float32)
     assert np.array_equal(hit.cpu().numpy(), h_want)
+
+
+@pytest.mark.gpu
+def test_vocab_ce_upstream_gradient_in_the_clip_regime():
+    """The upstream gradient folded into the logits-free head (b4c_vocab_ce_apply_grad) when rows ARE in TF's clip regime
+    (probabilities below 1e-7): g scales the gradient-linear row scalars only, never the clip range -- 0.5 x loss gives
+    exactly half of dh, dW and db (powers of two commute with every rounding), 0.37 x within bf16 rounding.
+    (Scaling all of rowscal[:, 1:5], as the host code once did, moved the lower clip bound with g.)"""
+    from bert4clickpath_amd import ops
+    torch.manual_seed(11)
+    dev = 'cuda'
+    R, K, V = 96, 64, 4000
+    h0 = (torch.randn(R, K, device=dev) * 2.0).bfloat16()
+    kern = torch.nn.Parameter(torch.randn(K, V, device=dev) * 0.8)            # wide logits: many p < 1e-7
+    bias = torch.nn.Parameter(torch.zeros(V, device=dev))
+    pack = ops.PackedLinear([kern], [bias])
+    lab = torch.randint(0, V, (R,), device=dev, dtype=torch.int32)
+    res = {}
+    for mul in (1.0, 0.5, 0.37):
+        h = h0.clone().requires_grad_(True)
+        kern.grad = bias.grad = None
+        loss = ops.VocabCEFn.apply(h, pack, lab, V, ops.L.CE_TF, False, kern, bias)
+        (mul * loss).backward()
+        res[mul] = (h.grad.float().clone(), kern.grad.clone(), bias.grad.clone())
+    logits = h0.float() @ kern.detach().bfloat16().float()
+    p = torch.softmax(logits, 1)
+    assert float((p < 1e-7).float().mean()) > 0.05                            # the clip regime is exercised
+    for a, b in zip(res[1.0], res[0.5]):
+        assert torch.equal(0.5 * a, b)
+    for a, b in zip(res[1.0], res[0.37]):
+        assert float((0.37 * a - b).abs().max()) <= 2e-2 * float(a.abs().max()) * 0.37 + 1e-12
