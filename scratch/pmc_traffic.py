@@ -8,6 +8,7 @@ FAM = [('gemm_nt_ln', ('gemm_nt_ln_kernel', 'gemm_nt_ln256_kernel'), None), ('vo
        ('attn_bwd', ('attn_bwd',), None), ('attn_fwd', ('attn_fwd',), None), ('softmax_ce', ('softmax_ce',), None),
        ('add_ln_fwd', ('add_ln_fwd',), None), ('add_ln_bwd', ('add_ln_bwd',), None), ('embed_bwd', ('embed_bwd',), None),
        ('embed_fwd', ('embed_fwd',), None), ('adam', ('adam_kernel',), None),
+       ('vocab_lse', ('vce_token_kernel<128, 0>', 'vce_token_kernel<64, 0>', 'vce_token_kernelILi128ELi0E', 'vce_lse_kernel'), 'vce_lse_kernel'),
        ('vocab_ce_fwd', ('vce_token_kernel', 'vce_combine_kernel'), 'vce_combine_kernel'),
        ('vocab_ce_dw', ('vce_dw_kernel', 'vce_label'), 'vce_dw_kernel')]
 def fam_of(name):
