@@ -768,3 +768,30 @@ def test_vocab_ce_upstream_gradient_in_the_clip_regime():
         assert torch.equal(0.5 * a, b)
     for a, b in zip(res[1.0], res[0.37]):
         assert float((0.37 * a - b).abs().max()) <= 2e-2 * float(a.abs().max()) * 0.37 + 1e-12
+
+
+@pytest.mark.gpu
+def test_loss_bookkeeping_kernels():
+    """b4c_label_scale / b4c_sum_scaled / b4c_relu_gate against their one-line restatements (losses.py:80-98: the mask is
+    label != pad, the loss the mean over the masked rows)."""
+    from bert4clickpath_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for R, V in ((1, 10), (37, 10), (5000, 300), (40960, 50000)):
+        lab = torch.randint(-3, V + 3, (R,), generator=g).int().cuda()
+        sc = ops.label_scale(lab, V).cpu().numpy()
+        n = int(((lab >= 0) & (lab < V)).sum())
+        assert sc[1] == n and sc[0] == (np.float32(1.0) / np.float32(n) if n else 0.0)
+        item = torch.rand(R, generator=g).cuda()
+        scale = torch.tensor([0.25, 0.0]).cuda()
+        got = float(ops.sum_scaled(item, scale))
+        assert abs(got - 0.25 * float(item.double().sum())) <= 1e-5 * max(1.0, abs(got))
+        bad = torch.tensor([-7], dtype=torch.int32).cuda()
+        ok = torch.tensor([5], dtype=torch.int32).cuda()
+        assert np.isnan(float(ops.sum_scaled(item, scale, bad))) and float(ops.sum_scaled(item, scale, ok)) == got
+    empty = torch.zeros(0, dtype=torch.int32).cuda()
+    assert ops.label_scale(empty, 10).tolist() == [0.0, 0.0]
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(64, 24, generator=g).to(dt).cuda()
+        act = torch.randn(64, 24, generator=g).to(dt).cuda()
+        act[0, :5] = 0.0
+        assert torch.equal(ops.relu_gate(x, act), torch.where(act > 0, x, torch.zeros_like(x)))
