@@ -57,7 +57,7 @@ def parse():
     ap.add_argument('--full_length', action='store_true', help='SURVEY 8d no-padding variant: every sequence has 197 items (the packed '
                     'layout then equals the dense one)')
     ap.add_argument('--host_flat_idx', action='store_true', help='A/B: hand the step host-precomputed [MASK] indices (round-1 bench)')
-    ap.add_argument('--record_steps', type=int, default=5,
+    ap.add_argument('--record_steps', type=int, default=3,
                     help='timed steps (the first N of the timed region) whose launches are bracketed by HIP events for the roofline; '
                          '-1 = all (costs ~0.4 ms/step of event overhead), 0 = none')
     ap.add_argument('--ops_flags', default='', help='A/B switches of bert4clickpath_amd.ops, e.g. "fused_ln=0,sorted_embed_bwd=0"')
