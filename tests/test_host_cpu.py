@@ -158,3 +158,21 @@ def test_reference_import_paths_resolve():
     from clickstream_transformer.losses import MaskedLoss   # noqa: F401
     from clickstream_transformer.constants import RESERVED_TOKENS, LABEL_PAD   # noqa: F401
     from clickstream_transformer.training_utils import load_vocabulary   # noqa: F401
+
+
+def test_row_pitch_of_vocabulary_wide_tensors():
+    """ops.row_pitch / empty_rows: vocabulary-wide rows start on 256-byte boundaries (128 elements), narrow ones keep their
+    width; the view handed out has the requested shape, and a (B, M, V) view of it reshapes to rows without a copy."""
+    import torch
+    from bert4clickpath_amd import ops
+    assert ops.row_pitch(104) == 104 and ops.row_pitch(2047) == 2047
+    assert ops.row_pitch(2048) == 2048 and ops.row_pitch(50000) == 50048 and ops.row_pitch(100000) == 100096
+    t = ops.empty_rows(6, 50000, torch.bfloat16, 'cpu')
+    assert t.shape == (6, 50000) and t.stride() == (50048, 1) and (t.stride(0) * t.element_size()) % 256 == 0
+    assert ops.empty_rows(6, 104, torch.float32, 'cpu').is_contiguous()
+    v = t.view(2, 3, 50000)
+    r = v.reshape(-1, 50000)
+    assert r.data_ptr() == t.data_ptr() and r.stride() == (50048, 1)
+    g = ops._rows_ok(t, torch.bfloat16)
+    assert g.data_ptr() == t.data_ptr()                      # pitched rows are taken as they are
+    assert ops._rows_ok(t.t()[:8].t(), torch.bfloat16).stride(1) == 1
