@@ -872,7 +872,7 @@ _desc_cache = {}
 
 def repack_stale(dtype, dev):
     """One launch refreshes every allocated compute copy (this dtype / device) whose masters changed."""
-    descs, ents, max_tiles = [], [], 1
+    descs, ents, tiles = [], [], []
     alive = []
     for ref in _pack_registry:
         pk = ref()
@@ -888,10 +888,16 @@ def repack_stale(dtype, dev):
                 continue
             descs += pk._descs(ent, Kp)
             ents.append((ent, key))
-            max_tiles = max(max_tiles, max(((pk.K + 31) // 32) * ((n + 31) // 32) for n in pk.Ns))
+            tiles += [((pk.K + 31) // 32) * ((n + 31) // 32) for n in pk.Ns]
     _pack_registry[:] = alive
     if not descs:
         return
+    # The launch is a (largest tile count) x (descriptors) grid whose surplus workgroups exit at once; one vocabulary
+    # projection (6,252 tiles of 32 x 32 at C2) beside thirty encoder matrices (16 tiles each) made that 180,000 workgroups
+    # for 7,500 tiles of work.  Descriptors are ordered by size and launched in groups of similar size (a factor of 8).
+    order = sorted(range(len(descs)), key=lambda i: tiles[i])
+    descs = [descs[i] for i in order]
+    tiles = [tiles[i] for i in order]
     sig = tuple((d.src, d.wt, d.wc, d.bias_src) for d in descs)
     cached = _desc_cache.get((dtype, dev))
     if cached is None or cached[0] != sig:
@@ -899,9 +905,16 @@ def repack_stale(dtype, dev):
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         cached = (sig, host.to(dev))
         _desc_cache[(dtype, dev)] = cached
+    esz = ctypes.sizeof(L.PackDesc)
     with torch.no_grad():
-        L.check(L.lib().b4c_pack_weights_batched(cached[1].data_ptr(), len(descs), max_tiles, dt_code(dtype), _st()),
-                'pack_weights_batched')
+        i0 = 0
+        while i0 < len(descs):
+            i1 = i0 + 1
+            while i1 < len(descs) and tiles[i1] <= 8 * max(tiles[i0], 1):
+                i1 += 1
+            L.check(L.lib().b4c_pack_weights_batched(cached[1].data_ptr() + i0 * esz, i1 - i0, max(tiles[i1 - 1], 1),
+                                                     dt_code(dtype), _st()), 'pack_weights_batched')
+            i0 = i1
     for ent, key in ents:
         ent['key'] = key
 
