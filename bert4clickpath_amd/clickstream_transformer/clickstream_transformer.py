@@ -144,7 +144,9 @@ class ClickstreamTransformer(nn.Module):
         return flat.reshape(a.shape)
 
     # ---- shared front half: chain, look up, encode -------------------------------------------
-    def _encode(self, inputs, training, pack=False, n_real_tokens=None):
+    def _encode(self, inputs, training, pack=False, n_real_tokens=None, rows_of=None):
+        """rows_of(ids_first, raw_first) -> (flat_idx, offsets, extra) or None: called once the ids are known; when it returns
+        indices, the last encoder layer is evaluated at those positions only and `enc` is the (R, d) rows."""
         raw_features, seg_starts, seg_ends = self.transformer_input_prep(features=inputs)
         dev = self.transformer.pos_encoding.device
         if dev.type != 'cuda':
@@ -175,7 +177,16 @@ class ClickstreamTransformer(nn.Module):
                     counts, cu, tok_src, packed_of, mx = ops.nonpad_positions(ids0, T_real)
             self._packed = ops.Packed(cu, tok_src, packed_of, B, S, T_real, S)
             self._packed.ids_packed = mx          # < 0: the given n_real_tokens was wrong (poisons the loss, see cloze_loss)
-        enc, key_pad = self.transformer(seq, training, None, return_key_pad=True, packed=self._packed)
+        rows = None
+        self._rows_extra = None
+        if rows_of is not None:
+            got = rows_of(seq[first], raw_features[first])
+            if got is not None:
+                flat_idx, offsets, self._rows_extra = got
+                if self._packed is not None:
+                    flat_idx = ops.remap_index(flat_idx.contiguous(), self._packed.packed_of)
+                rows = (flat_idx.contiguous(), offsets.contiguous())
+        enc, key_pad = self.transformer(seq, training, None, return_key_pad=True, packed=self._packed, rows=rows)
         return enc, seq[first], raw_features[first], seg_starts, seg_ends
 
     def _use_packed(self, inputs, packed, n_real_tokens):
@@ -242,17 +253,26 @@ class ClickstreamTransformer(nn.Module):
         the device, exactly `cap` rows come back (those beyond the real count R are zero rows whose label is -1) together
         with the compact int32 labels.  Neither: R is read back from the device (one host sync).
         pack: the encoder runs on the padding-free layout; the dense [MASK] indices are mapped to its rows."""
+        def positions(ids_first, raw_first):
+            if cap is not None:
+                counts, offsets, flat, _ = self._match_positions(ids_first, raw_first, cap)
+                lab = ops.compact_labels(labels_padded, counts, offsets, cap, flat)     # also sets flat[R:] = -1
+                return flat, offsets, lab
+            _, offsets, flat, _ = self._match_positions(ids_first, raw_first)
+            R = int(offsets[-1].item())
+            return flat[:R], offsets, None
+
+        # The positions depend on the ids alone.  With them in hand BEFORE the encoder runs, its last layer is evaluated
+        # for those rows only (ops.MQAttnBlockFn): nothing else of that layer's output is ever read on this path.
+        mq = flat_idx is None and ops.mq_last_layer and self.transformer.encoder.rows_supported(None)
+        if mq:
+            rows, _, _, _, _ = self._encode(inputs, training, pack, n_real_tokens, rows_of=positions)
+            return rows, self._rows_extra
         enc, ids_first, raw_first, _, _ = self._encode(inputs, training, pack, n_real_tokens)
         d = enc.shape[-1]
         lab = None
-        if flat_idx is None and cap is not None:
-            counts, offsets, flat, _ = self._match_positions(ids_first, raw_first, cap)
-            lab = ops.compact_labels(labels_padded, counts, offsets, cap, flat)     # also sets flat[R:] = -1
-            flat_idx = flat
-        elif flat_idx is None:
-            _, offsets, flat, _ = self._match_positions(ids_first, raw_first)
-            R = int(offsets[-1].item())
-            flat_idx = flat[:R]
+        if flat_idx is None:
+            flat_idx, _, lab = positions(ids_first, raw_first)
         if self._packed is not None:
             flat_idx = ops.remap_index(flat_idx.contiguous(), self._packed.packed_of)
         rows = ops.GatherRowsFn.apply(enc.reshape(-1, d), flat_idx, flat_idx.shape[0])

@@ -217,9 +217,11 @@ class EncoderLayer(nn.Module):
     def get_config(self):
         return {'d_model': self.d_model, 'num_heads': self.num_heads, 'dff': self.dff, 'rate': self.rate}
 
-    def forward(self, x, training=None, mask=None, packed=None):
+    def forward(self, x, training=None, mask=None, packed=None, rows=None):
         """x (B, S, d); or, with `packed` (ops.Packed), the (1, T, d) rows of the real tokens only and mask = the (T,) key
-        bytes the embedding stage produced for them."""
+        bytes the embedding stage produced for them.
+        rows = (midx [R] int32 token rows, moff [B+1] int32 per-sequence offsets into them): the layer is evaluated for
+        those query rows only (keys / values from every token) and returns (R, d) -- the last layer of the Cloze path."""
         B, S, d = x.shape
         training = bool(training)
         cu = None
@@ -237,6 +239,18 @@ class EncoderLayer(nn.Module):
         s1 = dropout_seeds.next() if training else 0
         s2 = dropout_seeds.next() if training else 0
         need_tape = training or torch.is_grad_enabled()
+        if rows is not None:
+            midx, moff = rows
+            if cu is None:          # dense layout: sequence b owns token rows b*S .. (b+1)*S, pad keys are masked by their bytes
+                cu = torch.arange(B + 1, dtype=torch.int32, device=x.device) * S
+                kp = key_pad.reshape(-1)
+            else:
+                kp = None           # packed layout: every token is real
+            out1 = ops.MQAttnBlockFn.apply(x2, midx, moff, cu, kp, m.wq.kernel, m.wq.bias, m.wk.kernel, m.wk.bias, m.wv.kernel,
+                                           m.wv.bias, m.dense.kernel, m.dense.bias, self.layernorm1.gamma, self.layernorm1.beta,
+                                           m._pk_qkv, m._pk_o, B, S, self.num_heads, self.rate if training else 0.0, s1, need_tape)
+            return ops.FFNBlockFn.apply(out1, f[0].kernel, f[0].bias, f[1].kernel, f[1].bias, self.layernorm2.gamma,
+                                        self.layernorm2.beta, f._pk1, f._pk2, self.rate if training else 0.0, s2, need_tape)
         out1 = ops.AttnBlockFn.apply(x2, key_pad, m.wq.kernel, m.wq.bias, m.wk.kernel, m.wk.bias, m.wv.kernel, m.wv.bias,
                                      m.dense.kernel, m.dense.bias, self.layernorm1.gamma, self.layernorm1.beta,
                                      m._pk_qkv, m._pk_o, B, S, self.num_heads, self.rate if training else 0.0, s1, need_tape, cu)
@@ -260,13 +274,14 @@ class Encoder(nn.Module):
         return {'num_layers': self.num_layers, 'd_model': self.d_model, 'num_heads': self.num_heads, 'dff': self.dff,
                 'dropout_rate': self.dropout_rate}
 
-    def forward(self, inputs, training=None, mask=None, _input_dropout_done=False, packed=None):
+    def forward(self, inputs, training=None, mask=None, _input_dropout_done=False, packed=None, rows=None):
+        """rows (see EncoderLayer.forward): the LAST layer is evaluated for those query rows only; returns (R, d)."""
         x = inputs
         if training and self.dropout_rate > 0 and not _input_dropout_done:
             x = ops.DropoutFn.apply(x, float(self.dropout_rate), dropout_seeds.next())
         B, S, d = x.shape
         layers = [{'mha': l.mha, 'ffn': l.ffn, 'ln1': l.layernorm1, 'ln2': l.layernorm2} for l in self.enc_layers]
-        if packed is None and mask is not None and mask.dtype == torch.uint8 and mask.dim() == 2 and \
+        if rows is None and packed is None and mask is not None and mask.dtype == torch.uint8 and mask.dim() == 2 and \
                 ops.encoder_stack_supported(x, layers, bool(training), self.dropout_rate):
             # one autograd node for the whole stack: LayerNorm backward runs in GEMM epilogues (ops.EncoderStackFn)
             for lay in layers:
@@ -274,9 +289,16 @@ class Encoder(nn.Module):
             out = ops.EncoderStackFn.apply(x.reshape(B * S, d), mask, layers, B, S, self.enc_layers[0].num_heads,
                                            float(self.dropout_rate))
             return out.view(B, S, d)
-        for layer in self.enc_layers:
-            x = layer(x, training, mask, packed)
+        last = len(self.enc_layers) - 1
+        for i, layer in enumerate(self.enc_layers):
+            x = layer(x, training, mask, packed, rows if i == last else None)
         return x
+
+    def rows_supported(self, x_dtype):
+        """The masked-query form of the last layer: head depth 32 / 64 (b4c_attn_mq_*), at least one layer."""
+        if not self.enc_layers:
+            return False
+        return (self.d_model // self.num_heads) in (32, 64) and self.d_model % 8 == 0
 
 
 class _Embedding(nn.Module):
@@ -340,9 +362,10 @@ class Transformer(nn.Module):
         dh = self.d_model // self.num_attention_heads
         return self.compute_dtype == torch.bfloat16 and dh in (32, 64) and S <= 512
 
-    def forward(self, inputs, training=None, mask=None, return_key_pad=False, packed=None):
+    def forward(self, inputs, training=None, mask=None, return_key_pad=False, packed=None, rows=None):
         """inputs: dict feature -> (B,S) int64 ids (first feature defines the padding mask).
-        packed (ops.Packed of the first feature's ids): run on the real tokens only -> ((1, T, d) rows, (T,) key bytes)."""
+        packed (ops.Packed of the first feature's ids): run on the real tokens only -> ((1, T, d) rows, (T,) key bytes).
+        rows (midx, moff): only those rows of the last layer's output are computed and returned, as (R, d)."""
         feats = list(inputs.keys())
         if set(feats) != set(self.embedding_dims.keys()):
             raise KeyError('Transformer inputs %s do not match embedded features %s' % (feats, list(self.embedding_dims)))
@@ -358,5 +381,5 @@ class Transformer(nn.Module):
             raise B4CError('packed layout needs bf16, head depth 32 / 64 and S <= 512')
         x, key_pad = ops.EmbedFn.apply(self.pos_encoding, self.scale, rate, seed, self.compute_dtype,
                                        len(ids) if packed is None else (len(ids), packed), *ids, *tables)
-        out = self.encoder(x, training, key_pad, _input_dropout_done=True, packed=packed)
+        out = self.encoder(x, training, key_pad, _input_dropout_done=True, packed=packed, rows=rows)
         return (out, key_pad) if return_key_pad else out

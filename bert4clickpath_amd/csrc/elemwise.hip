@@ -777,3 +777,41 @@ extern "C" int b4c_relu_gate(const void *g, const void *act, void *out, int64_t 
     else B4C_REQUIRE(false, "relu_gate: dtype %d", dtype);
     return b4c_check_launch("relu_gate");
 }
+
+// dst[idx[r]][:] += src[r][:]  for idx[r] >= 0 (distinct indices: no atomics): the gradient of the masked query rows
+// joins the gradient of all token rows (b4c_attn_mq_bwd's layer).  src may be fp32 beside a bf16 dst: one rounding less.
+template <typename T, typename TS>
+__global__ void __launch_bounds__(256) rows_add_kernel(T *__restrict__ dst, int ld_dst, const int32_t *__restrict__ idx,
+                                                       const TS *__restrict__ src, int ld_src, int64_t n_src, int width) {
+    const int cpr = width >> 3;
+    const int64_t total = n_src * cpr;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr) << 3;
+        const int t = idx[r];
+        if (t < 0) continue;
+        float a[8], b[8];
+        Vec8<T>::load(dst + (int64_t)t * ld_dst + c, a);
+        Vec8<TS>::load(src + r * ld_src + c, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += b[k];
+        Vec8<T>::store(dst + (int64_t)t * ld_dst + c, a);
+    }
+}
+
+extern "C" int b4c_rows_add(void *dst, int ld_dst, const int32_t *idx, const void *src, int ld_src, int64_t n_src, int width,
+                            int dtype, int src_dtype, void *stream) {
+    B4C_REQUIRE(dst && idx && src && n_src >= 0 && width > 0 && width % 8 == 0 && ld_dst % 8 == 0 && ld_src % 8 == 0,
+                "rows_add: bad shape (width %d)", width);
+    B4C_REQUIRE(src_dtype == dtype || src_dtype == B4C_F32, "rows_add: src dtype %d beside dst dtype %d", src_dtype, dtype);
+    if (n_src == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(n_src * (width / 8), 256);
+    if (dtype == B4C_F32) rows_add_kernel<float, float><<<grid, 256, 0, st>>>((float *)dst, ld_dst, idx, (const float *)src, ld_src, n_src, width);
+    else if (dtype == B4C_BF16 && src_dtype == B4C_BF16)
+        rows_add_kernel<bf16_t, bf16_t><<<grid, 256, 0, st>>>((bf16_t *)dst, ld_dst, idx, (const bf16_t *)src, ld_src, n_src, width);
+    else if (dtype == B4C_BF16)
+        rows_add_kernel<bf16_t, float><<<grid, 256, 0, st>>>((bf16_t *)dst, ld_dst, idx, (const float *)src, ld_src, n_src, width);
+    else B4C_REQUIRE(false, "rows_add: dtype %d", dtype);
+    return b4c_check_launch("rows_add");
+}

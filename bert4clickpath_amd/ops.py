@@ -417,6 +417,37 @@ def _ready(*params):
             _grad_ready_cb(p)
 
 
+def attn_mq_fwd(q, kv, cu, moff, B, max_len, H, dh, key_pad=None):
+    """Attention of a few query rows per sequence against all of its keys (b4c_attn_mq_fwd).
+    q [R, H*dh]; kv [T, 2*H*dh] (k | v); cu [B+1] token offsets; moff [B+1] query-row offsets -> (o [R, H*dh], lse [R, H])."""
+    R = q.shape[0]
+    # rows outside every [moff[b], moff[b+1]) range (the unused tail of the sync-free form) are not written: zeros, not garbage
+    o = torch.zeros(R, H * dh, dtype=q.dtype, device=q.device)
+    lse = torch.zeros(R, H, dtype=torch.float32, device=q.device)
+    if R == 0:
+        return o, lse
+    es = q.element_size()
+    with _record('attn_mq_fwd', kv.shape[0] * 2 * H * dh * es + 2 * R * H * dh * es, 4 * R * max_len * H * dh):
+        L.check(L.lib().b4c_attn_mq_fwd(_p(q), q.stride(0), _p(kv), kv.stride(0), _p(key_pad), _p(cu), _p(moff), _p(o), o.stride(0),
+                                        _p(lse), B, max_len, H, dh, dt_code(q.dtype), _st()), 'attn_mq_fwd')
+    return o, lse
+
+
+def attn_mq_bwd(q, kv, cu, moff, o, d_o, lse, B, max_len, H, dh, key_pad=None):
+    """-> (dq [R, H*dh], dkv [T, 2*H*dh]); every token row of dkv is written (zeros where no query reads the sequence)."""
+    R = q.shape[0]
+    dq = torch.zeros_like(q)
+    dkv = torch.empty_like(kv)
+    if kv.shape[0] == 0:
+        return dq, dkv
+    es = q.element_size()
+    with _record('attn_mq_bwd', kv.shape[0] * 4 * H * dh * es + 4 * R * H * dh * es, 10 * R * max_len * H * dh):
+        L.check(L.lib().b4c_attn_mq_bwd(_p(q), q.stride(0), _p(kv), kv.stride(0), _p(key_pad), _p(cu), _p(moff), _p(o), o.stride(0),
+                                        _p(d_o), d_o.stride(0), _p(lse), _p(dq), dq.stride(0), _p(dkv), dkv.stride(0), B, max_len,
+                                        H, dh, dt_code(q.dtype), _st()), 'attn_mq_bwd')
+    return dq, dkv
+
+
 def attn_fwd(qkv, key_pad, B, S, H, dh, cu=None):
     """cu (int32 [B+1]): packed layout -- sequence b owns rows cu[b] .. cu[b+1] of qkv, S = upper bound of the longest one."""
     d = H * dh
@@ -1018,6 +1049,86 @@ class AttnBlockFn(torch.autograd.Function):
             return (dx,) + (None,) * 20
         (gq, gk, gv), (gbq, gbk, gbv) = pk_qkv.split_grads(dWqkv, dbqkv)
         return (dx, None, gq, gbq, gk, gbk, gv, gbv, dWo, dbo, dgamma, dbeta) + (None,) * 9
+
+
+def rows_add_(dst, idx, src):
+    """dst[idx[r]] += src[r] for idx[r] >= 0 (distinct indices)."""
+    L.check(L.lib().b4c_rows_add(_p(dst), dst.stride(0), _p(idx), _p(src), src.stride(0), src.shape[0], src.shape[1],
+                                 dt_code(dst.dtype), dt_code(src.dtype), _st()), 'rows_add')
+    return dst
+
+
+mq_last_layer = True       # Cloze path: the last encoder layer runs for the [MASK] rows only (MQAttnBlockFn)
+
+
+class MQAttnBlockFn(torch.autograd.Function):
+    """The attention half of the LAST encoder layer for the query rows `midx` only: LN1(x_m + drop(MHA(x)_m)).
+    Every other row of that layer's output is never read on the Cloze path (clickstream_transformer.py:281-295 keeps the
+    [MASK] rows); keys and values still come from every token.
+      x [T, d] (all tokens), midx [R] int32 (token row of each query row, -1 = unused row), moff [B+1] (query rows of
+      sequence b), cu [B+1] (its token rows), key_pad [T] or None  ->  out1_m [R, d]."""
+
+    @staticmethod
+    def forward(ctx, x, midx, moff, cu, key_pad, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, pk_qkv, pk_o, B, max_len, H, rate, seed,
+                training):
+        T_tok, d = x.shape
+        dh = d // H
+        R = midx.shape[0]
+        wt_qkv, _, b_qkv = pk_qkv.get(x.dtype, d, training)
+        wt_o, _, b_o = pk_o.get(x.dtype, d, training)
+        kv = gemm_nt(x, wt_qkv[d:3 * d], 2 * d, b_qkv[d:3 * d])            # K | V of every token
+        x_m = gather_rows(x, midx, R)
+        q_m = gemm_nt(x_m, wt_qkv[:d], d, b_qkv[:d])
+        o_m, lse = attn_mq_fwd(q_m, kv, cu, moff, B, max_len, H, dh, key_pad)
+        if gemm_ln_supported(o_m, d):
+            z, out, stats = gemm_nt_add_ln(o_m, wt_o, b_o, x_m, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
+                                           save=training)
+        else:
+            y = gemm_nt(o_m, wt_o, d, b_o)
+            z, out, stats = add_dropout_layernorm_fwd(x_m, y, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
+                                                      save=training)
+        if training:
+            ctx.save_for_backward(x, x_m, midx, moff, cu, key_pad, q_m, kv, o_m, lse, z, stats, gamma)
+            ctx.pk = (pk_qkv, pk_o)
+            ctx.dims = (B, max_len, H, dh, rate, seed)
+            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, x_m, midx, moff, cu, key_pad, q_m, kv, o_m, lse, z, stats, gamma = ctx.saved_tensors
+        pk_qkv, pk_o = ctx.pk
+        B, max_len, H, dh, rate, seed = ctx.dims
+        wq, bq, wk, bk, wv, bv, wo, bo, gam, bet = ctx.params
+        d = H * dh
+        inplace = _inplace_ok(*ctx.params)
+        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
+                                                          into=(gam.grad, bet.grad) if inplace else None)
+        _, wc_o, _ = pk_o.get(x.dtype, d, True)
+        _, wc_qkv, _ = pk_qkv.get(x.dtype, d, True)
+        if inplace:
+            queue_dw(o_m, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
+        else:
+            dWo, dbo = gemm_tn(o_m, dy, d, d)
+        d_o = gemm_nt(dy, wc_o, d)
+        dq, dkv = attn_mq_bwd(q_m, kv, cu, moff, o_m, d_o, lse, B, max_len, H, dh, key_pad)
+        if inplace:
+            queue_dw(x_m, dq, d, d, [wq.grad], [bq.grad], (wq, bq))
+            flush_pending_dw()                      # (the query-row problems have R rows, the key / value problem T)
+            queue_dw(x, dkv, d, 2 * d, [wk.grad, wv.grad], [bk.grad, bv.grad], (wk, bk, wv, bv))
+        else:
+            dWq, dbq = gemm_tn(x_m, dq, d, d)
+            dWkv, dbkv = gemm_tn(x, dkv, d, 2 * d)
+        dx_m = gemm_nt(dq, wc_qkv[:, :d], d, residual=dz, out_dtype=torch.float32)      # query rows: through Wq + the residual branch (kept in fp32 until it joins dx)
+        dx = gemm_nt(dkv, wc_qkv[:, d:3 * d], d)               # every token: through Wk | Wv
+        rows_add_(dx, midx, dx_m)
+        if inplace:
+            _ready(gam, bet)
+            flush_pending_dw()
+            return (dx,) + (None,) * 22
+        dWk, dWv = dWkv[:, :d].contiguous(), dWkv[:, d:].contiguous()
+        dbk, dbv = dbkv[:d].contiguous(), dbkv[d:].contiguous()
+        return (dx, None, None, None, None, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, dgamma, dbeta) + (None,) * 8
 
 
 class FFNBlockFn(torch.autograd.Function):

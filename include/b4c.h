@@ -407,6 +407,25 @@ int b4c_attn_bwd_varlen(const void *qkv, int ld_qkv, const uint8_t *key_pad, con
                         int B, int max_len, int H, int dh, void *workspace, int64_t workspace_bytes, int dtype,
                         void *stream);
 
+/* ---- (ABI version 4) attention for a few query rows per sequence: the LAST encoder layer of the Cloze path ------------
+ * The reference runs every layer on every position (transformer.py:262-270) and keeps the rows at the [MASK] positions
+ * (clickstream_transformer.py:281-295); in the last layer all other rows are never read.  There the queries are the masked
+ * rows of a sequence, the keys / values all of its tokens (transformer.py:64-97 for those rows, fp32 math, both dtypes):
+ *   q / o / dq [R][ld]: head h in columns h*dh..;  kv / dkv [T][ld]: k in columns h*dh.., v in H*dh + h*dh..;
+ *   sequence b = token rows cu_seqlens[b] .. cu_seqlens[b+1] and query rows q_offsets[b] .. q_offsets[b+1];
+ *   key_pad [T] (1 = padded key, may be NULL); lse [R][H] (natural log of the row's softmax denominator).
+ * b4c_attn_mq_bwd writes dq for the R query rows and dk | dv for EVERY token row (zeros where no query reads them).
+ * dh in {32, 64}; max_len = longest sequence (LDS sizing). */
+int b4c_rows_add(void *dst, int ld_dst, const int32_t *idx, const void *src, int ld_src, int64_t n_src, int width, int dtype,
+                 int src_dtype, void *stream);   /* dst[idx[r]] += src[r] (idx distinct, < 0 skipped; src may be fp32 beside a
+                                                  * bf16 dst): the query rows' gradient joins that of all token rows */
+int b4c_attn_mq_fwd(const void *q, int ld_q, const void *kv, int ld_kv, const uint8_t *key_pad, const int32_t *cu_seqlens,
+                    const int32_t *q_offsets, void *o, int ld_o, float *lse, int B, int max_len, int H, int dh, int dtype,
+                    void *stream);
+int b4c_attn_mq_bwd(const void *q, int ld_q, const void *kv, int ld_kv, const uint8_t *key_pad, const int32_t *cu_seqlens,
+                    const int32_t *q_offsets, const void *o, int ld_o, const void *d_o, int ld_do, const float *lse,
+                    void *dq, int ld_dq, void *dkv, int ld_dkv, int B, int max_len, int H, int dh, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,8 +164,9 @@ def test_gradients_match_oracle_fp32(gpu, dropout):
 
 def test_train_step_bf16_tracks_fp32_oracle(gpu):
     """bf16 storage / fp32 accumulate path against the fp64 oracle (which uses the fp32 master weights):
-    loss within 2e-3 relative, every gradient tensor within 10% in L2 (measured: 0.2-8%; the fp32 HIP
-    path on the same inputs is at 1e-6, see test_gradients_match_oracle_fp32) -- the documented bf16
+    loss within 2e-3 relative, every gradient tensor within 12% in L2 (measured over three seeds, with the last layer
+    evaluated in full and at the [MASK] rows only: worst tensor 5-11%, either form better on some seeds -- scratch/mq_err.py;
+    the fp32 HIP path on the same inputs is at 1e-6, see test_gradients_match_oracle_fp32) -- the documented bf16
     tolerance: weights, activations and activation gradients are rounded to 8 significant bits."""
     V, d, L, H, B, S = 1000, 64, 2, 2, 16, 50
     model, batch = _random_model_and_batch(11, V, d, L, H, [128, 64], B, S, 0.0, torch.bfloat16)
@@ -182,7 +183,7 @@ def test_train_step_bf16_tracks_fp32_oracle(gpu):
         if float(gr.abs().max()) < 1e-9:      # key-bias gradient: identically zero
             continue
         err = float((p.grad.cpu().double() - gr).norm() / gr.norm())
-        assert err < 0.10, (name, err)
+        assert err < 0.12, (name, err)
 
 
 def test_adam_training_reduces_loss_and_matches_oracle_step(gpu):

@@ -1,0 +1,190 @@
+"""Masked-query attention (the last encoder layer of the Cloze path computed for the [MASK] rows only) -- kernels against an
+fp64 restatement of transformer.py:64-97 for those rows, then the model with the masked-query last layer against the full
+layer it replaces and against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def _ragged(B, smax, mmax, H, dh, seed, dtype, with_empty=True):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(3, smax + 1, (B,), generator=g)
+    lens[0] = smax
+    nq = torch.randint(0 if with_empty else 1, mmax + 1, (B,), generator=g)
+    nq[1 % B] = mmax
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    moff = torch.zeros(B + 1, dtype=torch.int32)
+    moff[1:] = torch.cumsum(nq, 0)
+    T, R, d = int(cu[-1]), int(moff[-1]), H * dh
+    q = (torch.randn(R, d, generator=g) * 0.8).to(dtype)
+    kv = (torch.randn(T, 2 * d, generator=g) * 0.8).to(dtype)
+    go = torch.randn(R, d, generator=g).to(dtype)
+    return cu, moff, q, kv, go
+
+
+def _ref(cu, moff, q, kv, go, H, dh, key_pad=None):
+    q64 = q.double().clone().requires_grad_(True)
+    kv64 = kv.double().clone().requires_grad_(True)
+    d = H * dh
+    outs, lses = [], []
+    for b in range(len(cu) - 1):
+        t0, t1, r0, r1 = int(cu[b]), int(cu[b + 1]), int(moff[b]), int(moff[b + 1])
+        if r1 == r0:
+            continue
+        o_b, l_b = [], []
+        for h in range(H):
+            qq = q64[r0:r1, h * dh:(h + 1) * dh]
+            kk = kv64[t0:t1, h * dh:(h + 1) * dh]
+            vv = kv64[t0:t1, d + h * dh:d + (h + 1) * dh]
+            s = qq @ kk.t() / np.sqrt(dh)
+            if key_pad is not None:
+                s = s + key_pad[t0:t1].double()[None, :] * -1e9
+            l_b.append(torch.logsumexp(s, 1))
+            o_b.append(torch.softmax(s, 1) @ vv)
+        outs.append(torch.cat(o_b, 1))
+        lses.append(torch.stack(l_b, 1))
+    o = torch.cat(outs, 0)
+    (o * go.double()).sum().backward()
+    return o.detach(), torch.cat(lses, 0).detach(), q64.grad, kv64.grad
+
+
+@pytest.mark.parametrize('dtype,H,dh,smax,mmax,pad', [
+    (torch.float32, 2, 64, 50, 10, False), (torch.float32, 4, 32, 200, 20, True), (torch.float32, 2, 64, 300, 5, False),
+    (torch.bfloat16, 2, 64, 200, 10, False), (torch.bfloat16, 4, 64, 512, 12, True), (torch.bfloat16, 2, 32, 70, 33, False)])
+def test_attn_mq_kernels_match_fp64(dtype, H, dh, smax, mmax, pad):
+    from bert4clickpath_amd import ops
+    B = 9
+    cu, moff, q, kv, go = _ragged(B, smax, mmax, H, dh, 100 + smax + mmax, dtype)
+    key_pad = None
+    if pad:
+        key_pad = (torch.rand(int(cu[-1]), generator=torch.Generator().manual_seed(1)) < 0.15).to(torch.uint8)
+        key_pad[cu[:-1].long()] = 0                      # every sequence keeps a live key
+    ro, rl, rdq, rdkv = _ref(cu, moff, q, kv, go, H, dh, key_pad)
+    dev = 'cuda'
+    kp = key_pad.to(dev) if key_pad is not None else None
+    o, lse = ops.attn_mq_fwd(q.to(dev), kv.to(dev), cu.to(dev), moff.to(dev), B, smax, H, dh, kp)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert float((o.double().cpu() - ro).abs().max()) < tol * max(1.0, float(ro.abs().max()))
+    assert float((lse.double().cpu() - rl).abs().max()) < (1e-4 if dtype == torch.float32 else 2e-2)
+    # backward from the fp64 o / lse rounded to the kernel's dtype (what the forward hands over)
+    dq, dkv = ops.attn_mq_bwd(q.to(dev), kv.to(dev), cu.to(dev), moff.to(dev), o, go.to(dev), lse, B, smax, H, dh, kp)
+    btol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert float((dq.double().cpu() - rdq).abs().max()) < btol * max(1.0, float(rdq.abs().max()))
+    assert float((dkv.double().cpu() - rdkv).abs().max()) < btol * max(1.0, float(rdkv.abs().max()))
+    # sequences without a query row: exact zeros in dk | dv
+    for b in range(B):
+        if moff[b + 1] == moff[b]:
+            assert float(dkv[int(cu[b]):int(cu[b + 1])].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the model: last encoder layer evaluated at the [MASK] rows only (ops.mq_last_layer) against the full layer and the oracle
+# ------------------------------------------------------------------------------------------------------------------
+from oracle import torch_ref as tr  # noqa: E402
+
+
+def _model(V, d, L, H, head_dims, dtype, dropout=0.0, seed=3):
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    torch.manual_seed(seed)
+    m = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': d},
+                               SoftMaxHead(list(head_dims), V), value_to_head='[MASK]', num_encoder_layers=L,
+                               num_attention_heads=H, dropout_rate=dropout, compute_dtype=dtype)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith('bias') or n.endswith('beta'):
+                p.normal_(0, 0.05)
+    return m.cuda()
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max()) / max(float(b.double().abs().max()), 1e-30)
+
+
+@pytest.mark.parametrize('L,H,d', [(2, 2, 64), (1, 2, 128), (3, 1, 64)])
+def test_masked_query_last_layer_fp32_equals_full_layer_and_oracle(L, H, d):
+    from bert4clickpath_amd import input_pipeline, ops
+    V, S, B = 90, 40, 7
+    model = _model(V, d, L, H, (32, 24), torch.float32)
+    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=5, min_len=3)
+    ids = torch.from_numpy(b['ids'])
+    feats = {'asin': ids[:, 2:S - 1].contiguous().cuda()}
+    labels = torch.from_numpy(b['labels_padded']).cuda()
+    res = {}
+    for mq in (True, False):
+        ops.mq_last_layer = mq
+        try:
+            for kw in ({}, {'max_masked_per_row': 10}):
+                model.zero_grad()
+                loss = model.cloze_loss(feats, labels, training=True, **kw)
+                loss.backward()
+                res[(mq, bool(kw))] = (float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+            with torch.no_grad():
+                res[(mq, 'topk')] = model.predict_topk(feats, 10, labels)
+        finally:
+            ops.mq_last_layer = True
+    for syncfree in (False, True):
+        (la, ga), (lb, gb) = res[(True, syncfree)], res[(False, syncfree)]
+        assert abs(la - lb) < 2e-6 * abs(lb)
+        for n in ga:
+            assert _rel(ga[n], gb[n]) < 2e-4 or float(gb[n].abs().max()) < 1e-7, n
+    ta, tb = res[(True, 'topk')], res[(False, 'topk')]
+    assert torch.equal(ta[0], tb[0]) and torch.equal(ta[1], tb[1])
+    # the fp64 oracle (full layers everywhere, rows gathered afterwards: the reference's dataflow)
+    P = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in model.state_dict().items() if 'pos_encoding' not in k}
+    tP = {k[len('transformer.'):]: v for k, v in P.items() if k.startswith('transformer.')}
+    hP = {k[len('head.'):]: v for k, v in P.items() if k.startswith('head.')}
+    enc = tr.transformer_forward({'items': ids}, tP, L, H)
+    rows, _ = tr.gather_masked_rows(enc, ids)
+    probs_ref = torch.softmax(tr.softmax_head_logits(rows, hP, 2), -1)
+    ref = tr.sparse_ce_tf(probs_ref, torch.from_numpy(b['labels']).long()).mean()
+    ref.backward()
+    la, ga = res[(True, False)]
+    assert abs(la - float(ref)) < 2e-5 * float(ref)
+    for n in ga:
+        if float(P[n].grad.abs().max()) > 1e-9:
+            assert _rel(ga[n], P[n].grad) < 2e-3, n
+
+
+def test_masked_query_last_layer_bf16_packed_and_dropout():
+    from bert4clickpath_amd import input_pipeline, ops, optim
+    V, S, B = 300, 48, 12
+    model = _model(V, 128, 2, 2, (64, 128), torch.bfloat16)
+    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=21, min_len=3)
+    ids = torch.from_numpy(b['ids'])
+    feats = {'asin': ids[:, 2:S - 1].contiguous().cuda()}
+    labels = torch.from_numpy(b['labels_padded']).cuda()
+    n_real = int((b['ids'] != 0).sum())
+    res = {}
+    for mq in (True, False):
+        ops.mq_last_layer = mq
+        try:
+            model.zero_grad()
+            loss = model.cloze_loss(feats, labels, training=True, max_masked_per_row=10, n_real_tokens=n_real)
+            loss.backward()
+            res[mq] = (float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+        finally:
+            ops.mq_last_layer = True
+    assert abs(res[True][0] - res[False][0]) < 3e-3 * abs(res[False][0])
+    for n in res[True][1]:
+        if float(res[False][1][n].float().norm()) < 1e-9 or n.endswith('mha.wk.bias'):
+            continue
+        assert _rel(res[True][1][n], res[False][1][n]) < 0.08, n
+    # with dropout and the optimizer's arena (in-place gradients, grouped dW launches): the loss goes down
+    m2 = _model(V, 128, 2, 2, (64, 128), torch.bfloat16, dropout=0.1)
+    opt = optim.Adam(m2.parameters(), 1e-3, 0.9, 0.999, 1e-9)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        loss = m2.cloze_loss(feats, labels, training=True, max_masked_per_row=10, n_real_tokens=n_real)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0]
