@@ -93,10 +93,10 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_fwd_kernel(const T *__rest
             if (row < S) Vec8<T>::load(kv + (tok0 + row) * ld_kv + dm + h * DH + part * 8, vraw[i]);
         }
         __syncthreads();                                      // the previous chunk's readers are done with sQ / sP / sV
-        for (int c = tid; c < mq * (DH / 8); c += MQ_THREADS) {
-            const int m = c / (DH / 8), part = c % (DH / 8);
-            float t[8];
-            Vec8<T>::load(q + (int64_t)(r0 + mc + m) * ld_q + h * DH + part * 8, t);
+        for (int c = tid; c < MQ * (DH / 8); c += MQ_THREADS) {       // rows past the chunk are zeros: the loops below run on
+            const int m = c / (DH / 8), part = c % (DH / 8);          // groups of four queries without a bound check
+            float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (m < mq) Vec8<T>::load(q + (int64_t)(r0 + mc + m) * ld_q + h * DH + part * 8, t);
 #pragma unroll
             for (int k = 0; k < 8; ++k) sQ[m * DH + part * 8 + k] = t[k];
         }
@@ -119,12 +119,18 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_fwd_kernel(const T *__rest
                 if (j < S) mq_load<T, HD>(kv + (tok0 + j) * ld_kv + h * DH + half * HD, kr);
             }
             const bool pad = j < S && key_pad && key_pad[tok0 + j];
-            for (int m = 0; m < mq; ++m) {
-                float s = mq_dot<HD>(kr, sQ + m * DH + half * HD);
-                s += __shfl_xor(s, 32);
-                s = s / sqrt_dk;
-                if (pad) s += -1e9f;
-                if (half == 0 && j < S) sP[(size_t)m * SP + j] = s;
+            for (int m0 = 0; m0 < mq; m0 += 4) {              // four independent dot -> shuffle chains in flight
+                float s4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s4[u] = mq_dot<HD>(kr, sQ + (m0 + u) * DH + half * HD);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s4[u] += __shfl_xor(s4[u], 32);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float sc = s4[u] / sqrt_dk;
+                    if (pad) sc += -1e9f;
+                    if (half == 0 && j < S) sP[(size_t)(m0 + u) * SP + j] = sc;
+                }
             }
         }
         (void)rs;
@@ -140,6 +146,7 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_fwd_kernel(const T *__rest
             sum = wave_sum(sum);
             const float L = mx + logf(sum);
             for (int j = lane; j < S; j += 64) row[j] = expf(row[j] - L);
+            for (int j = S + lane; j < SP; j += 64) row[j] = 0.f;     // (the loop below runs over whole groups of four keys)
             if (lane == 0) lse[(int64_t)(r0 + mc + m) * H + h] = L;
         }
         // phase 2: o_m = sum_key p[m][key] V[key]: lane = feature, the wave's queries share every V read
@@ -152,36 +159,27 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_fwd_kernel(const T *__rest
                 __syncthreads();                              // the previous V block is consumed
                 for (int c = tid; c < MQ_KB * (DH / 8); c += MQ_THREADS) {
                     const int row = c / (DH / 8), part = c % (DH / 8);
-                    if (k0 + row < S) {
-                        float t[8];
-                        Vec8<T>::load(kv + (tok0 + k0 + row) * ld_kv + dm + h * DH + part * 8, t);
-                        Vec8<T>::store(sV + row * DH + part * 8, t);
-                    }
+                    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (k0 + row < S) Vec8<T>::load(kv + (tok0 + k0 + row) * ld_kv + dm + h * DH + part * 8, t);
+                    Vec8<T>::store(sV + row * DH + part * 8, t);          // rows past the sequence: zeros
                 }
                 __syncthreads();
             }
             const int nk = min(MQ_KB, S - k0);
             if (lane < DH) {
-                int j = 0;
-                for (; j + 4 <= nk; j += 4) {
-                    const float v0 = (float)sV[j * DH + lane], v1 = (float)sV[(j + 1) * DH + lane];
-                    const float v2 = (float)sV[(j + 2) * DH + lane], v3 = (float)sV[(j + 3) * DH + lane];
+                // all reads of a step are requested before the first is used (the compiler waits once per group)
+                const int nk4 = (nk + 3) & ~3;                // rows of sV and columns of sP past the sequence are zeros
+                for (int j = 0; j < nk4; j += 4) {
+                    f32x4 p4[QW];
 #pragma unroll
-                    for (int i = 0; i < QW; ++i) {
-                        const int m = wave + 4 * i;
-                        if (m < mq) {
-                            const f32x4 p4 = *reinterpret_cast<const f32x4 *>(sP + (size_t)m * SP + k0 + j);
-                            acc[i] += p4[0] * v0 + p4[1] * v1 + p4[2] * v2 + p4[3] * v3;
-                        }
-                    }
-                }
-                for (; j < nk; ++j) {
-                    const float v0 = (float)sV[j * DH + lane];
+                    for (int i = 0; i < QW; ++i) p4[i] = *reinterpret_cast<const f32x4 *>(sP + (size_t)(wave + 4 * i) * SP + k0 + j);
+                    float v4[4];
 #pragma unroll
-                    for (int i = 0; i < QW; ++i) {
-                        const int m = wave + 4 * i;
-                        if (m < mq) acc[i] += sP[(size_t)m * SP + k0 + j] * v0;
-                    }
+                    for (int u = 0; u < 4; ++u) v4[u] = (float)sV[(j + u) * DH + lane];
+#pragma unroll
+                    for (int i = 0; i < QW; ++i)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[i] += p4[i][u] * v4[u];
                 }
             }
         }
@@ -238,32 +236,17 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_bwd_kernel(const T *__rest
             mq_load<T, HD>(kv + (tok0 + j) * ld_kv + dm + h * DH + half * HD, vr);
         }
         const bool pad = live && key_pad && key_pad[tok0 + j];
-        // the first chunk's query-side rows are requested now, together with the K / V half rows above (MQ * DH / 8 <= 256
-        // entries: one per thread): one memory round trip in front of the arithmetic instead of two
-        static_assert(MQ * (DH / 8) <= MQ_THREADS, "one query-side entry per thread");
-        float t0[8], g0[8], o0[8];
-        {
-            const int mq0 = min(MQ, M);
-            const int m = tid / (DH / 8), part = tid % (DH / 8);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { t0[k] = 0.f; g0[k] = 0.f; o0[k] = 0.f; }
-            if (tid < mq0 * (DH / 8)) {
-                Vec8<T>::load(q + (int64_t)(r0 + m) * ld_q + h * DH + part * 8, t0);
-                Vec8<T>::load(d_o + (int64_t)(r0 + m) * ld_do + h * DH + part * 8, g0);
-                Vec8<T>::load(o + (int64_t)(r0 + m) * ld_o + h * DH + part * 8, o0);
-            }
-        }
         __syncthreads();                                      // the previous key block's dq phase is done with sK
-        if (live) mq_store<T, HD>(sK + kl * DH + half * HD, kr);
+        mq_store<T, HD>(sK + kl * DH + half * HD, kr);          // (zeros for the slots past the sequence)
         for (int ci = 0; ci < nchunk; ++ci) {
             const int mc = ci * MQ, mq = min(MQ, M - mc);
             __syncthreads();                                  // the previous chunk's dq phase is done with sQ / sG / sDS
-            for (int c = tid; c < mq * (DH / 8); c += MQ_THREADS) {
+            for (int c = tid; c < MQ * (DH / 8); c += MQ_THREADS) {   // rows past the chunk: zeros (q, dO) -> dS = dV = dK terms 0
                 const int m = c / (DH / 8), part = c % (DH / 8);
                 float t[8], g8[8], o8[8];
-                if (ci == 0) {
+                if (m >= mq) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { t[k] = t0[k]; g8[k] = g0[k]; o8[k] = o0[k]; }
+                    for (int k = 0; k < 8; ++k) { t[k] = 0.f; g8[k] = 0.f; o8[k] = 0.f; }
                 } else {
                     Vec8<T>::load(q + (int64_t)(r0 + mc + m) * ld_q + h * DH + part * 8, t);
                     Vec8<T>::load(d_o + (int64_t)(r0 + mc + m) * ld_do + h * DH + part * 8, g8);
@@ -279,19 +262,19 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_bwd_kernel(const T *__rest
                 pd = group_sum<DH / 8>(pd);                   // the DH / 8 consecutive lanes of a row
                 if (part == 0) {
                     sDelta[m] = pd;
-                    sLse[m] = lse[(int64_t)(r0 + mc + m) * H + h];
+                    sLse[m] = m < mq ? lse[(int64_t)(r0 + mc + m) * H + h] : INFINITY;     // p = exp(s - inf) = 0 for the zero rows
                 }
             }
             __syncthreads();
             // phase 1: this thread's half key against the chunk's queries
             for (int m = 0; m < mq; ++m) {
-                float s = mq_dot<HD>(kr, sQ + m * DH + half * HD);
+                float sc = mq_dot<HD>(kr, sQ + m * DH + half * HD);
                 float dp = mq_dot<HD>(vr, sG + m * DH + half * HD);
-                s += __shfl_xor(s, 32);
+                sc += __shfl_xor(sc, 32);
                 dp += __shfl_xor(dp, 32);
                 float p = 0.f, ds = 0.f;
                 if (live && !pad) {                           // a padded key has p == 0 exactly (exp(-1e9 - lse))
-                    p = expf(s / sqrt_dk - sLse[m]);
+                    p = expf(sc / sqrt_dk - sLse[m]);
                     ds = p * (dp - sDelta[m]);
                 }
 #pragma unroll
@@ -303,6 +286,8 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_bwd_kernel(const T *__rest
                 }
                 if (half == 0) sDS[m * MQ_KB + kl] = ds;
             }
+            for (int m = mq + (tid >> 7); m < MQ; m += 2)     // rows past the chunk: zeros (phase 2 reads whole groups)
+                sDS[m * MQ_KB + (tid & 127)] = 0.f;
             __syncthreads();
             // phase 2: dq_m (+)= sum over this block's keys of dS[m][key] K[key] / sqrt(dk): a read-modify-write of the
             // output row when the sequence has more than one key block (S > 128)
@@ -312,26 +297,19 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_bwd_kernel(const T *__rest
                 float acc[QW];
 #pragma unroll
                 for (int i = 0; i < QW; ++i) acc[i] = 0.f;
-                int jj = 0;
-                for (; jj + 4 <= nk; jj += 4) {
-                    const float c0 = (float)sK[jj * DH + lane], c1 = (float)sK[(jj + 1) * DH + lane];
-                    const float c2 = (float)sK[(jj + 2) * DH + lane], c3 = (float)sK[(jj + 3) * DH + lane];
+                // every key slot of sDS is written each chunk (0 for slots past the sequence) and rows past the chunk are 0
+                const int nk4 = (nk + 3) & ~3;
+                for (int jj = 0; jj < nk4; jj += 4) {
+                    f32x4 d4[QW];
 #pragma unroll
-                    for (int i = 0; i < QW; ++i) {
-                        const int m = wave + 4 * i;
-                        if (m < mq) {
-                            const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sDS + m * MQ_KB + jj);
-                            acc[i] += d4[0] * c0 + d4[1] * c1 + d4[2] * c2 + d4[3] * c3;
-                        }
-                    }
-                }
-                for (; jj < nk; ++jj) {
-                    const float c0 = (float)sK[jj * DH + lane];
+                    for (int i = 0; i < QW; ++i) d4[i] = *reinterpret_cast<const f32x4 *>(sDS + (wave + 4 * i) * MQ_KB + jj);
+                    float c4[4];
 #pragma unroll
-                    for (int i = 0; i < QW; ++i) {
-                        const int m = wave + 4 * i;
-                        if (m < mq) acc[i] += sDS[m * MQ_KB + jj] * c0;
-                    }
+                    for (int u = 0; u < 4; ++u) c4[u] = (float)sK[(jj + u) * DH + lane];
+#pragma unroll
+                    for (int i = 0; i < QW; ++i)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[i] += d4[i][u] * c4[u];
                 }
 #pragma unroll
                 for (int i = 0; i < QW; ++i) {
