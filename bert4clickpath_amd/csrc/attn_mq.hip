@@ -332,6 +332,178 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_bwd_kernel(const T *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 forward on the matrix cores, ONE WAVE per (sequence, head): the item's work (a 32-row query tile against S keys)
+// is too small for a workgroup's barriers, and what it needs is many items in flight per CU (16 waves = 16 items).
+//   S^T = K Q^T per 32-key tile, key on the accumulator rows, query on the lane (the maps of attn_mfma.hip): K and Q
+//   fragments come straight from global memory (16 B per lane and k-step), the softmax statistics are lane-local (one
+//   xor-32 exchange), P^T feeds O^T = V^T P^T from the accumulator registers; only V passes through LDS (a wave-private
+//   double buffer, for the transposed fragment reads).  The next tile's K and V loads are in flight during a tile.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned mq_u32x4;
+typedef __attribute__((ext_vector_type(4))) short mq_s16x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 mq_bf16x4;
+__device__ __forceinline__ int mq_rowmap(int t, int hf) { return (t & 3) + 8 * (t >> 2) + 4 * hf; }
+__device__ __forceinline__ bf16x8 mq_pack8(const float *p) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)p[j];
+    return v;
+}
+__device__ __forceinline__ bf16x8 mq_frag_tr(const char *p, int second_off) {
+    const mq_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mq_s16x4 __attribute__((address_space(3))) *)(p));
+    const mq_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mq_s16x4 __attribute__((address_space(3))) *)(p + second_off));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 w = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+#define MQ_WAVES 4
+template <int DH, bool HAS_PAD>
+__global__ void __launch_bounds__(64 * MQ_WAVES, 3) attn_mq_fwd_mfma_kernel(const bf16_t *__restrict__ q, int ld_q, const bf16_t *__restrict__ kv,
+                                                                         int ld_kv, const uint8_t *__restrict__ key_pad,
+                                                                         const int32_t *__restrict__ cu, const int32_t *__restrict__ moff,
+                                                                         bf16_t *__restrict__ o, int ld_o, float *__restrict__ lse, int H,
+                                                                         int n_items, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KSTR = DH * 2 + 16;
+    constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8, VC = 32 * CH / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5, li = lane & 15, g = lane >> 4;
+    char *sV = smem + wave * (2 * 32 * KSTR);                 // this wave's two V tiles
+    const int item = blockIdx.x * MQ_WAVES + wave;
+    if (item >= n_items) return;                              // (no workgroup barrier anywhere below)
+    const int b = item / H, hh = item % H, dm = H * DH;
+    const int64_t tok0 = cu[b];
+    const int S = cu[b + 1] - cu[b];
+    const int r0 = moff[b], M = moff[b + 1] - moff[b];
+    if (M <= 0 || S <= 0) return;
+    const int nkt = (S + 31) >> 5;
+    const float scale2 = scale * 1.4426950408889634f;
+    const bf16_t *kbase = kv + tok0 * ld_kv + hh * DH;
+    const bf16_t *vbase = kbase + dm;
+    for (int q0 = 0; q0 < M; q0 += 32) {
+        const int qrow = q0 + r;
+        const bool qvalid = qrow < M;
+        bf16x8 qf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            mq_u32x4 v = {0u, 0u, 0u, 0u};
+            if (qvalid) v = *reinterpret_cast<const mq_u32x4 *>(q + (int64_t)(r0 + qrow) * ld_q + hh * DH + ks * 16 + hf * 8);
+            qf[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+        // K / V rows through buffer loads: one descriptor for the sequence's rows (reads past its end return zeros), 32-bit
+        // per-lane offsets -- no 64-bit address pair per load in the register file
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(kbase), 0, (unsigned)((int64_t)S * ld_kv * 2 - (int64_t)hh * DH * 2), 0x00020000);
+        const int koff = (r * ld_kv + hf * 8) * 2;                        // this lane's K row, its half of a k-step
+        const int voff0 = ((lane / CH) * ld_kv + dm + (lane % CH) * 8) * 2;     // V chunk i: rows (lane + 64 i) / CH
+        const int tile_bytes = 32 * ld_kv * 2;
+        mq_u32x4 kf[NKS], rv[VC];
+        auto fetch_k = [&](int kt, mq_u32x4 (&fk)[NKS]) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) fk[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, koff + kt * tile_bytes + ks * 32, 0, 0);
+        };
+        auto fetch_v = [&](int kt, mq_u32x4 (&fv)[VC]) {
+#pragma unroll
+            for (int i = 0; i < VC; ++i) fv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff0 + kt * tile_bytes + i * (64 / CH) * ld_kv * 2, 0, 0);
+        };
+        fetch_k(0, kf);
+        fetch_v(0, rv);
+        float m = -INFINITY, l = 0.f;
+        f32x16 oacc[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) oacc[dt][t] = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            char *vt = sV + (kt & 1) * (32 * KSTR);
+#pragma unroll
+            for (int i = 0; i < VC; ++i) {
+                const int c = lane + 64 * i, row = c / CH, part = c % CH;
+                *reinterpret_cast<mq_u32x4 *>(vt + row * KSTR + part * 16) = rv[i];
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], acc, 0, 0, 0);
+            if (kt + 1 < nkt) {                                // in flight during this tile's softmax and P V
+                fetch_k(kt + 1, kf);
+                fetch_v(kt + 1, rv);
+            }
+            float tm = -INFINITY;
+            const bool edge = (kt + 1) * 32 > S;              // keys past the sequence in this tile (wave-uniform)
+            if (HAS_PAD || edge) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int key = kt * 32 + mq_rowmap(t, hf);
+                    float madd = 0.f;
+                    if (key >= S) madd = -INFINITY;
+                    else if (HAS_PAD && key_pad[tok0 + key]) madd = -1e9f * 1.4426950408889634f;
+                    acc[t] = __builtin_fmaf(acc[t], scale2, madd);
+                    tm = fmaxf(tm, acc[t]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    acc[t] *= scale2;
+                    tm = fmaxf(tm, acc[t]);
+                }
+            }
+            tm = fmaxf(tm, __shfl_xor(tm, 32));               // the two lanes of a query (key halves) share the reference
+            const bool raise = tm > m + 12.0f;
+            if (__any(raise)) {
+                if (raise) {
+                    const float al = __builtin_amdgcn_exp2f(m - tm);      // 0 at the first tile (m = -inf)
+                    m = tm;
+                    l *= al;
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) oacc[dt][t] *= al;
+                }
+            }
+            const float mref = (m == -INFINITY) ? 0.f : m;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                acc[t] = __builtin_amdgcn_exp2f(acc[t] - mref);
+                l += acc[t];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tile's V rows are in LDS (written by the wave's lanes)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = acc[8 * s2 + j];
+                const bf16x8 pf = mq_pack8(pv);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    // V^T[dh = dt*32 + r][keys 16 s2 + 4 hf + {0..3, 8..11} of the tile] from the row-major V tile
+                    const char *vb = vt + (16 * s2 + 4 * hf + (li >> 2)) * KSTR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
+                    const bf16x8 vf = mq_frag_tr(vb, 8 * KSTR);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        l += __shfl_xor(l, 32);
+        if (qvalid) {
+            const float inv = 1.0f / l;
+            bf16_t *orow = o + (int64_t)(r0 + qrow) * ld_o + hh * DH;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    mq_bf16x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(oacc[dt][4 * tq + j] * inv);
+                    *reinterpret_cast<mq_bf16x4 *>(orow + dt * 32 + 8 * tq + 4 * hf) = w;
+                }
+            if (hf == 0) lse[(int64_t)(r0 + qrow) * H + hh] = (m + __log2f(l)) * 0.6931471805599453f;
+        }
+    }
+}
+
 static size_t mq_fwd_lds(int SP, int dh, int esz) { return (size_t)MQ * dh * 4 + (size_t)MQ * SP * 4 + (size_t)MQ_KB * dh * esz; }
 static size_t mq_bwd_lds(int dh, int esz) { return (size_t)2 * MQ * dh * 4 + 2 * MQ * 4 + (size_t)MQ * MQ_KB * 4 + (size_t)MQ_KB * dh * esz; }
 
@@ -359,6 +531,19 @@ extern "C" int b4c_attn_mq_fwd(const void *q, int ld_q, const void *kv, int ld_k
     const int SP = (max_len + 63) / 64 * 64;
     const float sq = sqrtf((float)dh);
     hipStream_t st = (hipStream_t)stream;
+    static const bool valu_only = getenv("B4C_MQ_VALU") && atoi(getenv("B4C_MQ_VALU")) != 0;
+    if (dtype == B4C_BF16 && !valu_only) {      // matrix-core form, one wave per (sequence, head)
+        const int n_items = B * H;
+        const size_t shm_m = (size_t)MQ_WAVES * 2 * 32 * (dh * 2 + 16);
+        const int grid = (n_items + MQ_WAVES - 1) / MQ_WAVES;
+#define MQ_MFMA(DHH, PP)                                                                                                             \
+    attn_mq_fwd_mfma_kernel<DHH, PP><<<grid, 64 * MQ_WAVES, shm_m, st>>>((const bf16_t *)q, ld_q, (const bf16_t *)kv, ld_kv, key_pad, cu_seqlens, \
+                                                                       q_offsets, (bf16_t *)o, ld_o, lse, H, n_items, 1.0f / sq)
+        if (dh == 64) { if (key_pad) MQ_MFMA(64, true); else MQ_MFMA(64, false); }
+        else { if (key_pad) MQ_MFMA(32, true); else MQ_MFMA(32, false); }
+#undef MQ_MFMA
+        return b4c_check_launch("attn_mq_fwd (mfma)");
+    }
     const size_t shm = mq_fwd_lds(SP, dh, dtype == B4C_BF16 ? 2 : 4);
     B4C_REQUIRE(shm <= 160 * 1024, "attn_mq_fwd: max_len %d needs %zu bytes of LDS", max_len, shm);
 #define MQ_FWD(TT, DHH)                                                                                                              \

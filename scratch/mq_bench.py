@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bert4clickpath_amd import ops
 torch.manual_seed(0)
-B, H, dh, S = 4096, 2, 64, 200
-lens = torch.randint(23, S + 1, (B,))
+B, H, dh, S = int(os.environ.get('MQ_B', '4096')), 2, 64, int(os.environ.get('MQ_S', '200'))
+lens = torch.randint(min(23, S), S + 1, (B,))
 cu = torch.zeros(B + 1, dtype=torch.int32); cu[1:] = torch.cumsum(lens, 0)
 M = int(os.environ.get('MQ_M', '10'))
 moff = (torch.arange(B + 1, dtype=torch.int32) * M)
