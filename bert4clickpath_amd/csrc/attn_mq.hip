@@ -504,6 +504,226 @@ __global__ void __launch_bounds__(64 * MQ_WAVES, 3) attn_mq_fwd_mfma_kernel(cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 backward on the matrix cores, one wave per (sequence, head), key tiles of 32 (the maps of attn_mfma.hip's backward):
+//   S = Q K^T and dP = dO V^T with the KEY on the lane (Q / dO rows and the K tile from LDS, V rows straight from global),
+//   P = 2^(S scale log2e + mask - lse_q), dS = P (dP - delta_q); P and dS feed dV^T = dO^T P and dK^T = Q^T dS from the
+//   accumulator registers; dS crosses LDS once for dQ^T += K^T dS^T (query on the lane: dQ stays in registers over the key
+//   tiles).  dK / dV of a tile leave as 8-byte pieces of their rows.  More than 32 query rows: further passes that add to
+//   the dK / dV rows already written.
+// LDS per wave: sQ | sG [32][KSTR] (the query tile and its dO), sK [32][KSTR] (current key tile), sDS [32][TSTR], lse2 / delta.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 mq_frag_2x8B(const char *p0, const char *p1) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2v;
+    const u32x2v lo = *reinterpret_cast<const u32x2v *>(p0);
+    const u32x2v hi = *reinterpret_cast<const u32x2v *>(p1);
+    const mq_u32x4 w = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+template <int DH, bool HAS_PAD>
+__global__ void __launch_bounds__(64 * MQ_WAVES, 2) attn_mq_bwd_mfma_kernel(const bf16_t *__restrict__ q, int ld_q, const bf16_t *__restrict__ kv,
+                                                                         int ld_kv, const uint8_t *__restrict__ key_pad,
+                                                                         const int32_t *__restrict__ cu, const int32_t *__restrict__ moff,
+                                                                         const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o,
+                                                                         int ld_do, const float *__restrict__ lse, bf16_t *__restrict__ dq,
+                                                                         int ld_dq, bf16_t *__restrict__ dkv, int ld_dkv, int H, int n_items,
+                                                                         float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KSTR = DH * 2 + 16, TSTR = 32 * 2 + 16;
+    constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8, VC = 32 * CH / 64;
+    constexpr int WBYTES = 3 * 32 * KSTR + 32 * TSTR + 2 * 32 * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5, li = lane & 15, g = lane >> 4;
+    char *sQ = smem + wave * WBYTES;
+    char *sG = sQ + 32 * KSTR;
+    char *sK = sG + 32 * KSTR;
+    char *sDS = sK + 32 * KSTR;
+    float *sLse = reinterpret_cast<float *>(sDS + 32 * TSTR);
+    float *sDelta = sLse + 32;
+    const int item = blockIdx.x * MQ_WAVES + wave;
+    if (item >= n_items) return;                              // (no workgroup barrier anywhere below)
+    const int b = item / H, hh = item % H, dm = H * DH;
+    const int64_t tok0 = cu[b];
+    const int S = cu[b + 1] - cu[b];
+    const int r0 = moff[b], M = moff[b + 1] - moff[b];
+    if (S <= 0) return;
+    bf16_t *dkbase = dkv + tok0 * ld_dkv + hh * DH;
+    if (M <= 0) {                                             // no query reads this sequence's keys in this layer
+        for (int c = lane; c < S * CH; c += 64) {
+            const int row = c / CH, part = c % CH;
+            const mq_u32x4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<mq_u32x4 *>(dkbase + (int64_t)row * ld_dkv + part * 8) = z;
+            *reinterpret_cast<mq_u32x4 *>(dkbase + (int64_t)row * ld_dkv + dm + part * 8) = z;
+        }
+        return;
+    }
+    const int nkt = (S + 31) >> 5;
+    const float scale2 = scale * 1.4426950408889634f;
+    const bf16_t *kbase = kv + tok0 * ld_kv + hh * DH;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(kbase), 0, (unsigned)((int64_t)S * ld_kv * 2 - (int64_t)hh * DH * 2), 0x00020000);
+    const int koff0 = ((lane / CH) * ld_kv + (lane % CH) * 8) * 2;            // K chunk i: rows (lane + 64 i) / CH
+    const int voff = (r * ld_kv + dm + hf * 8) * 2;                            // this lane's V row (as the B operand of dP)
+    const int tile_bytes = 32 * ld_kv * 2;
+    for (int q0 = 0; q0 < M; q0 += 32) {
+        const int qrow = q0 + r;
+        const bool qvalid = qrow < M;
+        // ---- the query tile: Q and dO rows -> LDS (row-major, zero rows past M), delta = rowsum(dO * O), lse in log2 units
+        {
+            float pd = 0.f;
+#pragma unroll
+            for (int i = 0; i < VC; ++i) {
+                const int c = lane + 64 * i, row = c / CH, part = c % CH;
+                mq_u32x4 vq = {0u, 0u, 0u, 0u}, vg = {0u, 0u, 0u, 0u}, vo = {0u, 0u, 0u, 0u};
+                if (q0 + row < M) {
+                    vq = *reinterpret_cast<const mq_u32x4 *>(q + (int64_t)(r0 + q0 + row) * ld_q + hh * DH + part * 8);
+                    vg = *reinterpret_cast<const mq_u32x4 *>(d_o + (int64_t)(r0 + q0 + row) * ld_do + hh * DH + part * 8);
+                    vo = *reinterpret_cast<const mq_u32x4 *>(o + (int64_t)(r0 + q0 + row) * ld_o + hh * DH + part * 8);
+                }
+                *reinterpret_cast<mq_u32x4 *>(sQ + row * KSTR + part * 16) = vq;
+                *reinterpret_cast<mq_u32x4 *>(sG + row * KSTR + part * 16) = vg;
+                const bf16x8 g8 = __builtin_bit_cast(bf16x8, vg), o8 = __builtin_bit_cast(bf16x8, vo);
+                pd = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pd += (float)g8[k] * (float)o8[k];
+                pd = group_sum<CH>(pd);                       // CH consecutive lanes share a row
+                if (part == 0) sDelta[row] = pd;
+            }
+            if (lane < 32) sLse[lane] = (q0 + lane < M) ? lse[(int64_t)(r0 + q0 + lane) * H + hh] * 1.4426950408889634f : INFINITY;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 qa[NKS], ga[NKS];                              // A operands: this lane's query row (half a k-step each)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qa[ks] = *reinterpret_cast<const bf16x8 *>(sQ + r * KSTR + ks * 32 + hf * 16);
+            ga[ks] = *reinterpret_cast<const bf16x8 *>(sG + r * KSTR + ks * 32 + hf * 16);
+        }
+        float lq[16], dl[16];                                 // lse2 / delta of the accumulator rows (queries) of this lane
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(sLse + 8 * tq + 4 * hf);
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sDelta + 8 * tq + 4 * hf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { lq[4 * tq + j] = a4[j]; dl[4 * tq + j] = b4[j]; }
+        }
+        f32x16 dqa[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) dqa[dt][t] = 0.f;
+        mq_u32x4 rk[VC], vb[NKS];
+        auto fetch = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < VC; ++i) rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, koff0 + kt * tile_bytes + i * (64 / CH) * ld_kv * 2, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) vb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kt * tile_bytes + ks * 32, 0, 0);
+        };
+        fetch(0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int key = kt * 32 + r;
+#pragma unroll
+            for (int i = 0; i < VC; ++i) {
+                const int c = lane + 64 * i, row = c / CH, part = c % CH;
+                *reinterpret_cast<mq_u32x4 *>(sK + row * KSTR + part * 16) = rk[i];
+            }
+            bf16x8 vcur[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) vcur[ks] = __builtin_bit_cast(bf16x8, vb[ks]);
+            float madd = (key < S) ? 0.f : -INFINITY;
+            if (HAS_PAD) { if (key < S && key_pad[tok0 + key]) madd = -1e9f * 1.4426950408889634f; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (kt + 1 < nkt) fetch(kt + 1);                  // in flight during this tile
+            f32x16 sa, pa;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { sa[t] = 0.f; pa[t] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kb = *reinterpret_cast<const bf16x8 *>(sK + r * KSTR + ks * 32 + hf * 16);
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kb, sa, 0, 0, 0);
+                pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[ks], vcur[ks], pa, 0, 0, 0);
+            }
+            float pv[16], dsv[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[t], scale2, madd - lq[t]));
+                pv[t] = p;
+                dsv[t] = p * (pa[t] - dl[t]);
+                *reinterpret_cast<bf16_t *>(sDS + mq_rowmap(t, hf) * TSTR + r * 2) = (bf16_t)dsv[t];
+            }
+            // dV^T = dO^T P, dK^T = Q^T dS (key on the lane), from the accumulator registers
+            f32x16 dv[NDT], dk[NDT];
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { dv[dt][t] = 0.f; dk[dt][t] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = mq_pack8(pv + 8 * s2);
+                const bf16x8 df = mq_pack8(dsv + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const int off = (16 * s2 + 4 * hf + (li >> 2)) * KSTR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
+                    const bf16x8 fgt = mq_frag_tr(sG + off, 8 * KSTR);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fgt, pf, dv[dt], 0, 0, 0);
+                    const bf16x8 fqt = mq_frag_tr(sQ + off, 8 * KSTR);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fqt, df, dk[dt], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the dS tile is in LDS
+            __builtin_amdgcn_wave_barrier();
+            // dQ^T += K^T dS^T (query on the lane)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 fs = mq_frag_2x8B(sDS + r * TSTR + (16 * s2 + 4 * hf) * 2, sDS + r * TSTR + (16 * s2 + 8 + 4 * hf) * 2);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const int off = (16 * s2 + 4 * hf + (li >> 2)) * KSTR + (dt * 32 + 16 * (g & 1) + 4 * (li & 3)) * 2;
+                    const bf16x8 fkt = mq_frag_tr(sK + off, 8 * KSTR);
+                    dqa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fkt, fs, dqa[dt], 0, 0, 0);
+                }
+            }
+            // this tile's dK / dV rows (key = lane): 8-byte pieces, added to what an earlier query pass wrote
+            if (key < S) {
+                bf16_t *krow = dkbase + (int64_t)key * ld_dkv;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int tq = 0; tq < 4; ++tq) {
+                        mq_bf16x4 wk, wv;
+                        bf16_t *pk = krow + dt * 32 + 8 * tq + 4 * hf;
+                        float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (q0 > 0) {
+                            const mq_bf16x4 ek = *reinterpret_cast<const mq_bf16x4 *>(pk), ev = *reinterpret_cast<const mq_bf16x4 *>(pk + dm);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { ak[j] = (float)ek[j]; av[j] = (float)ev[j]; }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            wk[j] = (bf16_t)(dk[dt][4 * tq + j] * scale + ak[j]);
+                            wv[j] = (bf16_t)(dv[dt][4 * tq + j] + av[j]);
+                        }
+                        *reinterpret_cast<mq_bf16x4 *>(pk) = wk;
+                        *reinterpret_cast<mq_bf16x4 *>(pk + dm) = wv;
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();                  // (sK / sDS are rewritten by the next tile: LDS is in order per wave)
+        }
+        if (qvalid) {
+            bf16_t *qo = dq + (int64_t)(r0 + qrow) * ld_dq + hh * DH;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    mq_bf16x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(dqa[dt][4 * tq + j] * scale);
+                    *reinterpret_cast<mq_bf16x4 *>(qo + dt * 32 + 8 * tq + 4 * hf) = w;
+                }
+        }
+    }
+}
+
 static size_t mq_fwd_lds(int SP, int dh, int esz) { return (size_t)MQ * dh * 4 + (size_t)MQ * SP * 4 + (size_t)MQ_KB * dh * esz; }
 static size_t mq_bwd_lds(int dh, int esz) { return (size_t)2 * MQ * dh * 4 + 2 * MQ * 4 + (size_t)MQ * MQ_KB * 4 + (size_t)MQ_KB * dh * esz; }
 
@@ -568,6 +788,22 @@ extern "C" int b4c_attn_mq_bwd(const void *q, int ld_q, const void *kv, int ld_k
                     ld_dq % 8 == 0 && ld_dkv % 8 == 0, "attn_mq_bwd: pitches");
     const float sq = sqrtf((float)dh);
     hipStream_t st = (hipStream_t)stream;
+    static const bool valu_only = getenv("B4C_MQ_VALU") && atoi(getenv("B4C_MQ_VALU")) != 0;
+    if (dtype == B4C_BF16 && !valu_only) {      // matrix-core form, one wave per (sequence, head)
+        const int n_items = B * H, kstr = dh * 2 + 16;
+        const size_t shm_m = (size_t)MQ_WAVES * (3 * 32 * kstr + 32 * (32 * 2 + 16) + 2 * 32 * 4);
+        const int grid = (n_items + MQ_WAVES - 1) / MQ_WAVES;
+#define MQ_MFMA_B(DHH, PP)                                                                                                           \
+    do {                                                                                                                             \
+        mq_allow_lds(attn_mq_bwd_mfma_kernel<DHH, PP>, shm_m);                                                                       \
+        attn_mq_bwd_mfma_kernel<DHH, PP><<<grid, 64 * MQ_WAVES, shm_m, st>>>((const bf16_t *)q, ld_q, (const bf16_t *)kv, ld_kv, key_pad, cu_seqlens, \
+            q_offsets, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dq, ld_dq, (bf16_t *)dkv, ld_dkv, H, n_items, 1.0f / sq); \
+    } while (0)
+        if (dh == 64) { if (key_pad) MQ_MFMA_B(64, true); else MQ_MFMA_B(64, false); }
+        else { if (key_pad) MQ_MFMA_B(32, true); else MQ_MFMA_B(32, false); }
+#undef MQ_MFMA_B
+        return b4c_check_launch("attn_mq_bwd (mfma)");
+    }
     const size_t shm = mq_bwd_lds(dh, dtype == B4C_BF16 ? 2 : 4);
 #define MQ_BWD(TT, DHH)                                                                                                              \
     do {                                                                                                                             \
