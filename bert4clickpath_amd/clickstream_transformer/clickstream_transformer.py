@@ -224,6 +224,37 @@ class ClickstreamTransformer(nn.Module):
         packed / n_real_tokens: as in cloze_loss (value_to_head models only)."""
         feats = {k: v for k, v in inputs.items() if k != 'instance_id'}
         pack = self._use_packed(feats, packed, n_real_tokens)
+        if self.segment_to_head is None and self.value_to_head is not None and ops.mq_last_layer and \
+                self.transformer.encoder.rows_supported(None):
+            # the head reads the rows at the value_to_head positions only: the last encoder layer is evaluated for those
+            # rows alone (padded to M per sequence; a padding slot is a query row made of zeros whose output nobody reads)
+            def positions(ids_first, raw_first):
+                counts, offsets, flat, mx = self._match_positions(ids_first, raw_first)
+                M = int(mx.item()) if max_matches is None else int(max_matches)   # .item(): the padded width
+                if M == 0:
+                    return None
+                B = ids_first.shape[0]
+                pidx = ops.padded_index(counts, offsets, flat, B, M)
+                moff = torch.arange(B + 1, dtype=torch.int32, device=pidx.device) * M
+                # the reference pads the (B, M, d) head input with ZERO rows (ragged -> dense): slot i keeps its row, a padding
+                # slot gathers row -1 = zeros
+                keep = torch.where(pidx >= 0, torch.arange(B * M, dtype=torch.int32, device=pidx.device),
+                                   torch.full_like(pidx, -1))
+                return pidx, moff, (M, keep)
+            enc, ids_first, raw_first, seg_starts, seg_ends = self._encode(feats, training, pack, n_real_tokens, rows_of=positions)
+            if self._rows_extra is not None:
+                M, keep = self._rows_extra
+                B = ids_first.shape[0]
+                enc = ops.GatherRowsFn.apply(enc, keep, B * M)
+                logits = self.head(enc.view(B, M, enc.shape[-1]))
+                if 'instance_id' in inputs.keys():
+                    return {'instance_id': inputs['instance_id'], 'logits': logits}
+                return logits
+            head_input = enc.new_zeros(ids_first.shape[0], 0, enc.shape[-1])       # no position matches anywhere
+            logits = self.head(head_input)
+            if 'instance_id' in inputs.keys():
+                return {'instance_id': inputs['instance_id'], 'logits': logits}
+            return logits
         enc, ids_first, raw_first, seg_starts, seg_ends = self._encode(feats, training, pack, n_real_tokens)
         B, S = ids_first.shape
         d = enc.shape[-1]
