@@ -339,7 +339,9 @@ def main():
                 roof['traffic'] = traffic.get(roof['family'])
         # per-step durations on the device timeline (events at the step boundaries; steps with the launch recorder on are
         # ~0.4 ms longer): SURVEY 8d asks for the median and p10 / p90
-        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+        raw_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+        step_ms = sorted(raw_ms)
+        slowest = max(range(a.steps), key=lambda i: raw_ms[i])
 
         def pct(q):
             return step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))]
@@ -363,7 +365,7 @@ def main():
                        'global_batch': a.batch * world, 'seq_len': a.seq, 'parallelism': 'dp%d' % world,
                        'grad_reduce': 'sum (reference semantics)'},
             'tokens_per_s': a.batch * world * a.seq * a.steps / dt,
-            'step_ms': {'median': pct(0.5), 'p10': pct(0.1), 'p90': pct(0.9), 'min': step_ms[0], 'max': step_ms[-1]},
+            'step_ms': {'median': pct(0.5), 'p10': pct(0.1), 'p90': pct(0.9), 'min': step_ms[0], 'max': step_ms[-1], 'slowest_step': slowest},
             'final_loss': float(loss.detach()),
             'roofline': roof,
         }
