@@ -1058,7 +1058,8 @@ def rows_add_(dst, idx, src):
     return dst
 
 
-mq_last_layer = True       # Cloze path: the last encoder layer runs for the [MASK] rows only (MQAttnBlockFn)
+# Cloze path: the last encoder layer runs for the [MASK] rows only (MQAttnBlockFn); B4C_MQ_LAST_LAYER=0 computes the full layer
+mq_last_layer = os.environ.get('B4C_MQ_LAST_LAYER', '1') != '0'
 
 
 class MQAttnBlockFn(torch.autograd.Function):
