@@ -175,7 +175,9 @@ def cpu_baseline(a):
 
 KERNEL_OF = {   # launch family (ops recorder) -> kernel symbol(s) in the rocprofv3 trace
     'gemm_nt': 'gemm_nt_kernel (dense fwd + dX)', 'gemm_tn': 'gemm_tn_bf16_kernel (dW)',
-    'attn_fwd': 'attn_fwd_mfma_kernel', 'attn_bwd': 'attn_bwd_resident_kernel', 'softmax_ce': 'softmax_ce_bf16_kernel',
+    'attn_fwd': 'attn_fwd_mfma_kernel', 'attn_bwd': 'attn_bwd_resident_kernel',
+    'attn_mq_fwd': 'attn_mq_fwd_mfma_kernel (last layer: the [MASK] rows against all keys, one wave per (sequence, head))',
+    'attn_mq_bwd': 'attn_mq_bwd_mfma_kernel', 'softmax_ce': 'softmax_ce_bf16_kernel',
     'add_ln_fwd': 'add_ln_fwd_kernel', 'gemm_nt_ln': 'gemm_nt_ln_kernel (out-proj / FFN2 GEMM + residual + dropout + LayerNorm)', 'add_ln_bwd': 'add_ln_bwd_kernel', 'embed_fwd': 'embed_fwd_kernel',
     'embed_bwd': 'embed_bwd_kernel', 'adam': 'adam_kernel',
     'vocab_ce_fwd': 'vce_token_kernel<128,1|2> + vce_combine_kernel (projection + softmax CE + dX, logits in registers)',

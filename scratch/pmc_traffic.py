@@ -3,7 +3,7 @@ HBM bytes per launch for each launch family, corrected as MI355X_MICROARCH.md pr
 (FETCH_SIZE counts 64 B per 128-B request of a wide streaming read -> x2; WRITE_SIZE is exact; both in KiB)."""
 import csv, glob, json, sys, collections
 # (family, kernels whose traffic counts, the kernel that marks ONE launch of the family)
-FAM = [('gemm_nt_ln', ('gemm_nt_ln_kernel', 'gemm_nt_ln256_kernel'), None), ('vocab_proj', ('gemm_nt_wide',), None), ('gemm_nt', ('gemm_nt_kernel',), None),
+FAM = [('attn_mq_fwd', ('attn_mq_fwd',), None), ('attn_mq_bwd', ('attn_mq_bwd',), None), ('gemm_nt_ln', ('gemm_nt_ln_kernel', 'gemm_nt_ln256_kernel'), None), ('vocab_proj', ('gemm_nt_wide',), None), ('gemm_nt', ('gemm_nt_kernel',), None),
        ('softmax_rows', ('softmax_rows',), None), ('topk_rows', ('topk_rows',), None), ('gemm_tn', ('gemm_tn_', 'tn_reduce_kernel'), 'gemm_tn_'),
        ('attn_bwd', ('attn_bwd',), None), ('attn_fwd', ('attn_fwd',), None), ('softmax_ce', ('softmax_ce',), None),
        ('add_ln_fwd', ('add_ln_fwd',), None), ('add_ln_bwd', ('add_ln_bwd',), None), ('embed_bwd', ('embed_bwd',), None),
