@@ -437,6 +437,8 @@ def attn_mq_bwd(q, kv, cu, moff, o, d_o, lse, B, max_len, H, dh, key_pad=None):
     """-> (dq [R, H*dh], dkv [T, 2*H*dh]); every token row of dkv is written (zeros where no query reads the sequence)."""
     R = q.shape[0]
     dq = torch.zeros_like(q)
+    if R == 0:                 # no query row anywhere: no key or value receives a gradient from this layer
+        return dq, torch.zeros_like(kv)
     dkv = torch.empty_like(kv)
     if kv.shape[0] == 0:
         return dq, dkv
@@ -496,6 +498,8 @@ def add_dropout_layernorm_fwd(x, y, gamma, beta, rate, seed, save=True):
     z = torch.empty_like(x) if save else None
     out = torch.empty_like(x)
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if save else None
+    if rows == 0:
+        return z, out, stats
     with _record('add_ln_fwd', rows * d * x.element_size() * (4 if save else 3)):
         L.check(L.lib().b4c_add_dropout_layernorm_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(z), _p(out), _p(stats), rows, d,
                                                       LN_EPS, rate, seed, dt_code(x.dtype), _st()), 'add_dropout_layernorm_fwd')
@@ -559,6 +563,8 @@ def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed, into=None):
     else:
         dgamma = torch.zeros(d, dtype=torch.float32, device=z.device)
         dbeta = torch.zeros(d, dtype=torch.float32, device=z.device)
+    if rows == 0:          # no row at all (a batch without a [MASK]): nothing to add to dgamma / dbeta
+        return dz, (dy if dy is not None else dz), dgamma, dbeta
     with _record('add_ln_bwd', rows * d * z.element_size() * (4 if rate > 0 else 3)):
         L.check(L.lib().b4c_add_dropout_layernorm_bwd(_p(dout), _p(z), _p(stats), _p(gamma), _p(dz), _p(dy), _p(dgamma),
                                                       _p(dbeta), rows, d, rate, seed, dt_code(z.dtype), _st()),
@@ -1053,6 +1059,8 @@ class AttnBlockFn(torch.autograd.Function):
 
 def rows_add_(dst, idx, src):
     """dst[idx[r]] += src[r] for idx[r] >= 0 (distinct indices)."""
+    if src.shape[0] == 0:
+        return dst
     L.check(L.lib().b4c_rows_add(_p(dst), dst.stride(0), _p(idx), _p(src), src.stride(0), src.shape[0], src.shape[1],
                                  dt_code(dst.dtype), dt_code(src.dtype), _st()), 'rows_add')
     return dst

@@ -188,3 +188,31 @@ def test_masked_query_last_layer_bf16_packed_and_dropout():
         opt.step()
         losses.append(float(loss))
     assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0]
+
+
+def test_masked_query_last_layer_without_any_mask():
+    """A batch without a single [MASK] (an empty replica of a data-parallel step): the loss is 0, every gradient is
+    defined (zeros), nothing faults -- with the arena's in-place gradients and without."""
+    from bert4clickpath_amd import optim
+    V, S, B = 90, 24, 5
+    for arena in (False, True):
+        model = _model(V, 64, 2, 2, (32, 24), torch.bfloat16, dropout=0.1)
+        opt = optim.Adam(model.parameters(), 1e-3, 0.9, 0.999, 1e-9) if arena else None
+        g = torch.Generator().manual_seed(2)
+        items = torch.randint(10, 10 + V, (B, S), generator=g).cuda()         # item ids only: no [MASK] (id 1) anywhere
+        labels = torch.full((B, 10), -1.0).cuda()
+        if opt:
+            opt.zero_grad()
+        loss = model.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, n_real_tokens=B * (S + 3))
+        loss.backward()
+        assert float(loss) == 0.0
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                assert bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) == 0.0, n
+        if opt:
+            opt.step()
+        # the form that reads the row count back: R = 0 rows reach the last layer and the head
+        model.zero_grad()
+        loss = model.cloze_loss({'asin': items}, labels, training=True)
+        loss.backward()
+        assert float(loss) == 0.0
