@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_rows', type=int, default=256, help='sequences in the bounded CPU-baseline sample (SURVEY 8d: B=256)')
     ap.add_argument('--eval_steps', type=int, default=6, help='timed scoring batches (0 = skip the scoring leg)')
+    ap.add_argument('--full_steps', type=int, default=8, help='extra steps, after the timed region, of the step that computes every position of every '
+                    'layer (padded layout, full last layer) for the every_position_of_every_layer entry; 0 = skip')
     ap.add_argument('--dense', action='store_true', help='A/B: run the encoder on the padded (B, S) layout as the reference does '
                     '(default: padding-free layout, pad positions are not computed -- DESIGN.md section 3)')
     ap.add_argument('--full_length', action='store_true', help='SURVEY 8d no-padding variant: every sequence has 197 items (the packed '
@@ -362,8 +364,9 @@ def main():
                                       '; two concatenated features items(%d)+actions(%d, vocab %d)' % (a.d_model - a.action_dim, a.action_dim, a.action_vocab)
                                       if a.action_dim > 0 else '',
                                       'the padded (B, S) layout' if a.dense else
-                                      'the padding-free layout (%.0f %% of the B x S positions are real tokens)'
-                                      % (100.0 * sum(b['n_real'] for b in batches) / (len(batches) * a.batch * a.seq))),
+                                      'the padding-free layout (%.0f %% of the B x S positions are real tokens)%s'
+                                      % (100.0 * sum(b['n_real'] for b in batches) / (len(batches) * a.batch * a.seq),
+                                         ', last layer evaluated at the [MASK] rows only' if ops.mq_last_layer else '')),
                        'global_batch': a.batch * world, 'seq_len': a.seq, 'parallelism': 'dp%d' % world,
                        'grad_reduce': 'sum (reference semantics)'},
             'tokens_per_s': a.batch * world * a.seq * a.steps / dt,
@@ -383,6 +386,31 @@ def main():
                 out['roofline_largest_hbm_family'] = r2
         if world == 1 and a.eval_steps > 0:
             out['eval'] = eval_leg(model, batches, a, peak_tf)
+        if world == 1 and a.full_steps > 0 and not a.dense:
+            # the same training step with EVERY position of EVERY layer computed, as the reference's dataflow does (padded
+            # layout, full last layer): same loss and gradients, the work whose results nothing reads included
+            prev = ops.mq_last_layer
+            ops.mq_last_layer = False
+            a.dense = True
+            try:
+                for i in range(3):
+                    step(i)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(a.full_steps):
+                    step(i)
+                e1.record()
+                torch.cuda.synchronize()
+                fms = e0.elapsed_time(e1) / a.full_steps
+                Rf = sum(batches[i % len(batches)]['R'] for i in range(a.full_steps)) / a.full_steps
+                out['every_position_of_every_layer'] = {
+                    'what': 'the same step on the padded layout with the full last layer (what the reference computes); '
+                            'identical loss and gradients', 'steps': a.full_steps, 'ms_per_step': fms,
+                    'masked_items_per_s': Rf / fms * 1e3}
+            finally:
+                ops.mq_last_layer = prev
+                a.dense = False
         if world == 1 and not a.no_cpu_baseline and a.action_dim == 0:
             out['cpu_baseline'] = cpu_baseline(a)
         print(json.dumps(out))
