@@ -50,6 +50,15 @@ def lib():
             raise B4CError(
                 'libb4c_hip.so not found at %s: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 '(or `make -C bert4clickpath_amd/csrc`).  There is no CPU fallback.' % LIB_PATH)
+        # PyTorch's HIP runtime must have seen the device before this library (and the system HIP runtime it links)
+        # comes into the process: loaded the other way round -- e.g. build() and then smoke() in ONE process -- this
+        # library's launches fail with "no ROCm-capable device is detected".  (No GPU: nothing to initialise.)
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         c = ctypes
         vp, i32, i64, f32, u64 = c.c_void_p, c.c_int, c.c_int64, c.c_float, c.c_uint64
