@@ -58,7 +58,9 @@ def _ref(cu, moff, q, kv, go, H, dh, key_pad=None):
 
 @pytest.mark.parametrize('dtype,H,dh,smax,mmax,pad', [
     (torch.float32, 2, 64, 50, 10, False), (torch.float32, 4, 32, 200, 20, True), (torch.float32, 2, 64, 300, 5, False),
-    (torch.bfloat16, 2, 64, 200, 10, False), (torch.bfloat16, 4, 64, 512, 12, True), (torch.bfloat16, 2, 32, 70, 33, False)])
+    (torch.bfloat16, 2, 64, 200, 10, False), (torch.bfloat16, 4, 64, 512, 12, True), (torch.bfloat16, 2, 32, 70, 33, False),
+    (torch.bfloat16, 1, 64, 3, 1, False), (torch.bfloat16, 2, 64, 33, 32, False), (torch.bfloat16, 2, 32, 64, 64, True),
+    (torch.float32, 1, 32, 3, 1, False), (torch.bfloat16, 3, 64, 129, 7, False)])
 def test_attn_mq_kernels_match_fp64(dtype, H, dh, smax, mmax, pad):
     from bert4clickpath_amd import ops
     B = 9
