@@ -671,7 +671,14 @@ extern "C" int b4c_row_scale_f32(const void *src, int ld, const float *scale, fl
 __global__ void __launch_bounds__(1024) label_scale_kernel(const int32_t *__restrict__ labels, int64_t R, int V, float *__restrict__ out) {
     __shared__ int part[16];
     int c = 0;
-    for (int64_t i = threadIdx.x; i < R; i += 1024) {
+    const int64_t R4 = ((reinterpret_cast<uintptr_t>(labels) & 15) == 0) ? (R >> 2) : 0;      // 16-byte loads over the aligned body
+    for (int64_t i = threadIdx.x; i < R4; i += 1024) {
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        const i32x4 y4 = reinterpret_cast<const i32x4 *>(labels)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c += (y4[k] >= 0 && y4[k] < V) ? 1 : 0;
+    }
+    for (int64_t i = R4 * 4 + threadIdx.x; i < R; i += 1024) {
         const int y = labels[i];
         c += (y >= 0 && y < V) ? 1 : 0;
     }
@@ -699,7 +706,12 @@ __global__ void __launch_bounds__(1024) sum_scaled_kernel(const float *__restric
                                                           const int32_t *__restrict__ poison, float *__restrict__ out) {
     __shared__ float part[16];
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < R; i += 1024) s += item[i];
+    const int64_t R4 = ((reinterpret_cast<uintptr_t>(item) & 15) == 0) ? (R >> 2) : 0;
+    for (int64_t i = threadIdx.x; i < R4; i += 1024) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(item)[i];
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (int64_t i = R4 * 4 + threadIdx.x; i < R; i += 1024) s += item[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
