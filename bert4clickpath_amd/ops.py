@@ -925,13 +925,13 @@ def repack_stale(dtype, dev):
                 continue
             descs += pk._descs(ent, Kp)
             ents.append((ent, key))
-            tiles += [((pk.K + 31) // 32) * ((n + 31) // 32) for n in pk.Ns]
+            tiles += [((pk.K + 63) // 64) * ((n + 63) // 64) for n in pk.Ns]       # 64 x 64 tiles (csrc/rowops.hip)
     _pack_registry[:] = alive
     if not descs:
         return
     # The launch is a (largest tile count) x (descriptors) grid whose surplus workgroups exit at once; one vocabulary
-    # projection (6,252 tiles of 32 x 32 at C2) beside thirty encoder matrices (16 tiles each) made that 180,000 workgroups
-    # for 7,500 tiles of work.  Descriptors are ordered by size and launched in groups of similar size (a factor of 8).
+    # projection (1,564 tiles of 64 x 64 at C2) beside thirty encoder matrices (4 tiles each) would make that 50,000 workgroups
+    # for 1,900 tiles of work.  Descriptors are ordered by size and launched in groups of similar size (a factor of 8).
     order = sorted(range(len(descs)), key=lambda i: tiles[i])
     descs = [descs[i] for i in order]
     tiles = [tiles[i] for i in order]

@@ -99,6 +99,7 @@ typedef struct {
     int32_t K, N, ld_t, ld_c, col_off, _pad;
 } b4c_pack_desc;
 int b4c_pack_weights_batched(const b4c_pack_desc *d_desc, int n_desc, int max_tiles, int dtype, void *stream);
+/* (max_tiles: the largest ceil(K / 64) * ceil(N / 64) over the descriptors -- the launch is max_tiles x n_desc workgroups) */
 
 /* C[M][N] = epilogue( A[M][K] . Bt[N][K]^T )     (both operands K-contiguous)
  *   v = acc + bias[n]            (bias fp32 or NULL)
