@@ -827,3 +827,148 @@ extern "C" int b4c_rows_add(void *dst, int ld_dst, const int32_t *idx, const voi
     else B4C_REQUIRE(false, "rows_add: dtype %d", dtype);
     return b4c_check_launch("rows_add");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stable LSD radix sort of token positions by table row (the order the sorted embedding backward walks): 8-bit digits,
+// one wave per 1024-key chunk, per pass a histogram, two scan and a scatter launch.  order[i] = position of the i-th
+// smallest id (ties in position order) -- what torch.sort(stable) returned through 14 launches.
+//   ids int64 [n] (clamped to [0, n_rows - 1] as the embedding kernels clamp them); workspace: see b4c_sort_ids_workspace_bytes
+// ------------------------------------------------------------------------------------------------------------------
+#define SORT_CHUNK 1024
+
+__device__ __forceinline__ unsigned sort_key(const int64_t *ids, const int32_t *pos_in, int64_t i, int n_rows) {
+    const int64_t p = pos_in ? pos_in[i] : i;
+    int64_t v = ids[p];
+    v = v < 0 ? 0 : (v >= n_rows ? n_rows - 1 : v);
+    return (unsigned)v;
+}
+
+__global__ void __launch_bounds__(64) sort_hist_kernel(const int64_t *__restrict__ ids, const int32_t *__restrict__ pos_in, int64_t n,
+                                                       int n_rows, int shift, int nblocks, int32_t *__restrict__ hist) {
+    __shared__ int cnt[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += 64) cnt[d] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t i0 = (int64_t)blockIdx.x * SORT_CHUNK;
+    for (int g = 0; g < SORT_CHUNK; g += 64) {
+        const int64_t i = i0 + g + lane;
+        if (i < n) atomicAdd(&cnt[(sort_key(ids, pos_in, i, n_rows) >> shift) & 255], 1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int d = lane; d < 256; d += 64) hist[(int64_t)d * nblocks + blockIdx.x] = cnt[d];      // digit-major: one scan orders it
+}
+
+// exclusive prefix sum over hist[256][nblocks] (digit-major) in place, in two launches of 256 workgroups: each digit's row
+// is scanned on its own and leaves its total; then every row adds the totals of the digits before it.  (One workgroup
+// walking all 256 * nblocks entries took 180 us.)
+__global__ void __launch_bounds__(256) sort_rowscan_kernel(int32_t *__restrict__ hist, int nblocks, int32_t *__restrict__ totals) {
+    __shared__ int part[256];
+    const int tid = threadIdx.x;
+    int32_t *row = hist + (int64_t)blockIdx.x * nblocks;
+    const int per = (nblocks + 255) / 256;
+    const int lo = tid * per, hi = min(nblocks, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += row[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int i = lo; i < hi; ++i) {
+        const int c = row[i];
+        row[i] = run;
+        run += c;
+    }
+    if (tid == 255) totals[blockIdx.x] = part[255];
+}
+__global__ void __launch_bounds__(256) sort_addbase_kernel(int32_t *__restrict__ hist, int nblocks, const int32_t *__restrict__ totals) {
+    __shared__ int sbase;
+    if (threadIdx.x < 64) {
+        int s = 0;
+        for (int d = threadIdx.x; d < (int)blockIdx.x; d += 64) s += totals[d];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (threadIdx.x == 0) sbase = s;
+    }
+    __syncthreads();
+    const int base = sbase;
+    int32_t *row = hist + (int64_t)blockIdx.x * nblocks;
+    for (int i = threadIdx.x; i < nblocks; i += 256) row[i] += base;
+}
+
+__global__ void __launch_bounds__(64) sort_scatter_kernel(const int64_t *__restrict__ ids, const int32_t *__restrict__ pos_in, int64_t n,
+                                                          int n_rows, int shift, int nblocks, const int32_t *__restrict__ offs,
+                                                          int32_t *__restrict__ pos_out) {
+    __shared__ int base[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += 64) base[d] = offs[(int64_t)d * nblocks + blockIdx.x];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int64_t i0 = (int64_t)blockIdx.x * SORT_CHUNK;
+    for (int g = 0; g < SORT_CHUNK; g += 64) {
+        const int64_t i = i0 + g + lane;
+        const bool live = i < n;
+        const unsigned digit = live ? ((sort_key(ids, pos_in, i, n_rows) >> shift) & 255u) : 256u;      // 256: matches nobody live
+        // lanes with the same digit: eight ballots (one per bit), then the dead-lane bit
+        unsigned long long same = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((digit >> b) & 1u);
+            same &= ((digit >> b) & 1u) ? m : ~m;
+        }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int rank = __popcll(same & lt), count = __popcll(same);
+        int b0 = 0;
+        if (live) b0 = base[digit];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (live) {
+            pos_out[b0 + rank] = pos_in ? pos_in[i] : (int32_t)i;
+            if (rank == count - 1) base[digit] = b0 + count;        // the group's last lane moves its digit's cursor
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+static int sort_passes(int n_rows) {
+    int bits = 1;
+    while ((1ll << bits) < n_rows) ++bits;
+    return (bits + 7) / 8;
+}
+extern "C" int64_t b4c_sort_ids_workspace_bytes(int64_t n, int n_rows) {
+    if (n <= 0) return 0;
+    const int64_t nblocks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
+    return (256 * nblocks + 256 + n) * 4;           // histogram + digit totals + one ping-pong position array
+}
+
+extern "C" int b4c_sort_ids(const int64_t *ids, int64_t n, int n_rows, int32_t *order, void *workspace, int64_t workspace_bytes,
+                            void *stream) {
+    B4C_REQUIRE(n >= 0 && n_rows > 0 && n < (1ll << 31), "sort_ids: n=%lld n_rows=%d", (long long)n, n_rows);
+    if (n == 0) return B4C_OK;
+    B4C_REQUIRE(ids && order && workspace && workspace_bytes >= b4c_sort_ids_workspace_bytes(n, n_rows) && (((uintptr_t)workspace) & 3) == 0,
+                "sort_ids: null pointer / workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblocks = (int)((n + SORT_CHUNK - 1) / SORT_CHUNK);
+    int32_t *hist = (int32_t *)workspace;
+    int32_t *totals = hist + 256 * (int64_t)nblocks;
+    int32_t *tmp = totals + 256;
+    const int passes = sort_passes(n_rows);
+    // the last pass must land in `order`: with an even number of passes the first goes to tmp
+    int32_t *dst = (passes % 2) ? order : tmp;
+    const int32_t *src = nullptr;                    // pass 0 reads positions 0..n-1 implicitly
+    for (int p = 0; p < passes; ++p) {
+        sort_hist_kernel<<<nblocks, 64, 0, st>>>(ids, src, n, n_rows, 8 * p, nblocks, hist);
+        sort_rowscan_kernel<<<256, 256, 0, st>>>(hist, nblocks, totals);
+        sort_addbase_kernel<<<256, 256, 0, st>>>(hist, nblocks, totals);
+        sort_scatter_kernel<<<nblocks, 64, 0, st>>>(ids, src, n, n_rows, 8 * p, nblocks, hist, dst);
+        src = dst;
+        dst = (dst == order) ? tmp : order;
+    }
+    return b4c_check_launch("sort_ids");
+}

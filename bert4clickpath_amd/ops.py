@@ -204,16 +204,35 @@ def embed_concat_pe_fwd(ids_list, tables, pe, scale, rate, seed, dtype, packed=N
     return out, key_pad
 
 
+library_sort = True      # b4c_sort_ids (6 - 9 launches) instead of torch.sort (14 launches through rocPRIM)
+_sort_ws = {}
+
+
 def _sort_order(ids, n_rows):
     """Token indices sorted by id (int32).  Radix-sort cost grows with the key width, and ids are row indices of a
     table: 16-bit keys for tables of up to 65,536 rows (biased into int16), else 32-bit (63 / 178 / 224 us for 16 / 32 / 64
     bits at 819,200 tokens).  Out-of-range ids are clamped exactly as the kernels clamp them."""
+    if library_sort and ids.is_cuda:
+        flat = ids.reshape(-1)
+        if flat.dtype != torch.int64 or not flat.is_contiguous():
+            flat = flat.to(torch.int64).contiguous()
+        n = flat.shape[0]
+        order = torch.empty(n, dtype=torch.int32, device=ids.device)
+        if n == 0:
+            return order
+        need = L.lib().b4c_sort_ids_workspace_bytes(n, n_rows)
+        ws = _sort_ws.get(ids.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=ids.device)
+            _sort_ws[ids.device] = ws
+        L.check(L.lib().b4c_sort_ids(_p(flat), n, n_rows, _p(order), ws.data_ptr(), ws.numel(), _st()), 'sort_ids')
+        return order
     flat = ids.view(-1).clamp(0, n_rows - 1)
     if n_rows <= 65536:
         keys = (flat - 32768).to(torch.int16)
     else:
         keys = flat.to(torch.int32)
-    return torch.sort(keys)[1].to(torch.int32)
+    return torch.sort(keys, stable=True)[1].to(torch.int32)
 
 
 sorted_embed_bwd = True     # sort the tokens of every feature by id (one radix sort per call) and sum runs in registers

@@ -417,6 +417,11 @@ int b4c_attn_bwd_varlen(const void *qkv, int ld_qkv, const uint8_t *key_pad, con
  *   key_pad [T] (1 = padded key, may be NULL); lse [R][H] (natural log of the row's softmax denominator).
  * b4c_attn_mq_bwd writes dq for the R query rows and dk | dv for EVERY token row (zeros where no query reads them).
  * dh in {32, 64}; max_len = longest sequence (LDS sizing). */
+/* order[i] = position (0..n-1) of the i-th smallest id, ties in position order (a stable sort of the token positions by
+ * table row: the order b4c_embed_concat_pe_bwd_sorted walks); ids are clamped to [0, n_rows - 1] as the embedding kernels
+ * clamp them.  LSD radix, 8-bit digits, 4 launches per pass; workspace >= b4c_sort_ids_workspace_bytes(n, n_rows), 4-B aligned. */
+int64_t b4c_sort_ids_workspace_bytes(int64_t n, int n_rows);
+int b4c_sort_ids(const int64_t *ids, int64_t n, int n_rows, int32_t *order, void *workspace, int64_t workspace_bytes, void *stream);
 int b4c_rows_add(void *dst, int ld_dst, const int32_t *idx, const void *src, int ld_src, int64_t n_src, int width, int dtype,
                  int src_dtype, void *stream);   /* dst[idx[r]] += src[r] (idx distinct, < 0 skipped; src may be fp32 beside a
                                                   * bf16 dst): the query rows' gradient joins that of all token rows */

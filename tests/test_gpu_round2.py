@@ -795,3 +795,25 @@ def test_loss_bookkeeping_kernels():
         act = torch.randn(64, 24, generator=g).to(dt).cuda()
         act[0, :5] = 0.0
         assert torch.equal(ops.relu_gate(x, act), torch.where(act > 0, x, torch.zeros_like(x)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,n_rows', [(1, 10), (1000, 7), (70000, 50011), (456789, 50011), (30000, 2000011), (4096, 256), (5000, 65536)])
+def test_library_sort_is_the_stable_argsort(n, n_rows):
+    """b4c_sort_ids (LSD radix, 1 - 3 passes of 8 bits) against torch's stable argsort of the clamped ids: identical
+    permutations, Zipf-skewed and out-of-range ids included."""
+    from bert4clickpath_amd import ops
+    g = torch.Generator().manual_seed(n + n_rows)
+    u = torch.rand(n, generator=g)
+    ids = (torch.exp(u * np.log(n_rows + 1.0)) - 1).long()            # log-uniform: a few very hot rows
+    ids[::97] = -5
+    ids[1::101] = n_rows + 3
+    idc = ids.cuda()
+    prev = ops.library_sort
+    try:
+        ops.library_sort = True
+        got = ops._sort_order(idc, n_rows)
+    finally:
+        ops.library_sort = prev
+    want = torch.sort(idc.clamp(0, n_rows - 1), stable=True)[1].to(torch.int32)
+    assert torch.equal(got, want)
