@@ -29,6 +29,8 @@ def _is_string_feature(x):
 class TransformerInputPrep:
     """[CLS] [SEP] seq_1 [SEP] seq_2 [SEP] ... per chained feature (reference :8-103)."""
 
+    _special_cols = {}
+
     def __init__(self, seq_chain_mapping):
         self.seq_chain_mapping = seq_chain_mapping
 
@@ -46,8 +48,15 @@ class TransformerInputPrep:
             return np.concatenate(parts, axis=1)
         seqs = [torch.as_tensor(s) for s in sequences]
         B = seqs[0].shape[0]
-        cls = torch.full((B, 1), CLS, dtype=seqs[0].dtype, device=seqs[0].device)
-        sep = torch.full((B, 1), SEP, dtype=seqs[0].dtype, device=seqs[0].device)
+        key = (B, seqs[0].dtype, seqs[0].device)
+        cols = TransformerInputPrep._special_cols.get(key)
+        if cols is None:            # the [CLS] / [SEP] columns of a batch size are constants: built once, not every step
+            if len(TransformerInputPrep._special_cols) > 64:
+                TransformerInputPrep._special_cols.clear()
+            cols = (torch.full((B, 1), CLS, dtype=seqs[0].dtype, device=seqs[0].device),
+                    torch.full((B, 1), SEP, dtype=seqs[0].dtype, device=seqs[0].device))
+            TransformerInputPrep._special_cols[key] = cols
+        cls, sep = cols
         parts = [cls, sep]
         for s in seqs:
             parts += [s, sep]

@@ -972,3 +972,16 @@ extern "C" int b4c_sort_ids(const int64_t *ids, int64_t n, int n_rows, int32_t *
     }
     return b4c_check_launch("sort_ids");
 }
+
+// out[i] = src[idx[i]] (int64 values, int32 indices): the ids of the packed tokens for the embedding backward
+__global__ void __launch_bounds__(256) gather_i64_kernel(const int64_t *__restrict__ src, const int32_t *__restrict__ idx,
+                                                         int64_t *__restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = src[idx[i]];
+}
+
+extern "C" int b4c_gather_i64(const int64_t *src, const int32_t *idx, int64_t *out, int64_t n, void *stream) {
+    B4C_REQUIRE(n >= 0 && (n == 0 || (src && idx && out)), "gather_i64: bad argument");
+    if (n == 0) return B4C_OK;
+    gather_i64_kernel<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(src, idx, out, n);
+    return b4c_check_launch("gather_i64");
+}

@@ -995,8 +995,15 @@ class EmbedFn(torch.autograd.Function):
         out, key_pad = embed_concat_pe_fwd(ids, [t.detach() for t in tables], pe, scale, rate, seed, dtype, packed)
         if packed is not None:
             # backward works on the packed ids (one gather per feature): B = 1, S = T rows
-            src = packed.tok_src[:packed.T].long()
-            ids = [i.reshape(-1)[src].reshape(1, -1).contiguous() for i in ids]
+            pk_ids = []
+            for i in ids:
+                flat = i.reshape(-1)
+                if flat.dtype != torch.int64 or not flat.is_contiguous():
+                    flat = flat.to(torch.int64).contiguous()
+                o = torch.empty(1, packed.T, dtype=torch.int64, device=flat.device)
+                L.check(L.lib().b4c_gather_i64(_p(flat), _p(packed.tok_src), _p(o), packed.T, _st()), 'gather_i64')
+                pk_ids.append(o)
+            ids = pk_ids
         ctx.save_for_backward(*ids, *tables)
         ctx.n, ctx.scale, ctx.rate, ctx.seed = n, scale, rate, seed
         ctx.mark_non_differentiable(key_pad)

@@ -422,6 +422,7 @@ int b4c_attn_bwd_varlen(const void *qkv, int ld_qkv, const uint8_t *key_pad, con
  * clamp them.  LSD radix, 8-bit digits, 4 launches per pass; workspace >= b4c_sort_ids_workspace_bytes(n, n_rows), 4-B aligned. */
 int64_t b4c_sort_ids_workspace_bytes(int64_t n, int n_rows);
 int b4c_sort_ids(const int64_t *ids, int64_t n, int n_rows, int32_t *order, void *workspace, int64_t workspace_bytes, void *stream);
+int b4c_gather_i64(const int64_t *src, const int32_t *idx, int64_t *out, int64_t n, void *stream);   /* out[i] = src[idx[i]] */
 int b4c_rows_add(void *dst, int ld_dst, const int32_t *idx, const void *src, int ld_src, int64_t n_src, int width, int dtype,
                  int src_dtype, void *stream);   /* dst[idx[r]] += src[r] (idx distinct, < 0 skipped; src may be fp32 beside a
                                                   * bf16 dst): the query rows' gradient joins that of all token rows */
