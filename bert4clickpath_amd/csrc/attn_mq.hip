@@ -107,7 +107,6 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_fwd_kernel(const T *__rest
         }
         __syncthreads();
         // phase 1: scores of every key against the chunk's queries (two threads per key, their half dots meet by a shuffle)
-        const float rs = 1.0f / sqrt_dk;
         for (int k0 = 0; k0 < S; k0 += MQ_KB) {
             const int j = k0 + kl;
             float kr[HD];
@@ -133,7 +132,6 @@ __global__ void __launch_bounds__(MQ_THREADS) attn_mq_fwd_kernel(const T *__rest
                 }
             }
         }
-        (void)rs;
         __syncthreads();
         // softmax over the keys: query m of the chunk belongs to wave m % 4
         for (int m = wave; m < mq; m += 4) {
