@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--n_batches', type=int, default=8, help='distinct resident batches cycled through')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_rows', type=int, default=256, help='sequences in the bounded CPU-baseline sample (SURVEY 8d: B=256)')
+    ap.add_argument('--cpu_seconds', type=float, default=15.0, help='wall-clock bound of the CPU-baseline sample')
     ap.add_argument('--eval_steps', type=int, default=6, help='timed scoring batches (0 = skip the scoring leg)')
     ap.add_argument('--full_steps', type=int, default=8, help='extra steps, after the timed region, of the step that computes every position of every '
                     'layer (padded layout, full last layer) for the every_position_of_every_layer entry; 0 = skip')
@@ -165,7 +166,7 @@ def cpu_baseline(a):
                 tr.adam_step(P[k], P[k].grad, m[k], vv[k], t)
     step(1)
     t0, n = time.perf_counter(), 0
-    while (time.perf_counter() - t0 < 15.0 and n < 50) or n < 2:
+    while (time.perf_counter() - t0 < a.cpu_seconds and n < 50) or n < 2:
         step(n + 2)
         n += 1
     dt = (time.perf_counter() - t0) / max(n, 1)
