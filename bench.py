@@ -101,14 +101,20 @@ def build_model(a, device):
 
 
 def backward_order(model):
-    """Arena order = the order gradients appear in backward: head, encoder layers last -> first, embedding."""
+    """Arena order = the order gradients COMPLETE in backward: head trunk, encoder layers last -> first, embedding -- and
+    the vocabulary projection with the embedding when its dW sweep runs as a background job beside the encoder backward
+    (ops.overlap_vocab_dw: it is announced when backward ends), so that the buckets before it go out as they complete."""
+    from bert4clickpath_amd import ops
     names = {id(p): n for n, p in model.named_parameters()}
     L = model.num_encoder_layers
+    late = ('head.output_layer.',) if (ops.overlap_vocab_dw and ops.flash_ce) else ()
 
     def key(p):
         n = names[id(p)]
         if n == 'head.output_embedding':       # the sampled head's vocabulary-major projection: row-sparse gradient, kept
             return (L + 3, n)                  # at the very end of the arena next to the embedding tables (parallel.py)
+        if n.startswith(late) and late:
+            return (L + 2, '~' + n)            # after the embedding tables, in their bucket
         if n.startswith('head.'):
             return (0, n)
         if 'enc_layers.' in n:
@@ -275,8 +281,10 @@ def main():
     model = build_model(a, device)
     opt = optim.Adam(model.parameters(), order=backward_order(model))
     arena = opt.arena
-    head_end = max(arena.slice_of(p)[1] for n, p in model.named_parameters() if n.startswith('head.') and n != 'head.output_embedding')
     emb_start = min(arena.slice_of(p)[0] for n, p in model.named_parameters() if 'embedding_layers' in n)
+    # (head parameters placed behind the tables -- the projection under ops.overlap_vocab_dw -- belong to the last bucket)
+    head_end = max(arena.slice_of(p)[1] for n, p in model.named_parameters()
+                   if n.startswith('head.') and n != 'head.output_embedding' and arena.slice_of(p)[0] < emb_start)
     tables = [p for n, p in model.named_parameters() if 'embedding_layers' in n]
     # config 5: the 2M-row tables' gradients travel as (indices, rows) instead of a 2 GB dense all-reduce
     sparse = (tables + [model.head.output_embedding]) if (a.sampled and world > 1) else []

@@ -26,6 +26,7 @@
 // over its rows in the order 16 s + 8 (j>>2) + 4 hf + (j&3); the A operand reads the same order through
 // ds_read_b64_tr_b16.
 #include <math.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -78,12 +79,13 @@ template <int KD> struct VTile {
     static __device__ __forceinline__ int chunk_off(int row, int chunk) { return row * STR + ((chunk ^ swz(row)) << 4); }
     // rows [row0, row0 + 128) of P (row pitch ld elements) -> LDS tile at `dst`; rows >= nrows arrive as zeros.
     // Completion is on the VM counter: s_waitcnt vmcnt(0) + a barrier before any wave reads the tile.
+    template <int NT = 512>
     static __device__ __forceinline__ void dma(const bf16_t *__restrict__ P, int ld, int64_t row0, int64_t nrows, char *dst, int tid) {
         const int64_t left = nrows - row0;
         const __amdgpu_buffer_rsrc_t rs = vce_rsrc(P + row0 * ld, left < 128 ? left : 128, (int64_t)ld * 2);
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int c = tid + i * 512, row = c / CH, slot = c % CH;
+        for (int i = 0; i < NIT * 512 / NT; ++i) {
+            const int c = tid + i * NT, row = c / CH, slot = c % CH;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst + ((c & ~63) << 4)), 16,
                                                      (row * ld + ((slot ^ swz(row)) << 3)) * 2, 0, 0, 0);
         }
@@ -481,20 +483,35 @@ struct VceDwArgs {
     int ld_h, ld_w, ldw;
     int64_t R;
     int V, tsplit;
+    int vt0, nvt;        // the vocabulary tiles [vt0, vt0 + nvt) this launch sweeps
 };
 
-template <int KD>
-__global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
+template <int KD, int TH>
+__global__ void __launch_bounds__(256 * TH, 2) vce_dw_kernel(VceDwArgs a) {
+    // TH = 2: 8 waves = 4 vocabulary groups x the 2 token halves of each 128-token h tile, one (vocabulary tile, token
+    // split) unit per workgroup.  TH = 1: 4 waves, one per SIMD, each taking all four 32-token sub-tiles; the grid is at
+    // most one workgroup per CU and walks the units -- half of every SIMD's registers and issue slots stay free for the
+    // HBM-bound kernels of the encoder backward that run beside it on the main stream (ops.overlap_vocab_dw).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NKS = KD / 16, NDT = KD / 32, STR = VTile<KD>::STR;
     constexpr int TILE_B = VTile<KD>::BYTES;
+    constexpr int NT = 256 * TH, RTN = 4 / TH;                        // threads; 32-token sub-tiles per wave and h tile
     f32x4 *sRow = reinterpret_cast<f32x4 *>(smem + 2 * TILE_B);      // [2][128]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int nvt = a.nvt;
+    const int nunits = nvt * a.tsplit;
+    int unit = blockIdx.x;
+    do {          // TH = 2: one unit per workgroup, no loop
+    // (lane coordinates re-derived per unit behind an opaque zero: hoisted, the per-lane LDS offsets of every access
+    // pattern stay live across the loop and the kernel spills)
+    int opaque0 = 0;
+    if (TH == 1) asm volatile("s_mov_b32 %0, 0" : "=s"(opaque0));
+    const int tid = threadIdx.x + opaque0, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int li = lane & 15, g = lane >> 4;
     const int vg = wave & 3, th = wave >> 2;
-    const int v = blockIdx.x * 128 + vg * 32 + r;          // the lane's vocabulary id
+    const int vt = a.vt0 + unit % nvt, ts = unit / nvt;
+    const int v = vt * 128 + vg * 32 + r;          // the lane's vocabulary id
     const int64_t ntt = (a.R + 127) >> 7;
-    const int64_t tt0 = ntt * blockIdx.y / a.tsplit, tt1 = ntt * (blockIdx.y + 1) / a.tsplit;
+    const int64_t tt0 = ntt * ts / a.tsplit, tt1 = ntt * (ts + 1) / a.tsplit;
 
     bf16x8 wfr[NKS];
 #pragma unroll
@@ -506,17 +523,17 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
     const float bv = (v < a.V) ? (a.bias ? a.bias[v] : 0.f) : -INFINITY;
     int foff[NKS], toff[NDT][2];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) foff[ks] = VTile<KD>::frag_off(r, ks, hf) + th * 64 * STR;
+    for (int ks = 0; ks < NKS; ++ks) foff[ks] = VTile<KD>::frag_off(r, ks, hf) + th * (RTN * 32) * STR;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-        toff[dt][0] = VTile<KD>::tr_off(hf, li, g, dt, 0) + th * 64 * STR;
-        toff[dt][1] = VTile<KD>::tr_off(hf, li, g, dt, 1) + th * 64 * STR;
+        toff[dt][0] = VTile<KD>::tr_off(hf, li, g, dt, 0) + th * (RTN * 32) * STR;
+        toff[dt][1] = VTile<KD>::tr_off(hf, li, g, dt, 1) + th * (RTN * 32) * STR;
     }
-    const int roff = (th * 64 + 4 * hf) * 16;       // the lane's first row-scalar entry (bytes)
+    const int roff = (th * (RTN * 32) + 4 * hf) * 16;       // the lane's first row-scalar entry (bytes)
 
     f32x4 rreg = {INFINITY, 0.f, 0.f, -INFINITY};
     auto fetch = [&](int64_t tt, int buf) {
-        VTile<KD>::dma(a.h, a.ld_h, tt * 128, tt < tt1 ? a.R : 0, smem + buf * TILE_B, tid);
+        VTile<KD>::template dma<NT>(a.h, a.ld_h, tt * 128, tt < tt1 ? a.R : 0, smem + buf * TILE_B, tid);
         if (tid < 128) {
             const int64_t row = tt * 128 + tid;
             rreg = (tt < tt1 && row < a.R) ? *reinterpret_cast<const f32x4 *>(a.rowscal + row * 8) : (f32x4){INFINITY, 0.f, 0.f, -INFINITY};
@@ -542,9 +559,10 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
         fetch(tt + 1, buf ^ 1);        // the other buffer was last read one tile ago (behind the previous barrier)
         // row scalars {lse2, c = a - b, nb = -b, lo}: lo > 0 marks a row whose probabilities leave the clip range
         // [lo, 1 - lo] (the upper bound follows from the lower one: rows that stay inside carry lo = -inf)
-        const bool any_clip = __any(rs[th * 64 + lane][3] > 0.f);     // the wave's 64 token rows
+        const bool any_clip = TH == 2 ? __any(rs[th * 64 + lane][3] > 0.f)      // the wave's token rows
+                                      : __any(rs[lane][3] > 0.f || rs[64 + lane][3] > 0.f);
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RTN; ++rt) {
             __builtin_amdgcn_sched_barrier(0);       // keep one 32-token tile's temporaries live at a time
             f32x16 acc;
 #pragma unroll
@@ -593,35 +611,53 @@ __global__ void __launch_bounds__(512) vce_dw_kernel(VceDwArgs a) {
         if (tt + 1 < tt1) tile(std::integral_constant<int, 1>{}, tt + 1);
     }
     __syncthreads();
-    // the two token halves are summed through LDS; [d][32 vocab] per vocabulary group
-    float *sD = reinterpret_cast<float *>(smem) + vg * (KD * 32 + 32);
     dbv += __shfl_xor(dbv, 32);
-    if (th == 1) {
+    const bool direct = a.tsplit == 1;
+    if (TH == 2) {
+        // the two token halves are summed through LDS; [d][32 vocab] per vocabulary group
+        float *sD = reinterpret_cast<float *>(smem) + vg * (KD * 32 + 32);
+        if (th == 1) {
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
+            for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) sD[(dt * 32 + vce_rowmap(t, hf)) * 32 + r] = dW[dt][t];
-        if (hf == 0) sD[KD * 32 + r] = dbv;
-    }
-    __syncthreads();
-    if (th == 0 && v < a.V) {
-        const bool direct = a.tsplit == 1;
+                for (int t = 0; t < 16; ++t) sD[(dt * 32 + vce_rowmap(t, hf)) * 32 + r] = dW[dt][t];
+            if (hf == 0) sD[KD * 32 + r] = dbv;
+        }
+        __syncthreads();
+        if (th == 0 && v < a.V) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int d = dt * 32 + vce_rowmap(t, hf);
+                    const float val = dW[dt][t] + sD[d * 32 + r];
+                    float *p = a.dW + (int64_t)d * a.ldw + v;
+                    if (direct) *p += val;
+                    else atomicAdd(p, val);
+                }
+            if (hf == 0 && a.db) {
+                const float val = dbv + sD[KD * 32 + r];
+                if (direct) a.db[v] += val;
+                else atomicAdd(a.db + v, val);
+            }
+        }
+    } else if (v < a.V) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const int d = dt * 32 + vce_rowmap(t, hf);
-                const float val = dW[dt][t] + sD[d * 32 + r];
-                float *p = a.dW + (int64_t)d * a.ldw + v;
-                if (direct) *p += val;
-                else atomicAdd(p, val);
+                float *p = a.dW + (int64_t)(dt * 32 + vce_rowmap(t, hf)) * a.ldw + v;
+                if (direct) *p += dW[dt][t];
+                else atomicAdd(p, dW[dt][t]);
             }
         if (hf == 0 && a.db) {
-            const float val = dbv + sD[KD * 32 + r];
-            if (direct) a.db[v] += val;
-            else atomicAdd(a.db + v, val);
+            if (direct) a.db[v] += dbv;
+            else atomicAdd(a.db + v, dbv);
         }
     }
+    if (TH == 1) __syncthreads();        // the next unit's tiles land in the images this one read
+    unit += gridDim.x;
+    } while (TH == 1 && unit < nunits);
 }
 
 // K5: the [j = y] term of dlogit: dW[:, y] -= yd h_row, db[y] -= yd.  dW is [K][V] (a label touches a column),
@@ -824,33 +860,92 @@ extern "C" int b4c_vocab_lse(const void *h, int ld_h, const void *wt, int ld_w, 
 }
 
 template <int KD>
-static int vce_dw_launch(VceDwArgs a, const int32_t *labels, float *tmp, hipStream_t st) {
-    const int nvt = (a.V + 127) / 128;
+static void vce_dw_sweep_launch(VceDwArgs a, int vt0, int nvt, int background_wgs, hipStream_t st) {
     const int64_t ntt = ceil_div64(a.R, 128);
-    a.tsplit = vce_pick_split(nvt, ntt, 0.025);
     const size_t lds = vce_dw_lds<KD>();
     static thread_local bool done = false;
-    if (!done) { vce_allow_lds(vce_dw_kernel<KD>, lds); done = true; }
-    vce_dw_kernel<KD><<<dim3((unsigned)nvt, (unsigned)a.tsplit), 512, lds, st>>>(a);
+    if (!done) { vce_allow_lds(vce_dw_kernel<KD, 2>, lds); vce_allow_lds(vce_dw_kernel<KD, 1>, lds); done = true; }
+    a.vt0 = vt0; a.nvt = nvt;
+    if (background_wgs > 0) {
+        // beside other kernels: at most background_wgs workgroups of 4 waves (one per SIMD), whole rounds of units
+        // the token split that fills whole rounds best (units / (rounds x workgroups)); at least two rounds when the
+        // tokens allow it, fewer splits (fewer dW atomics) among near-equals
+        int ts = 1;
+        double best = -1.0;
+        for (int t = 1; t <= 16 && t <= ntt; ++t) {
+            const int64_t units = (int64_t)nvt * t, rounds = ceil_div64(units, background_wgs);
+            const double fill = (double)units / (double)(rounds * background_wgs) - (rounds < 2 ? 0.5 : 0.0);
+            if (fill > best + 0.02) { best = fill; ts = t; }
+        }
+        a.tsplit = ts;
+        const int64_t units = (int64_t)nvt * ts, rounds = ceil_div64(units, background_wgs);
+        vce_dw_kernel<KD, 1><<<(unsigned)ceil_div64(units, rounds), 256, lds, st>>>(a);
+    } else {
+        a.tsplit = vce_pick_split(nvt, ntt, 0.025);
+        vce_dw_kernel<KD, 2><<<(unsigned)(nvt * a.tsplit), 512, lds, st>>>(a);
+    }
+}
+template <int KD>
+static void vce_dw_label_launch(VceDwArgs a, const int32_t *labels, float *tmp, hipStream_t st) {
     (void)hipMemsetAsync(tmp, 0, (size_t)a.V * KD * 4, st);
     vce_label_kernel<KD><<<(unsigned)ceil_div64(a.R, VCE_LABEL_ROWS), 256, 0, st>>>(a, labels, tmp);
     vce_label_add_kernel<KD><<<dim3((unsigned)((a.V + 31) / 32), KD / 32), 256, 0, st>>>(a.dW, a.ldw, tmp, a.V);
-    return b4c_check_launch("vocab_ce_dw");
+}
+
+static int vce_dw_check(const void *h, int ld_h, const void *wt, int ld_w, const float *rowscal, float *dW, int ldw, int64_t R, int V,
+                        int K, const char *who) {
+    B4C_REQUIRE(h && wt && rowscal && dW, "%s: null pointer", who);
+    B4C_REQUIRE(vce_shape_ok(K), "%s: K=%d unsupported (64 or 128)", who, K);
+    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K && ldw >= V, "%s: shape", who);
+    B4C_REQUIRE(ld_h % 8 == 0 && ld_w % 8 == 0 && ((((uintptr_t)h | (uintptr_t)wt | (uintptr_t)rowscal) & 15) == 0),
+                "%s: operands must be 16-byte aligned with pitches %% 8 == 0", who);
+    return B4C_OK;
+}
+static VceDwArgs vce_dw_args(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const float *rowscal, float *dW,
+                             int ldw, float *db, int64_t R, int V) {
+    VceDwArgs a = {};
+    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.rowscal = rowscal; a.dW = dW; a.db = db;
+    a.ld_h = ld_h; a.ld_w = ld_w; a.ldw = ldw; a.R = R; a.V = V;
+    return a;
 }
 
 extern "C" int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
                                const float *rowscal, float *dW, int ldw, float *db, void *workspace, int64_t workspace_bytes,
                                int64_t R, int V, int K, void *stream) {
-    B4C_REQUIRE(h && wt && labels && rowscal && dW && workspace, "vocab_ce_dw: null pointer");
+    if (int rc = vce_dw_check(h, ld_h, wt, ld_w, rowscal, dW, ldw, R, V, K, "vocab_ce_dw")) return rc;
+    B4C_REQUIRE(labels && workspace, "vocab_ce_dw: null pointer");
     B4C_REQUIRE(workspace_bytes >= (int64_t)V * K * 4, "vocab_ce_dw: workspace too small");
-    B4C_REQUIRE(vce_shape_ok(K), "vocab_ce_dw: K=%d unsupported (64 or 128)", K);
-    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K && ldw >= V, "vocab_ce_dw: shape");
-    B4C_REQUIRE(ld_h % 8 == 0 && ld_w % 8 == 0 && ((((uintptr_t)h | (uintptr_t)wt | (uintptr_t)rowscal) & 15) == 0),
-                "vocab_ce_dw: operands must be 16-byte aligned with pitches % 8 == 0");
     if (R == 0) return B4C_OK;
-    VceDwArgs a = {};
-    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.rowscal = rowscal; a.dW = dW; a.db = db;
-    a.ld_h = ld_h; a.ld_w = ld_w; a.ldw = ldw; a.R = R; a.V = V;
-    return K == 128 ? vce_dw_launch<128>(a, labels, (float *)workspace, (hipStream_t)stream)
-                    : vce_dw_launch<64>(a, labels, (float *)workspace, (hipStream_t)stream);
+    const VceDwArgs a = vce_dw_args(h, ld_h, wt, ld_w, bias, rowscal, dW, ldw, db, R, V);
+    const int nvt = (V + 127) / 128;
+    if (K == 128) { vce_dw_sweep_launch<128>(a, 0, nvt, 0, (hipStream_t)stream); vce_dw_label_launch<128>(a, labels, (float *)workspace, (hipStream_t)stream); }
+    else { vce_dw_sweep_launch<64>(a, 0, nvt, 0, (hipStream_t)stream); vce_dw_label_launch<64>(a, labels, (float *)workspace, (hipStream_t)stream); }
+    return b4c_check_launch("vocab_ce_dw");
+}
+
+extern "C" int b4c_vocab_ce_dw_sweep(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const float *rowscal,
+                                     float *dW, int ldw, float *db, int64_t R, int V, int K, int tile_begin, int tile_end,
+                                     int background_workgroups, void *stream) {
+    if (int rc = vce_dw_check(h, ld_h, wt, ld_w, rowscal, dW, ldw, R, V, K, "vocab_ce_dw_sweep")) return rc;
+    const int nvt = (V + 127) / 128;
+    B4C_REQUIRE(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nvt, "vocab_ce_dw_sweep: tiles [%d, %d) of %d", tile_begin, tile_end, nvt);
+    B4C_REQUIRE(background_workgroups >= 0, "vocab_ce_dw_sweep: background_workgroups %d", background_workgroups);
+    if (R == 0 || tile_begin == tile_end) return B4C_OK;
+    const VceDwArgs a = vce_dw_args(h, ld_h, wt, ld_w, bias, rowscal, dW, ldw, db, R, V);
+    if (K == 128) vce_dw_sweep_launch<128>(a, tile_begin, tile_end - tile_begin, background_workgroups, (hipStream_t)stream);
+    else vce_dw_sweep_launch<64>(a, tile_begin, tile_end - tile_begin, background_workgroups, (hipStream_t)stream);
+    return b4c_check_launch("vocab_ce_dw_sweep");
+}
+
+extern "C" int b4c_vocab_ce_dw_labels(const void *h, int ld_h, const int32_t *labels, const float *rowscal, float *dW, int ldw,
+                                      float *db, void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, void *stream) {
+    B4C_REQUIRE(h && labels && rowscal && dW && workspace, "vocab_ce_dw_labels: null pointer");
+    B4C_REQUIRE(vce_shape_ok(K), "vocab_ce_dw_labels: K=%d unsupported (64 or 128)", K);
+    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ldw >= V, "vocab_ce_dw_labels: shape");
+    B4C_REQUIRE(workspace_bytes >= (int64_t)V * K * 4, "vocab_ce_dw_labels: workspace too small");
+    if (R == 0) return B4C_OK;
+    const VceDwArgs a = vce_dw_args(h, ld_h, nullptr, 0, nullptr, rowscal, dW, ldw, db, R, V);
+    if (K == 128) vce_dw_label_launch<128>(a, labels, (float *)workspace, (hipStream_t)stream);
+    else vce_dw_label_launch<64>(a, labels, (float *)workspace, (hipStream_t)stream);
+    return b4c_check_launch("vocab_ce_dw_labels");
 }

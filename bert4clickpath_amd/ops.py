@@ -509,6 +509,7 @@ def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, cu=None):
             L.check(L.lib().b4c_attn_bwd_varlen(_p(qkv), qkv.stride(0), _p(key_pad), _p(cu), _p(o), o.stride(0), _p(d_o),
                                                 d_o.stride(0), _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, _p(ws),
                                                 need, dt_code(qkv.dtype), _st()), 'attn_bwd_varlen')
+    _background_kick()      # the next piece of the vocabulary head's dW sweep starts when this kernel has left the CUs
     return dqkv
 
 
@@ -737,6 +738,28 @@ def vocab_ce_dw(h, wt, bias, labels_i32, rowscal, V, dW, db):
     with _record('vocab_ce_dw', R * K * 2 + V * K * 2 + V * K * 4, 4 * R * V * K):
         L.check(L.lib().b4c_vocab_ce_dw(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(rowscal),
                                         _p(dW), dW.stride(0), _p(db), ws.data_ptr(), ws.numel(), R, V, K, _st()), 'vocab_ce_dw')
+
+
+def vocab_ce_dw_sweep(h, wt, bias, rowscal, V, dW, db, tile_begin, tile_end, background_workgroups=0):
+    """the dlogit part of vocab_ce_dw for the 128-id vocabulary tiles [tile_begin, tile_end); background_workgroups > 0:
+    as a background kernel of at most that many one-wave-per-SIMD workgroups (runs beside another stream's kernels)"""
+    R, K = h.shape
+    if R == 0 or tile_end <= tile_begin:
+        return
+    frac = (tile_end - tile_begin) / float((V + 127) // 128)
+    with _record('vocab_ce_dw', int(frac * (R * K * 2 + V * K * 2 + V * K * 4)), int(frac * 4 * R * V * K)):
+        L.check(L.lib().b4c_vocab_ce_dw_sweep(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(rowscal), _p(dW), dW.stride(0),
+                                              _p(db), R, V, K, tile_begin, tile_end, background_workgroups, _st()), 'vocab_ce_dw_sweep')
+
+
+def vocab_ce_dw_labels(h, labels_i32, rowscal, V, dW, db):
+    """the label term of vocab_ce_dw (dW[:, y] -= yd h_row, db[y] -= yd)"""
+    R, K = h.shape
+    if R == 0:
+        return
+    ws = _vce_workspace(h, R, V, K)
+    L.check(L.lib().b4c_vocab_ce_dw_labels(_p(h), h.stride(0), _p(labels_i32), _p(rowscal), _p(dW), dW.stride(0), _p(db),
+                                           ws.data_ptr(), ws.numel(), R, V, K, _st()), 'vocab_ce_dw_labels')
 
 
 fused_softmax_proj = True      # Dense(V, softmax) of the bf16 path in one pass over (R x V): lse sweep + softmax epilogue
@@ -1385,13 +1408,28 @@ class MLPFn(torch.autograd.Function):
         return (dx, None, None, None) + tuple(grads)
 
 
-# Vocabulary-head weight gradient on a side stream, under the encoder backward.  OFF by default: measured 10.78 -> 10.71 ms
-# per step only (the sweep's waves hold 212 registers each, two per SIMD: nothing else fits beside them, so the two kernels
-# time-slice the CUs instead of sharing them; the sweep stretches from 1.38 to 1.76 ms), and with a reducer the head's
-# bucket would become ready last.  B4C_OVERLAP_DW=1 switches it on.
-overlap_vocab_dw = os.environ.get('B4C_OVERLAP_DW', '0') == '1'
+# Vocabulary-head weight gradient BESIDE the encoder backward.  The dW sweep is MFMA / VALU bound and leaves HBM idle;
+# the encoder backward is HBM bound and leaves the matrix pipes idle; nothing in backward consumes the sweep's result.
+# As a plain second-stream launch the two only time-slice the CUs (the sweep's 512-thread workgroups hold 2 x 212 registers
+# per SIMD: nothing else fits beside them; 10.78 -> 10.71 ms).  What shares the CUs is the BACKGROUND form of the sweep
+# (b4c_vocab_ce_dw_sweep, background_workgroups > 0): one wave per SIMD, at most one workgroup per CU, cut into pieces
+# that start in the windows BETWEEN the resident attention backward kernels -- those take a whole CU's LDS (146 KB) and
+# cannot start on a CU that holds a sweep workgroup.  A piece is launched on the side stream right after every attention
+# backward launch (ops.attn_bwd -> _background_kick); how many such launches a backward pass has is learned from the
+# previous pass.  The main stream joins, and the gradient is announced to a reducer, when backward ends (join_side_work).
+# B4C_OVERLAP_DW=0 switches it off (the sweep then runs in the foreground, first thing in backward).
+overlap_vocab_dw = os.environ.get('B4C_OVERLAP_DW', '1') == '1'
+background_workgroups = int(os.environ.get('B4C_VCE_DW_BG', '256'))
+# the windows' relative lengths: the first one (head trunk + the rows-only last layer + half a layer), one per layer, the last
+# one (half a layer + the embedding backward)
+background_weights = tuple(float(x) for x in os.environ.get('B4C_VCE_DW_WEIGHTS', '2.2,1.0,0.6').split(','))
 _side_streams = {}
 _side_pending = []          # (event recorded on the side stream, parameters whose gradient it completes)
+_bg_pieces = []             # closures, each launching one piece of the sweep (on whatever stream is current)
+_bg_done = None             # closure that ends the job: label term, event, pending entry
+_bg_counting = False        # between the head's backward and the end of the pass
+_bg_kicks = 0               # attention-backward launches seen since the job was queued
+_bg_kicks_expected = 0      # ... in the previous backward pass
 
 
 def _side_stream(device):
@@ -1402,14 +1440,88 @@ def _side_stream(device):
     return s
 
 
+def _background_plan(n_tiles, kicks):
+    """tile boundaries of the kicks + 1 pieces"""
+    w0, wm, wl = background_weights
+    w = [w0] + [wm] * max(kicks - 1, 0) + ([wl] if kicks > 0 else [])
+    tot, acc, cuts = sum(w), 0.0, [0]
+    for x in w[:-1]:
+        acc += x
+        cuts.append(min(n_tiles, int(round(n_tiles * acc / tot))))
+    return cuts + [n_tiles]
+
+
+def _background_kick():
+    global _bg_kicks
+    if not _bg_counting:
+        return
+    _bg_kicks += 1
+    if _bg_pieces:
+        piece = _bg_pieces.pop(0)
+        main = torch.cuda.current_stream()
+        side = _side_stream(main.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            piece()
+            if not _bg_pieces:
+                _background_finish()
+
+
+def _background_finish():
+    """label term + completion event, on the current (side) stream"""
+    global _bg_done
+    done, _bg_done = _bg_done, None
+    done()
+
+
 def join_side_work():
     """The current stream waits for everything issued on the side stream; the gradients that work produced are then
     announced (grad-ready callback).  Runs at the end of every backward pass that used the side stream (autograd engine
     callback); optimizers and reducers call it too -- it is a no-op when nothing is pending."""
+    global _bg_counting, _bg_kicks_expected
+    if _bg_counting:                # the pass is over: its number of attention launches is the plan of the next one
+        _bg_counting, _bg_kicks_expected = False, _bg_kicks
+    if _bg_done is not None:        # fewer attention launches than planned: what is left of the sweep goes out now
+        main = torch.cuda.current_stream()
+        side = _side_stream(main.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            while _bg_pieces:
+                _bg_pieces.pop(0)()
+            _background_finish()
     while _side_pending:
         ev, params = _side_pending.pop(0)
         torch.cuda.current_stream().wait_event(ev)
         _ready(*params)
+
+
+def _queue_background_dw(h, wt, b, labels_i32, rowscal, V, kernel, bias):
+    global _bg_done, _bg_kicks, _bg_counting
+    if _bg_counting:                # a second head in the same backward pass: finish the first one's sweep first
+        join_side_work()
+    main, side = torch.cuda.current_stream(h.device), _side_stream(h.device)
+    n_tiles = (V + 127) // 128
+    cuts = _background_plan(n_tiles, _bg_kicks_expected)
+    dW, db = kernel.grad, bias.grad
+
+    def piece(lo, hi):
+        return lambda: vocab_ce_dw_sweep(h, wt, b, rowscal, V, dW, db, lo, hi, background_workgroups)
+
+    def done():
+        vocab_ce_dw_labels(h, labels_i32, rowscal, V, dW, db)
+        ev = torch.cuda.current_stream().record_event()
+        _side_pending.append((ev, (kernel, bias)))
+    for t in (h, rowscal, labels_i32, wt, b, dW, db):
+        if t is not None:
+            t.record_stream(side)
+    _bg_pieces[:] = [piece(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
+    _bg_done, _bg_kicks, _bg_counting = done, 0, True
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        _bg_pieces.pop(0)()
+        if not _bg_pieces:
+            _background_finish()
+    torch.autograd.Variable._execution_engine.queue_callback(join_side_work)
 
 
 class VocabCEFn(torch.autograd.Function):
@@ -1453,18 +1565,7 @@ class VocabCEFn(torch.autograd.Function):
             return dh, None, None, None, None, None, dtab, db, None
         if _inplace_ok(kernel, bias):
             if overlap_vocab_dw and h.is_cuda:
-                # The dW sweep is MFMA / VALU bound and leaves HBM idle; nothing in backward consumes its result.  It goes
-                # out on a side stream and runs UNDER the HBM-bound encoder backward; the main stream joins (and the
-                # gradient is announced to the reducer) when the backward pass ends (join_side_work).
-                main, side = torch.cuda.current_stream(h.device), _side_stream(h.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel.grad, bias.grad)
-                    ev = side.record_event()
-                for t in (h, rowscal, labels_i32, wt, b):
-                    t.record_stream(side)
-                _side_pending.append((ev, (kernel, bias)))
-                torch.autograd.Variable._execution_engine.queue_callback(join_side_work)
+                _queue_background_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel, bias)
             else:
                 vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel.grad, bias.grad)
                 _ready(kernel, bias)

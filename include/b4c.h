@@ -251,6 +251,18 @@ int b4c_vocab_ce_fwd(const void *h, int ld_h, const void *wt, int ld_w, const fl
 int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
                     const float *rowscal, float *dW, int ldw, float *db, void *workspace, int64_t workspace_bytes,
                     int64_t R, int V, int K, void *stream);
+/* (ABI version 5) b4c_vocab_ce_dw in pieces, so that the sweep can run BESIDE the HBM-bound encoder backward:
+ * b4c_vocab_ce_dw_sweep adds the dlogit part of dW / db for the 128-id vocabulary tiles [tile_begin, tile_end) only
+ * (tiles own disjoint columns of dW: any partition of [0, ceil(V / 128)) over any number of calls gives the full sweep);
+ * background_workgroups > 0 launches it as a background kernel -- at most that many 256-thread workgroups (one wave per
+ * SIMD, 220 registers) that walk the units, leaving the rest of every CU's registers and issue slots to the kernels of
+ * another stream -- 0 launches the foreground form of b4c_vocab_ce_dw.  b4c_vocab_ce_dw_labels adds the label term
+ * (dW[:, y] -= yd h_row, db[y] -= yd) once; workspace >= V * K * 4 bytes.  Sweep + labels == b4c_vocab_ce_dw. */
+int b4c_vocab_ce_dw_sweep(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const float *rowscal,
+                          float *dW, int ldw, float *db, int64_t R, int V, int K, int tile_begin, int tile_end,
+                          int background_workgroups, void *stream);
+int b4c_vocab_ce_dw_labels(const void *h, int ld_h, const int32_t *labels, const float *rowscal, float *dW, int ldw,
+                           float *db, void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, void *stream);
 
 /* ---- (ABI version 4) R12 for scoring: Dense(V, softmax) (head.py:36) with ONE pass over the (R x V) tensor ------------------
  * replaces the materialised projection + softmax (b4c_gemm_nt + b4c_softmax_rows: write, read, write) of the

@@ -218,3 +218,48 @@ def test_masked_query_last_layer_without_any_mask():
         loss = model.cloze_loss({'asin': items}, labels, training=True)
         loss.backward()
         assert float(loss) == 0.0
+
+
+def test_background_dw_sweep_gives_the_foreground_gradients():
+    """ops.overlap_vocab_dw: the vocabulary head's dW sweep runs in pieces on a side stream beside the encoder backward
+    (a piece per attention-backward launch, the count learned from the previous pass).  Same kernels' arithmetic: the
+    gradients of three consecutive steps must match the foreground order (fp32 atomics order apart), with and without
+    attention launches in the pass, and the pass count must be learned."""
+    from bert4clickpath_amd import input_pipeline, ops, optim
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    V, B, S = 3000, 48, 40
+    batch = input_pipeline.synthetic_cloze_batch(B, S, V, seed=11, min_len=6)
+    items = torch.from_numpy(batch['ids'])[:, 2:S - 1].contiguous().cuda()
+    labels = torch.from_numpy(batch['labels_padded']).cuda()
+    n_real = int((batch['ids'] != 0).sum())
+    grads = {}
+    prev = (ops.overlap_vocab_dw, ops.background_workgroups)
+    try:
+        for layers in (3, 1):               # 1 layer + masked-query last layer: no resident attention backward at all
+            for mode in (False, True):
+                ops.overlap_vocab_dw, ops.background_workgroups = mode, 8
+                ops._bg_kicks_expected = 0
+                torch.manual_seed(0)
+                head = SoftMaxHead([64, 128], V)
+                m = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': 128}, head,
+                                           value_to_head='[MASK]', num_encoder_layers=layers, num_attention_heads=2, dropout_rate=0.0,
+                                           compute_dtype=torch.bfloat16).to('cuda')
+                opt = optim.Adam(m.parameters())
+                out = []
+                for step in range(3):
+                    opt.zero_grad()
+                    loss = m.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, n_real_tokens=n_real)
+                    loss.backward()
+                    ops.join_side_work()
+                    torch.cuda.synchronize()
+                    out.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
+                    if mode:
+                        assert ops._bg_done is None and not ops._bg_pieces and not ops._side_pending
+                        assert ops._bg_kicks_expected == (layers - 1 if ops.mq_last_layer else layers)
+                grads[(layers, mode)] = out
+            for step in range(3):
+                for n, g in grads[(layers, False)][step].items():
+                    gb = grads[(layers, True)][step][n]
+                    assert float((g - gb).abs().max()) <= 2e-5 * float(g.abs().max()) + 1e-9, (layers, step, n)
+    finally:
+        ops.overlap_vocab_dw, ops.background_workgroups = prev

@@ -131,3 +131,37 @@ def test_vocab_ce_rejects_bad_shapes(ops):
     with pytest.raises(L.B4CError):
         ops.vocab_ce_fwd(h, wt, torch.zeros(16, device=dev), torch.zeros(8, dtype=torch.int32, device=dev),
                          torch.ones(1, device=dev), 16, L.CE_TF)
+
+
+@pytest.mark.parametrize('R,V,K,scale,bg', [(700, 1000, 128, 1.6, 3), (300, 1301, 128, 0.3, 256), (333, 700, 64, 1.2, 7),
+                                            (5000, 2100, 128, 1.0, 16)])
+def test_vocab_ce_dw_in_pieces_equals_the_whole(ops, R, V, K, scale, bg):
+    """b4c_vocab_ce_dw_sweep over any partition of the vocabulary tiles (background form: persistent one-wave-per-SIMD
+    workgroups that walk several units each; foreground form) + b4c_vocab_ce_dw_labels == b4c_vocab_ce_dw.  Same
+    products and fp32 sums; only the order in which the token splits meet in dW differs (atomics), hence 1e-5."""
+    from bert4clickpath_amd import _lib as L
+    h, W, b, y = _case(R, V, K, scale, seed=R + V, n_ignored=4)
+    dev = 'cuda'
+    hd = torch.tensor(h, device=dev).bfloat16()
+    Vp = (V + 7) // 8 * 8
+    wt = torch.zeros(Vp, K, device=dev, dtype=torch.bfloat16)
+    wt[:V] = torch.tensor(W, device=dev).bfloat16()
+    bd = torch.zeros(Vp, device=dev)
+    bd[:V] = torch.tensor(b, device=dev)
+    yd = torch.tensor(y, device=dev)
+    gs = torch.tensor([1.0 / R], device=dev)
+    _, _, rowscal = ops.vocab_ce_fwd(hd, wt, bd, yd, gs, V, L.CE_TF)
+    dW0, db0 = torch.zeros(K, V, device=dev), torch.zeros(V, device=dev)
+    ops.vocab_ce_dw(hd, wt, bd, yd, rowscal, V, dW0, db0)
+    nt = (V + 127) // 128
+    cuts = sorted({0, 1, nt // 3, nt // 3, (2 * nt) // 3, nt})       # includes an empty piece when nt is small
+    for background in (bg, 0):
+        dW, db = torch.zeros(K, V, device=dev), torch.zeros(V, device=dev)
+        ops.vocab_ce_dw_labels(hd, yd, rowscal, V, dW, db)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            ops.vocab_ce_dw_sweep(hd, wt, bd, rowscal, V, dW, db, lo, hi, background)
+        scale_w, scale_b = float(dW0.abs().max()), float(db0.abs().max())
+        assert float((dW - dW0).abs().max()) <= 1e-5 * scale_w + 1e-9, background
+        assert float((db - db0).abs().max()) <= 1e-5 * scale_b + 1e-9, background
+    with pytest.raises(L.B4CError):
+        ops.vocab_ce_dw_sweep(hd, wt, bd, rowscal, V, dW, db, 0, nt + 1, 0)
