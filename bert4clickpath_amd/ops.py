@@ -747,7 +747,8 @@ def vocab_ce_dw_sweep(h, wt, bias, rowscal, V, dW, db, tile_begin, tile_end, bac
     if R == 0 or tile_end <= tile_begin:
         return
     frac = (tile_end - tile_begin) / float((V + 127) // 128)
-    with _record('vocab_ce_dw', int(frac * (R * K * 2 + V * K * 2 + V * K * 4)), int(frac * 4 * R * V * K)):
+    with _record('vocab_ce_dw_bg' if background_workgroups > 0 else 'vocab_ce_dw',
+                 int(frac * (R * K * 2 + V * K * 2 + V * K * 4)), int(frac * 4 * R * V * K)):
         L.check(L.lib().b4c_vocab_ce_dw_sweep(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(rowscal), _p(dW), dW.stride(0),
                                               _p(db), R, V, K, tile_begin, tile_end, background_workgroups, _st()), 'vocab_ce_dw_sweep')
 
