@@ -176,3 +176,18 @@ def test_row_pitch_of_vocabulary_wide_tensors():
     g = ops._rows_ok(t, torch.bfloat16)
     assert g.data_ptr() == t.data_ptr()                      # pitched rows are taken as they are
     assert ops._rows_ok(t.t()[:8].t(), torch.bfloat16).stride(1) == 1
+
+
+def test_background_plan_partitions_the_vocabulary_tiles():
+    """ops._background_plan: kicks + 1 pieces (one at the head's backward, one behind every attention backward launch of
+    the previous pass), contiguous, covering every 128-id tile exactly once, first piece the largest."""
+    from bert4clickpath_amd import ops
+    for n_tiles in (1, 2, 7, 391, 782, 15625):
+        for kicks in (0, 1, 3, 5, 11):
+            cuts = ops._background_plan(n_tiles, kicks)
+            assert cuts[0] == 0 and cuts[-1] == n_tiles and len(cuts) == kicks + 2
+            assert all(a <= b for a, b in zip(cuts[:-1], cuts[1:]))
+            sizes = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+            assert sum(sizes) == n_tiles
+            if n_tiles >= 100 and kicks:
+                assert sizes[0] == max(sizes) and min(sizes) > 0
