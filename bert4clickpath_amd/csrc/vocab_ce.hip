@@ -135,6 +135,7 @@ struct VceArgs {
     int ld_h, ld_w, ld_dh;
     int64_t R;
     int V, parts, variant;
+    int tt0, ntt;         // the 128-token tiles [tt0, tt0 + ntt) this launch sweeps
 };
 
 // merge the per-part statistics of one row: lse2 = log2 sum_j 2^(x_j log2e), clipped flag, and (optionally) the
@@ -166,27 +167,38 @@ __device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, flo
 // ------------------------------------------------------------------------------------------
 #define VCE_LAZY 12.0f
 
-template <int KD, int MODE>
-__global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
+template <int KD, int MODE, int VH>
+__global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
+    // VH = 2: 8 waves = 4 token groups x the 2 vocabulary halves of each 128-row W tile, one (token tile, vocabulary part)
+    // unit per workgroup.  VH = 1 (background form, as vce_dw_kernel<KD, 1>): 4 waves, one per SIMD, each taking both
+    // halves in turn; at most one workgroup per CU walks the units of the token tiles [tt0, tt0 + ntt).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NKS = KD / 16, NDT = KD / 32, STR = VTile<KD>::STR;
     constexpr int TILE_B = VTile<KD>::BYTES;
+    constexpr int NT = 256 * VH, NH = 2 / VH;                         // threads; W-tile halves per wave
     float *sBias = reinterpret_cast<float *>(smem + 2 * TILE_B);     // [2][128]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int nunits = a.ntt * a.parts;
+    int unit = blockIdx.x;
+    do {          // VH = 2: one unit per workgroup, no loop
+    int opaque0 = 0;
+    if (VH == 1) asm volatile("s_mov_b32 %0, 0" : "=s"(opaque0));      // (see vce_dw_kernel)
+    const int tid = threadIdx.x + opaque0, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int li = lane & 15, g = lane >> 4;
     const int tg = wave & 3, vh = wave >> 2;
-    const int64_t tok0 = (int64_t)blockIdx.x * 128;
+    const int64_t tok0 = (int64_t)(a.tt0 + unit % a.ntt) * 128;
     const int64_t tok = tok0 + tg * 32 + r;
-    const int part = blockIdx.y;
+    const int part = unit / a.ntt;
     const int nvt = (a.V + 127) >> 7;
     const int vt0 = (int)((int64_t)nvt * part / a.parts), vt1 = (int)((int64_t)nvt * (part + 1) / a.parts);
 
     float lse2 = INFINITY;   // MODE 2: log2-domain lse of the lane's token
+    bool skip = false;
     if (MODE == 2) {
         bool clipped = false;
         if (tok < a.R) vce_row_stats(a, tok, lse2, clipped);
-        if (!__syncthreads_or(clipped)) return;   // no clipped row in these 128 tokens
+        skip = !__syncthreads_or(clipped);          // no clipped row in these 128 tokens
     }
+    if (!skip) {
     bf16x8 hfr[NKS];
     vce_load_hfrag<KD>(a.h, a.ld_h, tok, a.R, hf, hfr);
     int foff[NKS], toff[NDT][2];
@@ -201,7 +213,7 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
     // tile vt -> LDS buffer `buf` (DMA), its bias -> a register (stored to LDS after the current tile's reads)
     float breg = 0.f;
     auto fetch = [&](int vt, int buf) {
-        VTile<KD>::dma(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, smem + buf * TILE_B, tid);
+        VTile<KD>::template dma<NT>(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, smem + buf * TILE_B, tid);
         if (tid < 128) {
             const int v = vt * 128 + tid;
             breg = (vt < vt1 && v < a.V) ? (a.bias ? a.bias[v] : 0.f) : -INFINITY;   // rows past V: logit = -inf
@@ -225,15 +237,18 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
     // LDS address is a per-lane VGPR + an immediate
     auto tile = [&](auto BUF, int vt) {
         constexpr int buf = decltype(BUF)::value;
-        const char *w = smem + buf * TILE_B;
-        const float *bs = sBias + buf * 128;
         fetch(vt + 1, buf ^ 1);        // the other buffer was last read one tile ago (behind the previous barrier)
+#pragma unroll
+        for (int hv = 0; hv < NH; ++hv) {            // VH = 1: the wave takes the tile's two 64-row halves in turn
+        const int vhe = VH == 2 ? vh : hv;           // which half (offsets of a VH = 1 wave carry vh = 0: + hv * 64 rows)
+        const char *w = smem + buf * TILE_B + (VH == 2 ? 0 : hv * 64 * STR);
+        const float *bs = sBias + buf * 128;
         f32x16 acc[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
             for (int tq = 0; tq < 4; ++tq) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vh * 64 + rt * 32 + 8 * tq + 4 * hf);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vhe * 64 + rt * 32 + 8 * tq + 4 * hf);
                 acc[rt][4 * tq] = b4[0]; acc[rt][4 * tq + 1] = b4[1]; acc[rt][4 * tq + 2] = b4[2]; acc[rt][4 * tq + 3] = b4[3];
             }
 #pragma unroll
@@ -261,7 +276,7 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int t = 0; t < 16; ++t)
-                        if (vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V) mn = fminf(mn, acc[rt][t]);
+                        if (vt * 128 + vhe * 64 + rt * 32 + vce_rowmap(t, hf) < a.V) mn = fminf(mn, acc[rt][t]);
             }
             tm = fmaxf(tm, __shfl_xor(tm, 32));      // the two lanes of a token share the reference (their P mix in U)
             mx = fmaxf(mx, tm);
@@ -290,7 +305,7 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -e2));
-                    const bool valid = vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V;
+                    const bool valid = vt * 128 + vhe * 64 + rt * 32 + vce_rowmap(t, hf) < a.V;
                     const float pc = __builtin_amdgcn_fmed3f(pv, VCE_EPS, 1.0f - VCE_EPS);
                     const bool un = pc == pv;              // inside the clip range
                     if (valid) { S += pc; Pu += un ? pv : 0.f; }
@@ -327,6 +342,7 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
                 }
             }
         }
+        }
         if (tid < 128) sBias[(buf ^ 1) * 128 + tid] = breg;
         VCE_DMA_WAIT();
         B4C_LDS_BARRIER();
@@ -337,8 +353,8 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
     }
     __syncthreads();   // all tiles consumed: LDS is reused below
 
-    // U^T tiles -> LDS [token][d] per wave; per-lane scalars -> LDS; then the two vocabulary halves (and the two
-    // lanes of each token) are merged and stored row-major
+    // U^T tiles -> LDS [token][d] per wave; per-lane scalars -> LDS; then the two vocabulary halves (VH = 2) and the two
+    // lanes of each token are merged and stored row-major
     constexpr int USTR = KD + 4;                         // floats per token row
     float *sU = reinterpret_cast<float *>(smem) + wave * 32 * USTR;
     if (MODE != 0)
@@ -349,33 +365,39 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
             const f32x4 v = {U[dt][4 * tq], U[dt][4 * tq + 1], U[dt][4 * tq + 2], U[dt][4 * tq + 3]};
             *reinterpret_cast<f32x4 *>(sU + r * USTR + dt * 32 + 8 * tq + 4 * hf) = v;
         }
-    f32x4 *sS = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(smem) + 8 * 32 * USTR);   // [wave][lane]
+    f32x4 *sS = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(smem) + 4 * VH * 32 * USTR);   // [wave][lane]
     sS[wave * 64 + lane] = (MODE != 2) ? (f32x4){m2, l, mn, mx} : (f32x4){S, Pu, 0.f, 0.f};
     __syncthreads();
-    // token t of the tile: waves (t >> 5) and (t >> 5) + 4, lanes (t & 31) and (t & 31) + 32
+    // token t of the tile: waves (t >> 5) and, VH = 2, (t >> 5) + 4; lanes (t & 31) and (t & 31) + 32
     float *dst = (MODE == 1 ? a.u : a.ud) + (int64_t)part * a.R * KD;
     if (MODE != 0)
-    for (int c = tid; c < 128 * (KD / 4); c += 512) {
+    for (int c = tid; c < 128 * (KD / 4); c += NT) {
         const int t = c / (KD / 4), q = c % (KD / 4);
         if (tok0 + t < a.R) {
             const float *p0 = reinterpret_cast<const float *>(smem) + t * USTR + q * 4;
-            f32x4 v0 = *reinterpret_cast<const f32x4 *>(p0), v1 = *reinterpret_cast<const f32x4 *>(p0 + 4 * 32 * USTR);
-            if (MODE == 1) {
-                const float ma = sS[(t >> 5) * 64 + (t & 31)][0], mb = sS[((t >> 5) + 4) * 64 + (t & 31)][0];
-                const float M = fmaxf(ma, mb);
-                v0 = v0 * __builtin_amdgcn_exp2f(ma - M) + v1 * __builtin_amdgcn_exp2f(mb - M);
-            } else {
-                v0 = v0 + v1;
+            f32x4 v0 = *reinterpret_cast<const f32x4 *>(p0);
+            if (VH == 2) {
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(p0 + 4 * 32 * USTR);
+                if (MODE == 1) {
+                    const float ma = sS[(t >> 5) * 64 + (t & 31)][0], mb = sS[((t >> 5) + 4) * 64 + (t & 31)][0];
+                    const float M = fmaxf(ma, mb);
+                    v0 = v0 * __builtin_amdgcn_exp2f(ma - M) + v1 * __builtin_amdgcn_exp2f(mb - M);
+                } else {
+                    v0 = v0 + v1;
+                }
             }
             *reinterpret_cast<f32x4 *>(dst + (tok0 + t) * KD + q * 4) = v0;
         }
     }
     if (tid < 128 && tok0 + tid < a.R) {
         const int tgi = tid >> 5, ri = tid & 31;
-        const f32x4 a0 = sS[tgi * 64 + ri], a1 = sS[tgi * 64 + ri + 32], b0 = sS[(tgi + 4) * 64 + ri], b1 = sS[(tgi + 4) * 64 + ri + 32];
+        const f32x4 a0 = sS[tgi * 64 + ri], a1 = sS[tgi * 64 + ri + 32];
+        f32x4 b0 = {-INFINITY, 0.f, INFINITY, -INFINITY}, b1 = {-INFINITY, 0.f, INFINITY, -INFINITY};
+        if (VH == 2) { b0 = sS[(tgi + 4) * 64 + ri]; b1 = sS[(tgi + 4) * 64 + ri + 32]; }
+        else if (MODE == 2) { b0 = (f32x4){0.f, 0.f, 0.f, 0.f}; b1 = b0; }
         if (MODE != 2) {
             const float M = fmaxf(a0[0], b0[0]);     // the two lanes of a token share m2
-            const float fa = __builtin_amdgcn_exp2f(a0[0] - M), fb = __builtin_amdgcn_exp2f(b0[0] - M);
+            const float fa = __builtin_amdgcn_exp2f(a0[0] - M), fb = VH == 2 ? __builtin_amdgcn_exp2f(b0[0] - M) : 0.f;
             *reinterpret_cast<f32x4 *>(a.st1 + ((int64_t)part * a.R + tok0 + tid) * 4) =
                 (f32x4){M, (a0[1] + a1[1]) * fa + (b0[1] + b1[1]) * fb, fminf(fminf(a0[2], a1[2]), fminf(b0[2], b1[2])),
                         fmaxf(a0[3], b0[3])};
@@ -385,6 +407,10 @@ __global__ void __launch_bounds__(512) vce_token_kernel(VceArgs a) {
             o[1] = a0[1] + a1[1] + b0[1] + b1[1];
         }
     }
+    }
+    if (VH == 1) __syncthreads();        // the next unit's tiles land in the images this one read
+    unit += gridDim.x;
+    } while (VH == 1 && unit < nunits);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -756,9 +782,9 @@ static bool vce_shape_ok(int K) { return K == 64 || K == 128; }
 template <typename Kern> static void vce_allow_lds(Kern k, size_t bytes) {
     (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
-template <int KD> static size_t vce_token_lds() {
+template <int KD> static size_t vce_token_lds(int vh = 2) {
     const size_t tiles = 2 * (size_t)VTile<KD>::BYTES + 2 * 128 * 4;
-    const size_t outs = (size_t)8 * 32 * (KD + 4) * 4 + 8 * 64 * 16;
+    const size_t outs = (size_t)4 * vh * 32 * (KD + 4) * 4 + 4 * vh * 64 * 16;
     return tiles > outs ? tiles : outs;
 }
 template <int KD> static size_t vce_dw_lds() {
@@ -786,11 +812,12 @@ static int vce_fwd_launch(VceArgs a, hipStream_t st) {
     const size_t lds = vce_token_lds<KD>();
     static thread_local bool done = false;
     if (!done) {
-        vce_allow_lds(vce_token_kernel<KD, 1>, lds);
-        vce_allow_lds(vce_token_kernel<KD, 2>, lds);
+        vce_allow_lds(vce_token_kernel<KD, 1, 2>, lds);
+        vce_allow_lds(vce_token_kernel<KD, 2, 2>, lds);
         done = true;
     }
-    dim3 grid((unsigned)ntt, (unsigned)a.parts);
+    a.tt0 = 0; a.ntt = (int)ntt;
+    const unsigned grid = (unsigned)(ntt * a.parts);
     // B4C_VCE_TIMING=1: HIP events around the kernels, read back (without synchronising) at the next call
     static const bool dbg = getenv("B4C_VCE_TIMING") != nullptr;
     static hipEvent_t ev[4];
@@ -804,9 +831,9 @@ static int vce_fwd_launch(VceArgs a, hipStream_t st) {
         if (!have) { for (auto &e : ev) (void)hipEventCreate(&e); have = true; }
         (void)hipEventRecord(ev[0], st);
     }
-    vce_token_kernel<KD, 1><<<grid, 512, lds, st>>>(a);
+    vce_token_kernel<KD, 1, 2><<<grid, 512, lds, st>>>(a);
     if (dbg) (void)hipEventRecord(ev[1], st);
-    if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2><<<grid, 512, lds, st>>>(a);
+    if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2, 2><<<grid, 512, lds, st>>>(a);
     if (dbg) (void)hipEventRecord(ev[2], st);
     vce_combine_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a);
     if (dbg) (void)hipEventRecord(ev[3], st);
@@ -831,6 +858,77 @@ extern "C" int b4c_vocab_ce_fwd(const void *h, int ld_h, const void *wt, int ld_
     return K == 128 ? vce_fwd_launch<128>(a, (hipStream_t)stream) : vce_fwd_launch<64>(a, (hipStream_t)stream);
 }
 
+// ---- b4c_vocab_ce_fwd in pieces (ABI 6): the two sweeps over a range of 128-token tiles, foreground or background form,
+// and the combine step; `parts` (1 .. 8, <= vocabulary tiles) is the caller's and the same for every piece and the combine
+template <int KD>
+static void vce_fwd_sweep_launch(VceArgs a, int tt0, int ntt, int background_wgs, hipStream_t st) {
+    a.u = a.st1 + (int64_t)a.parts * a.R * 4;
+    a.ud = a.u + (int64_t)a.parts * a.R * KD;
+    a.sp = a.ud + (int64_t)a.parts * a.R * KD;
+    a.tt0 = tt0; a.ntt = ntt;
+    const int64_t units = (int64_t)ntt * a.parts;
+    static thread_local bool done = false;
+    if (!done) {
+        vce_allow_lds(vce_token_kernel<KD, 1, 2>, vce_token_lds<KD>(2)); vce_allow_lds(vce_token_kernel<KD, 2, 2>, vce_token_lds<KD>(2));
+        vce_allow_lds(vce_token_kernel<KD, 1, 1>, vce_token_lds<KD>(1)); vce_allow_lds(vce_token_kernel<KD, 2, 1>, vce_token_lds<KD>(1));
+        done = true;
+    }
+    if (background_wgs > 0) {
+        const int64_t rounds = ceil_div64(units, background_wgs);
+        const unsigned grid = (unsigned)ceil_div64(units, rounds);
+        vce_token_kernel<KD, 1, 1><<<grid, 256, vce_token_lds<KD>(1), st>>>(a);
+        if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2, 1><<<grid, 256, vce_token_lds<KD>(1), st>>>(a);
+    } else {
+        vce_token_kernel<KD, 1, 2><<<(unsigned)units, 512, vce_token_lds<KD>(2), st>>>(a);
+        if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2, 2><<<(unsigned)units, 512, vce_token_lds<KD>(2), st>>>(a);
+    }
+}
+
+extern "C" int b4c_vocab_ce_fwd_sweep(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, void *workspace,
+                                      int64_t workspace_bytes, int64_t R, int V, int K, int variant, int parts, int tile_begin,
+                                      int tile_end, int background_workgroups, void *stream) {
+    B4C_REQUIRE(h && wt && workspace, "vocab_ce_fwd_sweep: null pointer");
+    B4C_REQUIRE(vce_shape_ok(K), "vocab_ce_fwd_sweep: K=%d unsupported (64 or 128)", K);
+    B4C_REQUIRE(variant == B4C_CE_TF || variant == B4C_CE_PLAIN, "vocab_ce_fwd_sweep: variant %d", variant);
+    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K, "vocab_ce_fwd_sweep: shape");
+    B4C_REQUIRE(ld_h % 8 == 0 && ld_w % 8 == 0 && ((((uintptr_t)h | (uintptr_t)wt | (uintptr_t)workspace) & 15) == 0),
+                "vocab_ce_fwd_sweep: operands must be 16-byte aligned with pitches %% 8 == 0");
+    B4C_REQUIRE(workspace_bytes >= b4c_vocab_ce_workspace_bytes(R, V, K), "vocab_ce_fwd_sweep: workspace too small");
+    const int64_t ntt = ceil_div64(R, 128);
+    B4C_REQUIRE(parts >= 1 && parts <= 8 && parts <= (V + 127) / 128, "vocab_ce_fwd_sweep: parts %d", parts);
+    B4C_REQUIRE(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= ntt, "vocab_ce_fwd_sweep: tiles [%d, %d) of %lld", tile_begin, tile_end, (long long)ntt);
+    B4C_REQUIRE(background_workgroups >= 0, "vocab_ce_fwd_sweep: background_workgroups %d", background_workgroups);
+    if (R == 0 || tile_begin == tile_end) return B4C_OK;
+    VceArgs a = {};
+    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.st1 = (float *)workspace;
+    a.ld_h = ld_h; a.ld_w = ld_w; a.R = R; a.V = V; a.variant = variant; a.parts = parts;
+    if (K == 128) vce_fwd_sweep_launch<128>(a, tile_begin, tile_end - tile_begin, background_workgroups, (hipStream_t)stream);
+    else vce_fwd_sweep_launch<64>(a, tile_begin, tile_end - tile_begin, background_workgroups, (hipStream_t)stream);
+    return b4c_check_launch("vocab_ce_fwd_sweep");
+}
+
+extern "C" int b4c_vocab_ce_fwd_combine(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels, const float *grad_scale,
+                                        float *item_loss, void *dh, int ld_dh, float *rowscal, void *workspace,
+                                        int64_t workspace_bytes, int64_t R, int V, int K, int variant, int parts, void *stream) {
+    B4C_REQUIRE(h && wt && labels && grad_scale && item_loss && dh && rowscal && workspace, "vocab_ce_fwd_combine: null pointer");
+    B4C_REQUIRE(vce_shape_ok(K), "vocab_ce_fwd_combine: K=%d unsupported (64 or 128)", K);
+    B4C_REQUIRE(variant == B4C_CE_TF || variant == B4C_CE_PLAIN, "vocab_ce_fwd_combine: variant %d", variant);
+    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K && ld_dh >= K, "vocab_ce_fwd_combine: shape");
+    B4C_REQUIRE(workspace_bytes >= b4c_vocab_ce_workspace_bytes(R, V, K), "vocab_ce_fwd_combine: workspace too small");
+    B4C_REQUIRE(parts >= 1 && parts <= 8, "vocab_ce_fwd_combine: parts %d", parts);
+    if (R == 0) return B4C_OK;
+    VceArgs a = {};
+    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.labels = labels; a.grad_scale = grad_scale;
+    a.st1 = (float *)workspace; a.rowscal = rowscal; a.item_loss = item_loss; a.dh = (bf16_t *)dh;
+    a.ld_h = ld_h; a.ld_w = ld_w; a.ld_dh = ld_dh; a.R = R; a.V = V; a.variant = variant; a.parts = parts;
+    a.u = a.st1 + (int64_t)parts * R * 4;
+    a.ud = a.u + (int64_t)parts * R * K;
+    a.sp = a.ud + (int64_t)parts * R * K;
+    if (K == 128) vce_combine_kernel<128><<<(unsigned)ceil_div64(R, 4), 256, 0, (hipStream_t)stream>>>(a);
+    else vce_combine_kernel<64><<<(unsigned)ceil_div64(R, 4), 256, 0, (hipStream_t)stream>>>(a);
+    return b4c_check_launch("vocab_ce_fwd_combine");
+}
+
 template <int KD>
 static int vce_lse_launch(VceArgs a, float *lse2, hipStream_t st) {
     const int64_t ntt = ceil_div64(a.R, 128);
@@ -838,8 +936,9 @@ static int vce_lse_launch(VceArgs a, float *lse2, hipStream_t st) {
     a.parts = vce_pick_split(ntt, nvt, 0.005);
     const size_t lds = vce_token_lds<KD>();
     static thread_local bool done = false;
-    if (!done) { vce_allow_lds(vce_token_kernel<KD, 0>, lds); done = true; }
-    vce_token_kernel<KD, 0><<<dim3((unsigned)ntt, (unsigned)a.parts), 512, lds, st>>>(a);
+    if (!done) { vce_allow_lds(vce_token_kernel<KD, 0, 2>, lds); done = true; }
+    a.tt0 = 0; a.ntt = (int)ntt;
+    vce_token_kernel<KD, 0, 2><<<(unsigned)(ntt * a.parts), 512, lds, st>>>(a);
     vce_lse_kernel<<<(unsigned)ceil_div64(a.R, 256), 256, 0, st>>>(a, lse2);
     return b4c_check_launch("vocab_lse");
 }

@@ -729,6 +729,34 @@ def vocab_ce_fwd(h, wt, bias, labels_i32, grad_scale, V, variant=L.CE_TF):
     return item, dh, rowscal
 
 
+def vocab_ce_fwd_sweep(h, wt, bias, V, variant, parts, tile_begin, tile_end, background_workgroups=0):
+    """the two sweeps of vocab_ce_fwd for the 128-token tiles [tile_begin, tile_end) of h (partial results in the device's
+    vocabulary-head workspace, laid out for `parts` vocabulary parts); background_workgroups > 0: background kernels"""
+    R, K = h.shape
+    if R == 0 or tile_end <= tile_begin:
+        return
+    ws = _vce_workspace(h, R, V, K)
+    rows = min(R, tile_end * 128) - tile_begin * 128
+    with _record('vocab_ce_fwd_bg' if background_workgroups > 0 else 'vocab_ce_fwd', rows * K * 2 * 2 + V * K * 2, 4 * rows * V * K):
+        L.check(L.lib().b4c_vocab_ce_fwd_sweep(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), ws.data_ptr(), ws.numel(), R, V, K,
+                                               variant, parts, tile_begin, tile_end, background_workgroups, _st()), 'vocab_ce_fwd_sweep')
+
+
+def vocab_ce_fwd_combine(h, wt, bias, labels_i32, grad_scale, V, variant, parts):
+    """-> item_loss [R], dh [R, K], rowscal [R, 8] from the swept partial results (every token tile must have been swept)"""
+    R, K = h.shape
+    item = torch.empty(R, dtype=torch.float32, device=h.device)
+    dh = torch.empty(R, K, dtype=h.dtype, device=h.device)
+    rowscal = torch.empty(R, 8, dtype=torch.float32, device=h.device)
+    if R == 0:
+        return item, dh, rowscal
+    ws = _vce_workspace(h, R, V, K)
+    L.check(L.lib().b4c_vocab_ce_fwd_combine(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(grad_scale),
+                                             _p(item), _p(dh), dh.stride(0), _p(rowscal), ws.data_ptr(), ws.numel(), R, V, K,
+                                             variant, parts, _st()), 'vocab_ce_fwd_combine')
+    return item, dh, rowscal
+
+
 def vocab_ce_dw(h, wt, bias, labels_i32, rowscal, V, dW, db):
     """dW [K, V] fp32 += d loss / d kernel, db [V] += d loss / d bias (second half of vocab_ce_fwd)."""
     R, K = h.shape

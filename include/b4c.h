@@ -263,6 +263,18 @@ int b4c_vocab_ce_dw_sweep(const void *h, int ld_h, const void *wt, int ld_w, con
                           int background_workgroups, void *stream);
 int b4c_vocab_ce_dw_labels(const void *h, int ld_h, const int32_t *labels, const float *rowscal, float *dW, int ldw,
                            float *db, void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, void *stream);
+/* (ABI version 6) b4c_vocab_ce_fwd in pieces, for the same purpose: b4c_vocab_ce_fwd_sweep runs the two sweeps (online
+ * softmax + P W; the clipped-row sweep of the TF variant) for the 128-token tiles [tile_begin, tile_end) of h, as the
+ * foreground kernels (background_workgroups = 0) or as background kernels (at most that many 256-thread workgroups, one
+ * wave per SIMD, walking the (token tile, vocabulary part) units); the partial results go to `workspace`, laid out for
+ * `parts` vocabulary parts (1 .. 8, the same value in every piece and in the combine).  b4c_vocab_ce_fwd_combine, once
+ * every tile has been swept, writes item_loss, dh and rowscal exactly as b4c_vocab_ce_fwd does. */
+int b4c_vocab_ce_fwd_sweep(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, void *workspace,
+                           int64_t workspace_bytes, int64_t R, int V, int K, int variant, int parts, int tile_begin,
+                           int tile_end, int background_workgroups, void *stream);
+int b4c_vocab_ce_fwd_combine(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
+                             const float *grad_scale, float *item_loss, void *dh, int ld_dh, float *rowscal, void *workspace,
+                             int64_t workspace_bytes, int64_t R, int V, int K, int variant, int parts, void *stream);
 
 /* ---- (ABI version 4) R12 for scoring: Dense(V, softmax) (head.py:36) with ONE pass over the (R x V) tensor ------------------
  * replaces the materialised projection + softmax (b4c_gemm_nt + b4c_softmax_rows: write, read, write) of the
