@@ -431,7 +431,7 @@ def _inplace_ok(*params):
 
 
 def _ready(*params):
-    if _grad_ready_cb is not None:
+    if _grad_ready_cb is not None and not _ready_gate:
         for p in params:
             _grad_ready_cb(p)
 
@@ -1454,11 +1454,13 @@ background_workgroups = int(os.environ.get('B4C_VCE_DW_BG', '256'))
 background_weights = tuple(float(x) for x in os.environ.get('B4C_VCE_DW_WEIGHTS', '2.2,1.0,0.6').split(','))
 _side_streams = {}
 _side_pending = []          # (event recorded on the side stream, parameters whose gradient it completes)
-_bg_pieces = []             # closures, each launching one piece of the sweep (on whatever stream is current)
-_bg_done = None             # closure that ends the job: label term, event, pending entry
-_bg_counting = False        # between the head's backward and the end of the pass
-_bg_kicks = 0               # attention-backward launches seen since the job was queued
+_bg_queue = []              # closures to run on the side stream, in order: pieces of sweeps, label terms, event records
+_bg_slots = 0               # launch opportunities left in the current plan (one now, one per attention backward expected)
+_bg_future = 0              # closures the running step will still append (they count when the slots are shared out)
+_bg_counting = False        # inside a backward pass that feeds the queue
+_bg_kicks = 0               # attention-backward launches seen in this pass
 _bg_kicks_expected = 0      # ... in the previous backward pass
+_ready_gate = False         # True: gradients are not announced (an earlier pass of a step that has several)
 
 
 def _side_stream(device):
@@ -1480,76 +1482,103 @@ def _background_plan(n_tiles, kicks):
     return cuts + [n_tiles]
 
 
+def _background_slot():
+    """One launch opportunity: the queue's head goes out on the side stream, behind everything the main stream has been
+    given so far.  The closures still to come (queued + announced) are shared out evenly over the opportunities left."""
+    global _bg_slots
+    left = max(_bg_slots, 1)
+    _bg_slots = max(_bg_slots - 1, 0)
+    if not _bg_queue:
+        return
+    n = max(1, min(len(_bg_queue), -(-(len(_bg_queue) + _bg_future) // left)))
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for _ in range(n):
+            _bg_queue.pop(0)()
+
+
 def _background_kick():
     global _bg_kicks
     if not _bg_counting:
         return
     _bg_kicks += 1
-    if _bg_pieces:
-        piece = _bg_pieces.pop(0)
-        main = torch.cuda.current_stream()
-        side = _side_stream(main.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            piece()
-            if not _bg_pieces:
-                _background_finish()
+    _background_slot()
 
 
-def _background_finish():
-    """label term + completion event, on the current (side) stream"""
-    global _bg_done
-    done, _bg_done = _bg_done, None
-    done()
+def _background_drain(until=None):
+    """everything queued (or everything up to and including the closure `until`) goes out on the side stream now"""
+    if not _bg_queue or (until is not None and until not in _bg_queue):
+        return
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        while _bg_queue:
+            c = _bg_queue.pop(0)
+            c()
+            if c is until:
+                break
+
+
+def background_pass_begin():
+    global _bg_counting, _bg_kicks
+    _bg_counting, _bg_kicks = True, 0
+
+
+def background_pass_end():
+    """the pass is over: its number of attention launches is the plan of the next one"""
+    global _bg_counting, _bg_kicks_expected
+    if _bg_counting:
+        _bg_counting, _bg_kicks_expected = False, _bg_kicks
 
 
 def join_side_work():
     """The current stream waits for everything issued on the side stream; the gradients that work produced are then
     announced (grad-ready callback).  Runs at the end of every backward pass that used the side stream (autograd engine
     callback); optimizers and reducers call it too -- it is a no-op when nothing is pending."""
-    global _bg_counting, _bg_kicks_expected
-    if _bg_counting:                # the pass is over: its number of attention launches is the plan of the next one
-        _bg_counting, _bg_kicks_expected = False, _bg_kicks
-    if _bg_done is not None:        # fewer attention launches than planned: what is left of the sweep goes out now
-        main = torch.cuda.current_stream()
-        side = _side_stream(main.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            while _bg_pieces:
-                _bg_pieces.pop(0)()
-            _background_finish()
+    global _bg_slots, _bg_future
+    background_pass_end()
+    _background_drain()             # fewer attention launches than planned: what is left of the sweeps goes out now
+    _bg_slots = _bg_future = 0
     while _side_pending:
         ev, params = _side_pending.pop(0)
         torch.cuda.current_stream().wait_event(ev)
         _ready(*params)
 
 
-def _queue_background_dw(h, wt, b, labels_i32, rowscal, V, kernel, bias):
-    global _bg_done, _bg_kicks, _bg_counting
-    if _bg_counting:                # a second head in the same backward pass: finish the first one's sweep first
-        join_side_work()
-    main, side = torch.cuda.current_stream(h.device), _side_stream(h.device)
-    n_tiles = (V + 127) // 128
-    cuts = _background_plan(n_tiles, _bg_kicks_expected)
+def _dw_pieces(h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts):
+    """closures for the vocabulary tiles cuts[i] .. cuts[i + 1]; the last one adds the label term and records the event that
+    completes the projection's gradient"""
     dW, db = kernel.grad, bias.grad
-
-    def piece(lo, hi):
-        return lambda: vocab_ce_dw_sweep(h, wt, b, rowscal, V, dW, db, lo, hi, background_workgroups)
-
-    def done():
-        vocab_ce_dw_labels(h, labels_i32, rowscal, V, dW, db)
-        ev = torch.cuda.current_stream().record_event()
-        _side_pending.append((ev, (kernel, bias)))
+    side = _side_stream(h.device)
     for t in (h, rowscal, labels_i32, wt, b, dW, db):
         if t is not None:
             t.record_stream(side)
-    _bg_pieces[:] = [piece(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
-    _bg_done, _bg_kicks, _bg_counting = done, 0, True
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        _bg_pieces.pop(0)()
-        if not _bg_pieces:
-            _background_finish()
+    spans = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
+
+    def piece(lo, hi, last):
+        def run():
+            vocab_ce_dw_sweep(h, wt, b, rowscal, V, dW, db, lo, hi, background_workgroups)
+            if last:
+                vocab_ce_dw_labels(h, labels_i32, rowscal, V, dW, db)
+                _side_pending.append((torch.cuda.current_stream().record_event(), (kernel, bias)))
+        return run
+    return [piece(lo, hi, i == len(spans) - 1) for i, (lo, hi) in enumerate(spans)]
+
+
+def _queue_background_dw(h, wt, b, labels_i32, rowscal, V, kernel, bias):
+    """(inside a backward pass) the dW sweep of the vocabulary head as kicks + 1 background pieces: one now, one behind
+    every attention backward launch of this pass"""
+    global _bg_slots
+    if _bg_counting or _bg_queue:   # a second head in the same backward pass: finish the first one's sweep first
+        join_side_work()
+    cuts = _background_plan((V + 127) // 128, _bg_kicks_expected)
+    _bg_queue.extend(_dw_pieces(h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts))
+    _bg_slots = len(_bg_queue)
+    background_pass_begin()
+    _background_slot()
     torch.autograd.Variable._execution_engine.queue_callback(join_side_work)
 
 

@@ -125,6 +125,9 @@ class GradReducer:
             # autograd's post-accumulate hook): count it once, or a bucket would be reduced before it is complete
             if self._pending is None or id(param) in self._seen:
                 return
+            from . import ops
+            if ops._ready_gate:      # an earlier pass of a step that runs several backward passes: not complete yet
+                return
             self._seen.add(id(param))
             self._pending[b] -= 1
             self._launch_in_order()
