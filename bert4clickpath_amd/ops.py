@@ -1543,7 +1543,8 @@ def join_side_work():
     _background_drain()             # fewer attention launches than planned: what is left of the sweeps goes out now
     _bg_slots = _bg_future = 0
     while _side_pending:
-        ev, params = _side_pending.pop(0)
+        ev, params, stream = _side_pending.pop(0)
+        stream.wait_event(ev)               # the stream backward ran on (this may be the engine's thread, with another current stream)
         torch.cuda.current_stream().wait_event(ev)
         _ready(*params)
 
@@ -1553,6 +1554,7 @@ def _dw_pieces(h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts):
     completes the projection's gradient"""
     dW, db = kernel.grad, bias.grad
     side = _side_stream(h.device)
+    main = torch.cuda.current_stream(h.device)
     for t in (h, rowscal, labels_i32, wt, b, dW, db):
         if t is not None:
             t.record_stream(side)
@@ -1563,7 +1565,7 @@ def _dw_pieces(h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts):
             vocab_ce_dw_sweep(h, wt, b, rowscal, V, dW, db, lo, hi, background_workgroups)
             if last:
                 vocab_ce_dw_labels(h, labels_i32, rowscal, V, dW, db)
-                _side_pending.append((torch.cuda.current_stream().record_event(), (kernel, bias)))
+                _side_pending.append((torch.cuda.current_stream().record_event(), (kernel, bias), main))
         return run
     return [piece(lo, hi, i == len(spans) - 1) for i, (lo, hi) in enumerate(spans)]
 

@@ -343,3 +343,38 @@ def test_cloze_step_falls_back_to_the_plain_calls():
     assert float(l1) == float(l2)
     for n, p in m.named_parameters():       # (the LayerNorm / bias column sums meet through float atomics: last bits differ)
         assert float((p.grad - g1[n]).abs().max()) <= 1e-5 * float(g1[n].abs().max()) + 1e-12, n
+
+
+def test_background_dw_sweep_on_a_user_stream():
+    """the whole step issued under `with torch.cuda.stream(s)`: the end-of-backward join has to make THAT stream wait for the
+    side stream (the callback may run on the autograd engine's thread, whose current stream is the default one)"""
+    from bert4clickpath_amd import input_pipeline, ops, optim
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    V, B, S = 20000, 64, 40
+    batch = input_pipeline.synthetic_cloze_batch(B, S, V, seed=21, min_len=6)
+    items = torch.from_numpy(batch['ids'])[:, 2:S - 1].contiguous().cuda()
+    labels = torch.from_numpy(batch['labels_padded']).cuda()
+    n_real = int((batch['ids'] != 0).sum())
+    prev = ops.overlap_vocab_dw
+    try:
+        out = {}
+        for mode in (False, True):
+            ops.overlap_vocab_dw = mode
+            torch.manual_seed(0)
+            m = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': 128},
+                                       SoftMaxHead([64, 128], V), value_to_head='[MASK]', num_encoder_layers=2,
+                                       num_attention_heads=2, dropout_rate=0.0, compute_dtype=torch.bfloat16).to('cuda')
+            opt = optim.Adam(m.parameters())
+            torch.cuda.synchronize()
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for step in range(2):
+                    opt.zero_grad()
+                    loss = m.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, n_real_tokens=n_real)
+                    loss.backward()
+                    snap = m.head.output_layer.kernel.grad.detach().clone()       # on s, right behind backward: no explicit join
+            torch.cuda.synchronize()
+            out[mode] = snap
+        assert float((out[True] - out[False]).abs().max()) <= 2e-5 * float(out[False].abs().max()) + 1e-12
+    finally:
+        ops.overlap_vocab_dw = prev
