@@ -1318,13 +1318,19 @@ __device__ __forceinline__ void tn_emit_bias(const TNOut &out, const float *red,
 // Second pass of TN_WS (latency-bound: every thread has at most ceil(nsplit/64) independent 16-B loads in
 // flight).  Blocks [0, tiles*256): 1024 threads = 16 float4 groups of one output tile x 64 split phases;
 // shuffles, then LDS across the 16 waves, then dW += sum.  Blocks [tiles*256, +tn): column sums.
+// blocks per 128 x 128 output tile.  A block sums GPB groups of four outputs over 1024 / GPB partitions of the splits: 16
+// groups x 64 partitions for the encoder layers' ~40 splits; with few splits (the head trunk: 8) most of those partitions
+// would idle, so 64 groups x 16 partitions (a quarter of the blocks).
+__host__ __device__ __forceinline__ int tn_reduce_bpt(int nsplit) { return nsplit <= 16 ? 64 : 256; }
+
 __device__ __forceinline__ void tn_reduce_body(const TNOut &out, int K, int N, int tk, int tn, int nsplit, int blk) {
-    __shared__ f32x4 part[16][16];
+    __shared__ f32x4 part[16][64];
     const int tid = threadIdx.x;
     const int tiles = tk * tn;
-    if (blk >= tiles * 256) {
+    const int bpt = tn_reduce_bpt(nsplit);
+    if (blk >= tiles * bpt) {
         if (!out.db[0]) return;
-        const int by = blk - tiles * 256, c = tid & 127, zp = tid >> 7;
+        const int by = blk - tiles * bpt, c = tid & 127, zp = tid >> 7;
         float s = 0.f;
         for (int z = zp; z < nsplit; z += 8) s += out.ws_db[((int64_t)z * tn + by) * 128 + c];
         float *red = reinterpret_cast<float *>(part);
@@ -1338,20 +1344,28 @@ __device__ __forceinline__ void tn_reduce_body(const TNOut &out, int K, int N, i
         }
         return;
     }
-    const int tile = blk >> 8, grp = ((blk & 255) << 4) + (tid & 15), zp = tid >> 4;
+    const bool narrow = bpt == 64;          // uniform over the launch
+    const int tile = blk / bpt;
+    const int grp = narrow ? (((blk & 63) << 6) + (tid & 63)) : (((blk & 255) << 4) + (tid & 15));
+    const int zp = narrow ? (tid >> 6) : (tid >> 4);
     const f32x4 *w = reinterpret_cast<const f32x4 *>(out.ws) + (int64_t)tile * 4096 + grp;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     const int64_t zstride = (int64_t)tiles * 4096;
+    if (narrow) {
+        for (int z = zp; z < nsplit; z += 16) s += w[z * zstride];
+        part[tid >> 6][tid & 63] = s;
+    } else {
 #pragma unroll 4
-    for (int z = zp; z < nsplit; z += 64) s += w[z * zstride];
+        for (int z = zp; z < nsplit; z += 64) s += w[z * zstride];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        s[k] += __shfl_xor(s[k], 16);
-        s[k] += __shfl_xor(s[k], 32);
+        for (int k = 0; k < 4; ++k) {
+            s[k] += __shfl_xor(s[k], 16);
+            s[k] += __shfl_xor(s[k], 32);
+        }
+        if ((tid & 63) < 16) part[tid >> 6][tid & 15] = s;
     }
-    if ((tid & 63) < 16) part[tid >> 6][tid & 15] = s;
     __syncthreads();
-    if (tid < 16) {
+    if (tid < (narrow ? 64 : 16)) {
         f32x4 v = part[0][tid];
 #pragma unroll
         for (int q = 1; q < 16; ++q) v += part[q][tid];
@@ -1684,7 +1698,7 @@ __global__ void __launch_bounds__(1024) tn_reduce_group_kernel(TNGroup g, int ns
     int blk = blockIdx.x;
     for (int i = 0; i < g.np; ++i) {
         const TNProb &pr = g.p[i];
-        const int nb = pr.tk * pr.tn * 256 + pr.tn;
+        const int nb = pr.tk * pr.tn * tn_reduce_bpt(nsplit) + pr.tn;
         if (blk < nb) {
             tn_reduce_body(pr.out, pr.K, pr.N, pr.tk, pr.tn, nsplit, blk);
             return;
@@ -1750,7 +1764,7 @@ static int gemm_tn_launch(const void *A, int lda, const void *G, int ldg, TNOut 
     else
         gemm_tn_kernel<bf16_t><<<grid, 256, shm, st>>>((const bf16_t *)A, lda, (const bf16_t *)G, ldg, out, M, K, N, chunk);
     if (out.mode == TN_WS)
-        tn_reduce_kernel<<<tk * tn * 256 + tn, 1024, 0, st>>>(out, K, N, tk, tn, (int)nsplit);
+        tn_reduce_kernel<<<tk * tn * tn_reduce_bpt((int)nsplit) + tn, 1024, 0, st>>>(out, K, N, tk, tn, (int)nsplit);
     return b4c_check_launch("gemm_tn");
 }
 
@@ -1846,7 +1860,7 @@ extern "C" int b4c_gemm_tn_group(const b4c_tn_desc *h_desc, int n_prob, int M, i
             p.out.ws_db = ws + nsplit * p.tk * p.tn * 16384;
             ws = p.out.ws_db + nsplit * p.tn * 128;
         }
-        reduce_blocks += p.tk * p.tn * 256 + p.tn;
+        reduce_blocks += p.tk * p.tn * tn_reduce_bpt((int)nsplit) + p.tn;
     }
     hipStream_t st = (hipStream_t)stream;
     gemm_tn_bf16_group_kernel<2><<<dim3(g.tiles, 1, (unsigned)nsplit), 256, 2 * TN_TILE_BYTES, st>>>(g, M, chunk);
