@@ -454,8 +454,7 @@ class ClickstreamTransformer(nn.Module):
         # ---- backward, part by part; the queue feeds the side stream at the start of a pass and behind every attention backward
         def dw_closures(s):
             item, dh, rowscal = s['res']['out']
-            cuts = ops._background_plan((V + 127) // 128, kicks) if P == 1 else \
-                [((V + 127) // 128) * j // (kicks + 1) for j in range(kicks + 2)]
+            cuts = [((V + 127) // 128) * j // (kicks + 1) for j in range(kicks + 2)]      # equal pieces: the slots share them out
             return ops._dw_pieces(s['h_d'], s['wt'], s['b'], s['lab'], rowscal, V, kernel, bias, cuts)
 
         losses = []
