@@ -305,6 +305,7 @@ def main():
     sparse = (tables + [model.head.output_embedding]) if (a.sampled and world > 1) else []
     reducer = parallel.GradReducer(arena, bucket_bounds=[head_end, emb_start], reduce='sum', sparse_params=sparse)
     specials = torch.tensor([3, 4], device=device)
+    one = torch.ones((), dtype=torch.float32, device=device)       # d loss / d loss, built once (backward() would fill one per step)
     batches = make_batches(a, rank, device)
 
     def step(i):
@@ -320,9 +321,9 @@ def main():
         else:       # device-side index generation + label compaction, cap = 10 rows per sequence, no host sync
             loss = model.cloze_loss(b['feats'], b['labels_padded'], training=True, max_masked_per_row=10,
                                     packed=False if a.dense else None, n_real_tokens=None if a.dense else b['n_real'])
-            loss.backward()
+            loss.backward(one)
         if a.host_flat_idx:
-            loss.backward()
+            loss.backward(one)
         if sparse:
             for t, f in zip(tables, b['feats'].values()):
                 reducer.set_touched_rows(t, torch.cat([f.reshape(-1), specials]))

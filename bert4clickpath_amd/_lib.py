@@ -104,6 +104,8 @@ def lib():
             'b4c_sort_ids_workspace_bytes': (i64, [i64, i32]),
             'b4c_sort_ids': (i32, [vp, i64, i32, vp, vp, i64, vp]),
             'b4c_gather_i64': (i32, [vp, vp, vp, i64, vp]),
+            'b4c_zero': (i32, [vp, i64, vp]),
+            'b4c_chain_ids': (i32, [vp, vp, vp, i32, i32, i64, i64, vp, i32, vp]),
             'b4c_rows_add': (i32, [vp, i32, vp, vp, i32, i64, i32, i32, i32, vp]),
             'b4c_attn_mq_fwd': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
             'b4c_attn_mq_bwd': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),

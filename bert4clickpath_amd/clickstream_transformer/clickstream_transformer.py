@@ -48,6 +48,8 @@ class TransformerInputPrep:
             return np.concatenate(parts, axis=1)
         seqs = [torch.as_tensor(s) for s in sequences]
         B = seqs[0].shape[0]
+        if all(s.is_cuda and s.dtype == torch.int64 and s.dim() == 2 for s in seqs) and len(seqs) <= 8:
+            return ops.chain_ids(seqs, CLS, SEP)          # one library launch instead of torch.cat
         key = (B, seqs[0].dtype, seqs[0].device)
         cols = TransformerInputPrep._special_cols.get(key)
         if cols is None:            # the [CLS] / [SEP] columns of a batch size are constants: built once, not every step

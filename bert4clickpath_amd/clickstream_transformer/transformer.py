@@ -78,7 +78,7 @@ def positional_encoding(position, d_model):
 def _mask_to_bytes(mask, B, S, device):
     """Accepts the reference's (B,1,1,S) float mask or a (B,S) byte/bool mask; None = no padding."""
     if mask is None:
-        return torch.zeros(B, S, dtype=torch.uint8, device=device)
+        return ops.zeros(B, S, dtype=torch.uint8, device=device)
     m = mask.reshape(B, S)
     return (m != 0).to(torch.uint8).contiguous()
 
@@ -87,7 +87,7 @@ def _key_mask_bytes(mask, B, Sk, device):
     """Key-side padding masks only: the reference's (B,1,1,Sk) float mask, a (B,Sk) byte / bool / float mask, or None.
     (The reference's function also accepts any mask broadcastable to (..., Sq, Sk); the encoder never builds one.)"""
     if mask is None:
-        return torch.zeros(B, Sk, dtype=torch.uint8, device=device)
+        return ops.zeros(B, Sk, dtype=torch.uint8, device=device)
     if mask.numel() != B * Sk:
         raise B4CError('MI355X build: attention masks are key-side padding masks of %d x %d elements, got shape %s'
                        % (B, Sk, tuple(mask.shape)))

@@ -985,3 +985,50 @@ extern "C" int b4c_gather_i64(const int64_t *src, const int32_t *idx, int64_t *o
     gather_i64_kernel<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(src, idx, out, n);
     return b4c_check_launch("gather_i64");
 }
+
+// ---- (ABI 7) zero fill and id chaining: the last two things the training step asked PyTorch kernels for -------------
+extern "C" int b4c_zero(void *p, int64_t nbytes, void *stream) {
+    B4C_REQUIRE(nbytes >= 0 && (nbytes == 0 || p), "zero: bad argument");
+    if (nbytes == 0) return B4C_OK;
+    if (hipMemsetAsync(p, 0, (size_t)nbytes, (hipStream_t)stream) != hipSuccess) {
+        b4c_set_error("zero: hipMemsetAsync of %lld bytes failed", (long long)nbytes);
+        return B4C_ELAUNCH;
+    }
+    return B4C_OK;
+}
+
+// out[b] = [cls, sep, seq_0[b], sep, seq_1[b], sep, ...]   (TransformerInputPrep._chain_sequences, clickstream_transformer.py:38-63)
+#define CHAIN_MAX 8
+struct ChainArgs {
+    const int64_t *seq[CHAIN_MAX];
+    int len[CHAIN_MAX], pitch[CHAIN_MAX], start[CHAIN_MAX];      // start: first output column of the sequence
+    int n, B, S, ld_out;
+    int64_t cls, sep;
+};
+__global__ void __launch_bounds__(256) chain_ids_kernel(ChainArgs a, int64_t *__restrict__ out) {
+    const int64_t total = (int64_t)a.B * a.S;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / a.S), c = (int)(i % a.S);
+        int64_t v = c == 0 ? a.cls : a.sep;
+#pragma unroll
+        for (int s = 0; s < CHAIN_MAX; ++s)
+            if (s < a.n && c >= a.start[s] && c < a.start[s] + a.len[s]) v = a.seq[s][(int64_t)b * a.pitch[s] + (c - a.start[s])];
+        out[(int64_t)b * a.ld_out + c] = v;
+    }
+}
+extern "C" int b4c_chain_ids(const int64_t *const *seqs, const int *lens, const int *pitches, int n_seq, int B, int64_t cls,
+                             int64_t sep, int64_t *out, int ld_out, void *stream) {
+    B4C_REQUIRE(seqs && lens && pitches && out && n_seq >= 1 && n_seq <= CHAIN_MAX && B >= 0, "chain_ids: bad argument (1..%d sequences)", CHAIN_MAX);
+    ChainArgs a = {};
+    int pos = 2;
+    for (int s = 0; s < n_seq; ++s) {
+        B4C_REQUIRE(lens[s] >= 0 && pitches[s] >= lens[s] && (lens[s] == 0 || B == 0 || seqs[s]), "chain_ids: sequence %d", s);
+        a.seq[s] = seqs[s]; a.len[s] = lens[s]; a.pitch[s] = pitches[s]; a.start[s] = pos;
+        pos += lens[s] + 1;
+    }
+    B4C_REQUIRE(ld_out >= pos, "chain_ids: ld_out %d < %d columns", ld_out, pos);
+    a.n = n_seq; a.B = B; a.S = pos; a.ld_out = ld_out; a.cls = cls; a.sep = sep;
+    if (B == 0) return B4C_OK;
+    chain_ids_kernel<<<ew_grid((int64_t)B * pos, 256), 256, 0, (hipStream_t)stream>>>(a, out);
+    return b4c_check_launch("chain_ids");
+}

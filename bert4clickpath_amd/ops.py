@@ -160,7 +160,7 @@ def nonpad_positions(ids, cap, pad_value=0):
     dev = ids.device
     counts = torch.empty(B, dtype=torch.int32, device=dev)
     cu = torch.empty(B + 1, dtype=torch.int32, device=dev)
-    tok_src = torch.zeros(max(cap, 1), dtype=torch.int32, device=dev)      # rows past the true count (wrong cap) read token 0
+    tok_src = zeros(max(cap, 1), dtype=torch.int32, device=dev)      # rows past the true count (wrong cap) read token 0
     packed_of = torch.empty(B * S, dtype=torch.int32, device=dev)
     mx = torch.empty(1, dtype=torch.int32, device=dev)
     L.check(L.lib().b4c_nonpad_positions(_p(ids), B, S, pad_value, _p(counts), _p(cu), _p(tok_src), cap, _p(packed_of), _p(mx),
@@ -271,6 +271,35 @@ def empty_rows(R, n, dtype, device):
     ld = row_pitch(n)
     buf = torch.empty(R, ld, dtype=dtype, device=device)
     return buf if ld == n else buf[:, :n]
+
+
+def zero_(t):
+    """zeros into a contiguous tensor through the library (hipMemsetAsync on the launch stream), in place"""
+    if t.is_cuda and t.is_contiguous():
+        if t.numel():
+            L.check(L.lib().b4c_zero(_p(t), t.numel() * t.element_size(), _st()), 'zero')
+        return t
+    return t.zero_()
+
+
+def zeros(*shape, dtype=torch.float32, device=None):
+    """torch.zeros through the library's fill on a GPU (no PyTorch kernel in the training step's trace)"""
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    return zero_(t) if t.is_cuda else t.zero_()
+
+
+def chain_ids(seqs, cls, sep):
+    """[cls, sep, seq_0, sep, seq_1, sep, ...] along axis 1 for (B, L_i) int64 id tensors on a GPU (b4c_chain_ids)"""
+    B = seqs[0].shape[0]
+    seqs = [s if (s.stride(-1) == 1 or s.shape[1] == 0) else s.contiguous() for s in seqs]
+    S = 2 + sum(int(s.shape[1]) + 1 for s in seqs)
+    out = torch.empty(B, S, dtype=torch.int64, device=seqs[0].device)
+    n = len(seqs)
+    ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in seqs])
+    lens = (ctypes.c_int * n)(*[int(s.shape[1]) for s in seqs])
+    pitches = (ctypes.c_int * n)(*[int(s.stride(0)) if s.shape[1] else 0 for s in seqs])
+    L.check(L.lib().b4c_chain_ids(ptrs, lens, pitches, n, B, int(cls), int(sep), _p(out), S, _st()), 'chain_ids')
+    return out
 
 
 def _rows_ok(g, dtype):
@@ -441,8 +470,8 @@ def attn_mq_fwd(q, kv, cu, moff, B, max_len, H, dh, key_pad=None):
     q [R, H*dh]; kv [T, 2*H*dh] (k | v); cu [B+1] token offsets; moff [B+1] query-row offsets -> (o [R, H*dh], lse [R, H])."""
     R = q.shape[0]
     # rows outside every [moff[b], moff[b+1]) range (the unused tail of the sync-free form) are not written: zeros, not garbage
-    o = torch.zeros(R, H * dh, dtype=q.dtype, device=q.device)
-    lse = torch.zeros(R, H, dtype=torch.float32, device=q.device)
+    o = zeros(R, H * dh, dtype=q.dtype, device=q.device)
+    lse = zeros(R, H, dtype=torch.float32, device=q.device)
     if R == 0:
         return o, lse
     es = q.element_size()
@@ -455,7 +484,7 @@ def attn_mq_fwd(q, kv, cu, moff, B, max_len, H, dh, key_pad=None):
 def attn_mq_bwd(q, kv, cu, moff, o, d_o, lse, B, max_len, H, dh, key_pad=None):
     """-> (dq [R, H*dh], dkv [T, 2*H*dh]); every token row of dkv is written (zeros where no query reads the sequence)."""
     R = q.shape[0]
-    dq = torch.zeros_like(q)
+    dq = zeros(q.shape[0], q.shape[1], dtype=q.dtype, device=q.device)
     if R == 0:                 # no query row anywhere: no key or value receives a gradient from this layer
         return dq, torch.zeros_like(kv)
     dkv = torch.empty_like(kv)
@@ -1059,11 +1088,14 @@ class EmbedFn(torch.autograd.Function):
         ctx.save_for_backward(*ids, *tables)
         ctx.n, ctx.scale, ctx.rate, ctx.seed = n, scale, rate, seed
         ctx.mark_non_differentiable(key_pad)
+        ctx.set_materialize_grads(False)       # (or autograd fills a zero "gradient" of key_pad's size every step)
         return out, key_pad
 
     @staticmethod
     def backward(ctx, dout, _):
         flush_pending_dw()
+        if dout is None:
+            return (None,) * (6 + 2 * ctx.n)
         saved = ctx.saved_tensors
         ids, tables = list(saved[:ctx.n]), list(saved[ctx.n:])
         dout = dout.reshape(ids[0].shape[0], ids[0].shape[1], -1)

@@ -44,7 +44,7 @@ class FlatArena:
         return self.offsets[i], self.offsets[i] + p.numel()
 
     def zero_grad(self):
-        self.grad.zero_()
+        ops.zero_(self.grad)
 
 
 class Adam:

@@ -447,6 +447,13 @@ int b4c_attn_bwd_varlen(const void *qkv, int ld_qkv, const uint8_t *key_pad, con
 int64_t b4c_sort_ids_workspace_bytes(int64_t n, int n_rows);
 int b4c_sort_ids(const int64_t *ids, int64_t n, int n_rows, int32_t *order, void *workspace, int64_t workspace_bytes, void *stream);
 int b4c_gather_i64(const int64_t *src, const int32_t *idx, int64_t *out, int64_t n, void *stream);   /* out[i] = src[idx[i]] */
+/* (ABI version 7) b4c_zero: nbytes of zeros at p (stream-ordered).  b4c_chain_ids: out[b] = [cls, sep, seq_0[b], sep, seq_1[b],
+ * sep, ...] -- TransformerInputPrep._chain_sequences (clickstream_transformer.py:38-63) for already-mapped int64 ids;
+ * seqs / lens / pitches are HOST arrays of n_seq (<= 8) device pointers, row lengths and row pitches (elements);
+ * out has 2 + sum(lens) + n_seq columns on a pitch of ld_out. */
+int b4c_zero(void *p, int64_t nbytes, void *stream);
+int b4c_chain_ids(const int64_t *const *seqs, const int *lens, const int *pitches, int n_seq, int B, int64_t cls,
+                  int64_t sep, int64_t *out, int ld_out, void *stream);
 int b4c_rows_add(void *dst, int ld_dst, const int32_t *idx, const void *src, int ld_src, int64_t n_src, int width, int dtype,
                  int src_dtype, void *stream);   /* dst[idx[r]] += src[r] (idx distinct, < 0 skipped; src may be fp32 beside a
                                                   * bf16 dst): the query rows' gradient joins that of all token rows */

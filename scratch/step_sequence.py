@@ -10,7 +10,7 @@ want = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
 a, b = starts[want], starts[want + 1]
 ours = ('gemm_', 'attn_', 'vce_', 'add_ln', 'embed_', 'adam', 'mask_', 'topk', 'softmax_', 'pack_', 'nonpad', 'remap', 'compact',
         'rows_kernel', 'tn_reduce', 'ln_bwd', 'padded_index', 'transpose', 'dropout', 'sampled', 'log_uniform', 'sort_', 'label_scale',
-        'sum_scaled', 'relu_gate', 'rows_add', 'vce_apply', 'gather_i64')
+        'sum_scaled', 'relu_gate', 'rows_add', 'vce_apply', 'gather_i64', 'chain_ids')
 glue_us = lib_us = gap_us = 0.0
 prev_end = int(rows[a]['Start_Timestamp'])
 n_glue = 0

@@ -817,3 +817,29 @@ def test_library_sort_is_the_stable_argsort(n, n_rows):
         ops.library_sort = prev
     want = torch.sort(idc.clamp(0, n_rows - 1), stable=True)[1].to(torch.int32)
     assert torch.equal(got, want)
+
+
+def test_chain_ids_and_zero_fill_match_torch():
+    """b4c_chain_ids == the torch.cat of TransformerInputPrep._chain_sequences (clickstream_transformer.py:38-63) for one,
+    two and three id sequences, strided rows included; b4c_zero == Tensor.zero_()."""
+    from bert4clickpath_amd import ops
+    from bert4clickpath_amd.clickstream_transformer.clickstream_transformer import TransformerInputPrep
+    from bert4clickpath_amd.clickstream_transformer.constants import CLS, SEP
+    g = torch.Generator().manual_seed(3)
+    for B, lens in ((7, (5,)), (33, (17, 4)), (4, (3, 1, 9)), (1, (1,)), (5, (0, 6))):
+        wide = [torch.randint(10, 5000, (B, n + 3), generator=g).cuda() for n in lens]
+        seqs = [w[:, 1:1 + n] for w, n in zip(wide, lens)]                # row pitch n + 3, offset 1: not contiguous
+        cls = torch.full((B, 1), CLS, dtype=torch.int64, device='cuda')
+        sep = torch.full((B, 1), SEP, dtype=torch.int64, device='cuda')
+        parts = [cls, sep]
+        for s in seqs:
+            parts += [s, sep]
+        ref = torch.cat(parts, dim=1)
+        assert torch.equal(ops.chain_ids(seqs, CLS, SEP), ref)
+        assert torch.equal(TransformerInputPrep._chain_sequences(seqs), ref)
+        assert torch.equal(TransformerInputPrep._chain_sequences([s.cpu() for s in seqs]).cuda(), ref)     # the torch.cat path
+    t = torch.randn(1000, 37, device='cuda')
+    assert float(ops.zero_(t).abs().max()) == 0.0
+    z = ops.zeros(5, 3, dtype=torch.bfloat16, device='cuda')
+    assert z.shape == (5, 3) and z.dtype == torch.bfloat16 and float(z.float().abs().max()) == 0.0
+    assert ops.zeros(0, 4, device='cuda').numel() == 0
