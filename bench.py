@@ -232,9 +232,11 @@ def roofline_from(fams, steps, peak_tf, dom=None):
                  'launches_timed': v['launches'], 'traffic': None, 'families': table})
     bg = sorted(f for f in fams if f.endswith('_bg'))
     if bg:
-        head['beside'] = {'families': bg, 'ms_per_step': sum(fams[f]['ms'] for f in bg) / steps,
+        # kept out of `families`, whose rows add up to (at most) the step: these overlap the rows there
+        head['beside'] = {'families': {f: table.pop(f) for f in bg}, 'ms_per_step': sum(fams[f]['ms'] for f in bg) / steps,
                           'note': 'launches of these families run on a side stream at the same time as the main stream\'s '
-                                  '(every main-stream duration above was measured with them on the CUs)'}
+                                  '(every duration in `families` was measured with them on the CUs); their time is not '
+                                  'additive to the step'}
     return head
 
 
