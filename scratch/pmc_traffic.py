@@ -8,9 +8,11 @@ FAM = [('attn_mq_fwd', ('attn_mq_fwd',), None), ('attn_mq_bwd', ('attn_mq_bwd',)
        ('attn_bwd', ('attn_bwd',), None), ('attn_fwd', ('attn_fwd',), None), ('softmax_ce', ('softmax_ce',), None),
        ('add_ln_fwd', ('add_ln_fwd',), None), ('add_ln_bwd', ('add_ln_bwd',), None), ('embed_bwd', ('embed_bwd',), None),
        ('embed_fwd', ('embed_fwd',), None), ('adam', ('adam_kernel',), None),
-       ('vocab_lse', ('vce_token_kernel<128, 0>', 'vce_token_kernel<64, 0>', 'vce_token_kernelILi128ELi0E', 'vce_lse_kernel'), 'vce_lse_kernel'),
+       ('vocab_lse', ('vce_token_kernel<128, 0,', 'vce_token_kernel<64, 0,', 'vce_token_kernelILi128ELi0E', 'vce_lse_kernel'), 'vce_lse_kernel'),
        ('vocab_ce_fwd', ('vce_token_kernel', 'vce_combine_kernel'), 'vce_combine_kernel'),
-       ('vocab_ce_dw', ('vce_dw_kernel', 'vce_label'), 'vce_dw_kernel')]
+       # (the background form goes out in pieces: the label kernel marks one launch of the family per step)
+       ('vocab_ce_dw_bg', ('vce_dw_kernel<128, 1>', 'vce_dw_kernel<64, 1>', 'vce_label'), 'vce_label_kernel'),
+       ('vocab_ce_dw', ('vce_dw_kernel',), 'vce_dw_kernel')]
 def fam_of(name):
     for f, pats, prim in FAM:
         if any(p in name for p in pats): return f, (prim is None or prim in name)
