@@ -409,7 +409,7 @@ class ClickstreamTransformer(nn.Module):
         bounds = [B * i // P for i in range(P + 1)]
         main = torch.cuda.current_stream(dev)
         side = ops._side_stream(dev)
-        bg = ops.background_workgroups
+        bg = ops.background_wgs(dev)
         kicks = ops._bg_kicks_expected
         parts_v = max(1, min(8, (V + 127) // 128))
         block = max(1, bg // parts_v)               # token tiles per full round of background workgroups

@@ -1480,7 +1480,16 @@ class MLPFn(torch.autograd.Function):
 # previous pass.  The main stream joins, and the gradient is announced to a reducer, when backward ends (join_side_work).
 # B4C_OVERLAP_DW=0 switches it off (the sweep then runs in the foreground, first thing in backward).
 overlap_vocab_dw = os.environ.get('B4C_OVERLAP_DW', '1') == '1'
-background_workgroups = int(os.environ.get('B4C_VCE_DW_BG', '256'))
+background_workgroups = int(os.environ.get('B4C_VCE_DW_BG', '0'))      # 0: one per CU of the device
+
+
+def background_wgs(device):
+    """workgroups of a background sweep: ops.background_workgroups, or one per CU of `device` (256 on an MI355X)"""
+    if background_workgroups > 0:
+        return background_workgroups
+    return int(torch.cuda.get_device_properties(device).multi_processor_count)
+
+
 # the windows' relative lengths: the first one (head trunk + the rows-only last layer + half a layer), one per layer, the last
 # one (half a layer + the embedding backward)
 background_weights = tuple(float(x) for x in os.environ.get('B4C_VCE_DW_WEIGHTS', '2.2,1.0,0.6').split(','))
@@ -1594,7 +1603,7 @@ def _dw_pieces(h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts):
 
     def piece(lo, hi, last):
         def run():
-            vocab_ce_dw_sweep(h, wt, b, rowscal, V, dW, db, lo, hi, background_workgroups)
+            vocab_ce_dw_sweep(h, wt, b, rowscal, V, dW, db, lo, hi, background_wgs(h.device))
             if last:
                 vocab_ce_dw_labels(h, labels_i32, rowscal, V, dW, db)
                 _side_pending.append((torch.cuda.current_stream().record_event(), (kernel, bias), main))
