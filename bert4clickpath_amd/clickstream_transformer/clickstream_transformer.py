@@ -483,6 +483,10 @@ class ClickstreamTransformer(nn.Module):
                 ops.background_pass_end()
                 losses.append(ops.sum_scaled(item, scale, s['poison']))
                 s['h'] = None
+        except BaseException:
+            del ops._bg_queue[:]            # closures of a step that failed must not run inside a later one
+            ops._bg_counting = False
+            raise
         finally:
             ops._ready_gate = False
         ops.join_side_work()
