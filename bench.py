@@ -55,8 +55,6 @@ def parse():
     ap.add_argument('--eval_steps', type=int, default=6, help='timed scoring batches (0 = skip the scoring leg)')
     ap.add_argument('--full_steps', type=int, default=8, help='extra steps, after the timed region, of the step that computes every position of every '
                     'layer (padded layout, full last layer) for the every_position_of_every_layer entry; 0 = skip')
-    ap.add_argument('--row_parts', type=int, default=int(os.environ.get('B4C_ROW_PARTS', '1')),
-                    help='> 1: the step runs as model.cloze_step with the batch cut into this many row parts (same loss and gradients)')
     ap.add_argument('--dense', action='store_true', help='A/B: run the encoder on the padded (B, S) layout as the reference does '
                     '(default: padding-free layout, pad positions are not computed -- DESIGN.md section 3)')
     ap.add_argument('--full_length', action='store_true', help='SURVEY 8d no-padding variant: every sequence has 197 items (the packed '
@@ -143,9 +141,6 @@ def make_batches(a, rank, device):
                     # host-side batch metadata, as the input pipeline has it when it pads (input_pipeline.py:198-214):
                     # number of non-pad positions of the chained batch ([CLS] [SEP] items [SEP])
                     'n_real': int((b['ids'] != 0).sum()),
-                    # the same per row part of the pipelined step (--row_parts)
-                    'n_real_parts': [int((b['ids'][a.batch * i // a.row_parts:a.batch * (i + 1) // a.row_parts] != 0).sum())
-                                     for i in range(a.row_parts)],
                     'R': int(b['labels'].shape[0])})
     return out
 
@@ -316,10 +311,6 @@ def main():
         reducer.begin_backward()
         if a.host_flat_idx:
             loss = model.cloze_loss(b['feats'], b['labels'], training=True, flat_idx=b['flat_idx'], packed=False)
-        elif a.row_parts > 1 and not a.dense and not a.sampled:
-            # forward + backward with the batch moving through the step in row parts, one behind the other: the vocabulary
-            # head's matrix-pipe-bound sweeps of one part run beside the HBM-bound encoder work of the other
-            loss = model.cloze_step(b['feats'], b['labels_padded'], 10, n_real_tokens=b['n_real_parts'], row_parts=a.row_parts)
         else:       # device-side index generation + label compaction, cap = 10 rows per sequence, no host sync
             loss = model.cloze_loss(b['feats'], b['labels_padded'], training=True, max_masked_per_row=10,
                                     packed=False if a.dense else None, n_real_tokens=None if a.dense else b['n_real'])

@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('B4C_LIB_PATH') or os.path.join(_HERE, 'libb4c_hip.so')     # override: A/B of two builds (scratch)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'b4c.h')
 
+ABI_VERSION = 8      # include/b4c.h; b4c_abi_version() of the library must agree
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
 CE_TF, CE_PLAIN = 0, 1
@@ -87,7 +88,8 @@ def lib():
             'b4c_attn_bwd_ws': (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
             'b4c_add_dropout_layernorm_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, u64, i32, vp]),
             'b4c_add_dropout_layernorm_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, i32, vp]),
-            'b4c_mask_positions': (i32, [vp, i32, i32, i64, vp, vp, vp, i32, vp, vp]),
+            'b4c_poison_rows': (i32, [vp, i32, i64, i32, vp, i32, vp]),
+            'b4c_mask_positions': (i32, [vp, i32, i32, i64, vp, vp, vp, i32, vp, vp, vp]),
             'b4c_padded_index': (i32, [vp, vp, vp, i32, i32, vp, vp]),
             'b4c_gather_rows': (i32, [vp, i32, vp, vp, i32, i64, i32, i32, vp]),
             'b4c_scatter_rows': (i32, [vp, i32, vp, vp, i32, i64, i64, i32, i32, vp]),
@@ -99,8 +101,6 @@ def lib():
             'b4c_vocab_ce_dw': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i64, i64, i32, i32, vp]),
             'b4c_vocab_ce_dw_sweep': (i32, [vp, i32, vp, i32, vp, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
             'b4c_vocab_ce_dw_labels': (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i64, i64, i32, i32, vp]),
-            'b4c_vocab_ce_fwd_sweep': (i32, [vp, i32, vp, i32, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
-            'b4c_vocab_ce_fwd_combine': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i64, i64, i32, i32, i32, i32, vp]),
             'b4c_sort_ids_workspace_bytes': (i64, [i64, i32]),
             'b4c_sort_ids': (i32, [vp, i64, i32, vp, vp, i64, vp]),
             'b4c_gather_i64': (i32, [vp, vp, vp, i64, vp]),

@@ -215,8 +215,9 @@ class ClickstreamTransformer(nn.Module):
             raise B4CError('packed=True needs bf16 compute, head depth 32 / 64 and an encoder length <= 512')
         return ok
 
-    def _match_positions(self, ids_first, raw_first, cap=None):
-        """Flat (b*S+s) indices, row-major, where the first feature's RAW value == value_to_head."""
+    def _match_positions(self, ids_first, raw_first, cap=None, poison=None):
+        """Flat (b*S+s) indices, row-major, where the first feature's RAW value == value_to_head.  More matches than `cap`:
+        offsets clamped to cap, the returned maxcount negative and the int32 flag `poison` set to -1 (ops.mask_positions)."""
         name = list(self.sequential_input_config.keys())[0]
         t = self.vocab_lookup_tables[name]
         vid = t['table'].get(self.value_to_head, t['oov'])
@@ -226,7 +227,16 @@ class ClickstreamTransformer(nn.Module):
             hit = (np.asarray(raw_first, dtype=object) == self.value_to_head)
             ids_first = torch.from_numpy(np.where(hit, -7, 0).astype(np.int64)).to(ids_first.device)
             vid = -7
-        return ops.mask_positions(ids_first.contiguous(), int(vid), cap)
+        return ops.mask_positions(ids_first.contiguous(), int(vid), cap, poison)
+
+    def _poisoned(self, out, n_real_tokens):
+        """forward() with a caller-given n_real_tokens: a count that disagrees with the device's own would silently drop
+        tokens or invent token-0 rows.  The head's output is overwritten with NaN when the device flag says so (a kernel
+        that returns at once otherwise), without a read-back.  (The flag goes to the OUTPUT: a NaN in the head's input
+        would not survive its ReLUs.)"""
+        if self._packed is None or n_real_tokens is None or not isinstance(out, torch.Tensor) or not out.is_floating_point():
+            return out
+        return ops.poison_rows(out, self._packed.ids_packed)
 
     # ---- reference call ------------------------------------------------------------------------
     def forward(self, inputs, training=None, mask=None, max_matches=None, packed=None, n_real_tokens=None):
@@ -257,12 +267,12 @@ class ClickstreamTransformer(nn.Module):
                 M, keep = self._rows_extra
                 B = ids_first.shape[0]
                 enc = ops.GatherRowsFn.apply(enc, keep, B * M)
-                logits = self.head(enc.view(B, M, enc.shape[-1]))
+                logits = self._poisoned(self.head(enc.view(B, M, enc.shape[-1])), n_real_tokens)
                 if 'instance_id' in inputs.keys():
                     return {'instance_id': inputs['instance_id'], 'logits': logits}
                 return logits
             head_input = enc.new_zeros(ids_first.shape[0], 0, enc.shape[-1])       # no position matches anywhere
-            logits = self.head(head_input)
+            logits = self._poisoned(self.head(head_input), n_real_tokens)
             if 'instance_id' in inputs.keys():
                 return {'instance_id': inputs['instance_id'], 'logits': logits}
             return logits
@@ -283,7 +293,7 @@ class ClickstreamTransformer(nn.Module):
                 head_input = ops.GatherRowsFn.apply(enc.reshape(-1, d), pidx, B * M).view(B, M, d)
         else:
             raise ValueError("One of value_to_head and segment_to_head must be provided.")
-        logits = self.head(head_input)
+        logits = self._poisoned(self.head(head_input), n_real_tokens)
         if 'instance_id' in inputs.keys():
             return {'instance_id': inputs['instance_id'], 'logits': logits}
         return logits
@@ -295,9 +305,16 @@ class ClickstreamTransformer(nn.Module):
         the device, exactly `cap` rows come back (those beyond the real count R are zero rows whose label is -1) together
         with the compact int32 labels.  Neither: R is read back from the device (one host sync).
         pack: the encoder runs on the padding-free layout; the dense [MASK] indices are mapped to its rows."""
+        self._mask_flag = None
+
         def positions(ids_first, raw_first):
             if cap is not None:
-                counts, offsets, flat, _ = self._match_positions(ids_first, raw_first, cap)
+                # more [MASK] positions than cap = B x max_masked_per_row: the offsets stay inside the cap (the masked-query
+                # kernels index rows by them) and the loss comes back NaN -- through the packed layout's flag when that one is
+                # folded into the loss anyway, else through this call's own
+                pk_flag = self._packed.ids_packed if (self._packed is not None and n_real_tokens is not None) else None
+                counts, offsets, flat, mx = self._match_positions(ids_first, raw_first, cap, pk_flag)
+                self._mask_flag = mx if pk_flag is None else None
                 lab = ops.compact_labels(labels_padded, counts, offsets, cap, flat)     # also sets flat[R:] = -1
                 return flat, offsets, lab
             _, offsets, flat, _ = self._match_positions(ids_first, raw_first)
@@ -346,8 +363,9 @@ class ClickstreamTransformer(nn.Module):
             if lab.shape[0] != rows.shape[0]:
                 raise ValueError('%d labels for %d masked positions' % (lab.shape[0], rows.shape[0]))
         code = CE_TF if variant == 'tf' else CE_PLAIN
-        # a wrong n_real_tokens would silently drop or invent tokens: the device-side count disagrees -> NaN loss
-        poison = self._packed.ids_packed if (self._packed is not None and n_real_tokens is not None) else None
+        # a wrong n_real_tokens would silently drop or invent tokens, more [MASK] positions than B x max_masked_per_row
+        # would drop rows: the device-side counts disagree -> NaN loss (no read-back)
+        poison = self._packed.ids_packed if (self._packed is not None and n_real_tokens is not None) else self._mask_flag
         if hasattr(self.head, 'cloze_ce'):
             if poison is not None and getattr(self.head, 'accepts_poison', False):
                 loss = self.head.cloze_ce(rows, lab, code, unit_grad, poison=poison)      # folded into the loss kernel
@@ -360,140 +378,6 @@ class ClickstreamTransformer(nn.Module):
         if poison is not None:
             loss = loss + torch.where(poison[0] < 0, float('nan'), 0.0).to(loss.dtype)
         return loss
-
-    def cloze_step(self, inputs, labels, max_masked_per_row, n_real_tokens=None, variant='tf', row_parts=2):
-        """Forward AND backward of one training step: `loss = cloze_loss(...); loss.backward()` with the batch cut into
-        `row_parts` contiguous row ranges that move through the step one behind the other (same loss -- the mean over the
-        masked items of the WHOLE batch -- and the same gradients, accumulated into .grad; the detached loss comes back).
-        What it buys: the vocabulary head's sweeps are matrix-pipe bound and everything else in the step is HBM bound, and
-        within ONE batch the forward sweeps have nothing to run beside (loss -> dh -> all of backward).  With two parts
-        A, B the side stream carries  sweeps(A) | sweeps(B) | dW(A) | dW(B)  as background kernels (ops: one wave per
-        SIMD, pieces between the resident attention backward launches) beside  fwd(B) | bwd(A) | bwd(A), bwd(B) | bwd(B)
-        on the main stream.
-        MEASURED SLOWER than the whole-batch step at C2 on one MI355X (10.85 against 9.85 ms, `bench.py --row_parts 2`,
-        DESIGN.md section 7): the forward sweeps slow the kernels beside them by 2 x, not by the 1.15 x the dW sweep costs.
-        Kept, tested and off by default as the starting point of that work; `cloze_loss(...).backward()` is the fast path.
-        n_real_tokens: one host int per part (the padding-free layout needs each part's count) or None.
-        Needs the logits-free head (SoftMaxHead, bf16, K in {64, 128}) with in-place gradients (optim.FlatArena) and
-        ops.overlap_vocab_dw; anything else runs the plain two calls."""
-        from collections.abc import Sequence
-        head = self.head
-        P = int(row_parts)
-        first = next(iter(v for k, v in inputs.items() if k != 'instance_id'))
-        B = len(first)
-        counts = list(n_real_tokens) if isinstance(n_real_tokens, Sequence) else None
-        ok = (P > 1 and B >= P and ops.overlap_vocab_dw and ops.flash_ce and hasattr(head, '_proj') and hasattr(head, 'trunk')
-              and getattr(head, 'num_sampled', 0) == 0 and self.compute_dtype == torch.bfloat16
-              and (n_real_tokens is None or (counts is not None and len(counts) == P)))
-        if ok:
-            if not head._built():
-                head.build(self.transformer.d_model)
-                head.to(self.transformer.pos_encoding.device)
-            K, kernel, bias = head._proj()
-            pack = head._packs[-1]
-            ok = (K in (64, 128) and getattr(pack, 'tied_offset', None) is None and ops._inplace_ok(kernel, bias))
-        if not ok:
-            n = sum(counts) if counts is not None else n_real_tokens
-            loss = self.cloze_loss(inputs, labels, True, variant=variant, max_masked_per_row=max_masked_per_row, n_real_tokens=n)
-            loss.backward()
-            return loss.detach()
-
-        dev = self.transformer.pos_encoding.device
-        lab = torch.as_tensor(labels, device=dev)
-        if lab.dim() != 2:
-            raise ValueError('cloze_step needs the padded (B, M) labels')
-        V = head.output_vocab_size
-        code = CE_TF if variant == 'tf' else CE_PLAIN
-        M = int(max_masked_per_row)
-        scale = ops.label_scale(lab.reshape(-1).to(torch.int32), V)         # [1 / n_valid, n_valid] of the WHOLE batch
-        bounds = [B * i // P for i in range(P + 1)]
-        main = torch.cuda.current_stream(dev)
-        side = ops._side_stream(dev)
-        bg = ops.background_wgs(dev)
-        kicks = ops._bg_kicks_expected
-        parts_v = max(1, min(8, (V + 127) // 128))
-        block = max(1, bg // parts_v)               # token tiles per full round of background workgroups
-        st = []                                     # per part: h (graph), closures, results
-
-        def fwd_closures(h_d, lab_i, wt, b, res):
-            ntt = (h_d.shape[0] + 127) // 128
-            nblk = -(-ntt // block)
-            npieces = max(1, min(kicks + 1, nblk))
-            cuts = [min(ntt, block * (nblk * j // npieces)) for j in range(npieces)] + [ntt]
-
-            def sweep(lo, hi):
-                return lambda: ops.vocab_ce_fwd_sweep(h_d, wt, b, V, code, parts_v, lo, hi, bg)
-
-            def combine():
-                res['out'] = ops.vocab_ce_fwd_combine(h_d, wt, b, lab_i, scale, V, code, parts_v)
-                res['ev'] = torch.cuda.current_stream().record_event()
-            return [sweep(cuts[j], cuts[j + 1]) for j in range(npieces) if cuts[j + 1] > cuts[j]] + [combine]
-
-        # ---- forward of every part on the main stream; the first part's sweeps start beside the next part's encoder --------
-        for i in range(P):
-            b0, b1 = bounds[i], bounds[i + 1]
-            sub = {k: v[b0:b1] for k, v in inputs.items()}
-            n_i = counts[i] if counts is not None else None
-            pk = self._use_packed(sub, None, n_i)
-            rows, lab_i = self._masked_rows(sub, True, None, cap=(b1 - b0) * M, labels_padded=lab[b0:b1], pack=pk, n_real_tokens=n_i)
-            poison = self._packed.ids_packed if (self._packed is not None and n_i is not None) else None
-            h = head.trunk(rows)
-            h_d = h.detach().contiguous()
-            wt, _, b = pack.get(h_d.dtype, K, False)
-            for t in (h_d, lab_i, wt, b, scale):
-                if t is not None:
-                    t.record_stream(side)
-            res = {}
-            cl = fwd_closures(h_d, lab_i, wt, b, res)
-            st.append({'h': h, 'h_d': h_d, 'lab': lab_i, 'wt': wt, 'b': b, 'res': res, 'fwd': cl, 'poison': poison})
-            if i == 0:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    ops.vocab_ce_fwd_sweep(h_d, wt, b, V, code, parts_v, 0, (h_d.shape[0] + 127) // 128, bg)
-                    cl[-1]()
-                cl.clear()
-
-        # ---- backward, part by part; the queue feeds the side stream at the start of a pass and behind every attention backward
-        def dw_closures(s):
-            item, dh, rowscal = s['res']['out']
-            cuts = [((V + 127) // 128) * j // (kicks + 1) for j in range(kicks + 2)]      # equal pieces: the slots share them out
-            return ops._dw_pieces(s['h_d'], s['wt'], s['b'], s['lab'], rowscal, V, kernel, bias, cuts)
-
-        losses = []
-        try:
-            ops._bg_slots = P * (kicks + 1)
-            n_dw = kicks + 1
-            for i in range(P):
-                s = st[i]
-                if 'ev' not in s['res']:                     # its combine is still queued: everything up to it goes out now
-                    ops._background_drain(until=s['fwd'][-1] if s['fwd'] else None)
-                main.wait_event(s['res']['ev'])
-                item, dh, rowscal = s['res']['out']
-                for t in (item, dh, rowscal):
-                    t.record_stream(main)
-                nxt = st[i + 1]['fwd'] if i + 1 < P else []
-                ops._bg_queue.extend(nxt)
-                ops._bg_queue.extend(dw_closures(s))
-                ops._bg_future = sum(len(st[j]['fwd']) for j in range(i + 2, P)) + n_dw * (P - 1 - i)
-                ops._ready_gate = i < P - 1
-                ops.background_pass_begin()
-                ops._background_slot()
-                torch.autograd.backward([s['h']], [dh])
-                ops.flush_pending_dw()
-                ops.background_pass_end()
-                losses.append(ops.sum_scaled(item, scale, s['poison']))
-                s['h'] = None
-        except BaseException:
-            del ops._bg_queue[:]            # closures of a step that failed must not run inside a later one
-            ops._bg_counting = False
-            raise
-        finally:
-            ops._ready_gate = False
-        ops.join_side_work()
-        loss = losses[0]
-        for x in losses[1:]:
-            loss = loss + x
-        return loss.detach()
 
     @torch.no_grad()
     def predict_topk(self, inputs, k, labels=None, flat_idx=None, packed=None, n_real_tokens=None):
@@ -509,7 +393,15 @@ class ClickstreamTransformer(nn.Module):
             if lab.dim() == 2:
                 lab = lab[lab != -1.0]
             lab = lab.to(torch.int32).contiguous()
-        return ops.topk_rows(logits, self.head.output_vocab_size, k, lab)
+        idx, hit, ndcg = ops.topk_rows(logits, self.head.output_vocab_size, k, lab)
+        if self._packed is not None and n_real_tokens is not None:
+            # a caller-given token count that the device's own contradicts: ids -1, hit / ndcg NaN (no read-back)
+            flag = self._packed.ids_packed
+            ops.poison_rows(idx, flag)
+            if hit is not None:
+                ops.poison_rows(hit.view(-1, 1), flag)
+                ops.poison_rows(ndcg.view(-1, 1), flag)
+        return idx, hit, ndcg
 
     def get_serving_signature(self):
         names = []

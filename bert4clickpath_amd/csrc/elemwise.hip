@@ -7,6 +7,8 @@
 // gfx950, wave64, 16-byte accesses; one workgroup per row for the vocabulary-wide kernels.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #define KERAS_EPS 1e-7f
@@ -826,6 +828,31 @@ extern "C" int b4c_rows_add(void *dst, int ld_dst, const int32_t *idx, const voi
         rows_add_kernel<bf16_t, float><<<grid, 256, 0, st>>>((bf16_t *)dst, ld_dst, idx, (const float *)src, ld_src, n_src, width);
     else B4C_REQUIRE(false, "rows_add: dtype %d", dtype);
     return b4c_check_launch("rows_add");
+}
+
+// x[rows][width] := NaN when the device flag is negative, untouched (not even read) otherwise: how a scoring path reports a
+// caller-given count that disagrees with the device's own (include/b4c.h b4c_poison_rows) without a read-back
+template <typename T>
+__global__ void __launch_bounds__(256) poison_rows_kernel(T *__restrict__ x, int ld, int64_t rows, int width, const int32_t *__restrict__ flag) {
+    if (flag[0] >= 0) return;
+    const int64_t total = rows * width;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / width;
+        if constexpr (std::is_same<T, int32_t>::value) x[r * ld + (i - r * width)] = -1;
+        else x[r * ld + (i - r * width)] = (T)__builtin_nanf("");
+    }
+}
+
+extern "C" int b4c_poison_rows(void *x, int ld, int64_t rows, int width, const int32_t *flag, int dtype, void *stream) {
+    B4C_REQUIRE(x && flag && rows >= 0 && width > 0 && ld >= width, "poison_rows: bad argument");
+    if (rows == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(rows * width, 256);
+    if (dtype == B4C_F32) poison_rows_kernel<float><<<grid, 256, 0, st>>>((float *)x, ld, rows, width, flag);
+    else if (dtype == B4C_BF16) poison_rows_kernel<bf16_t><<<grid, 256, 0, st>>>((bf16_t *)x, ld, rows, width, flag);
+    else if (dtype == B4C_I32) poison_rows_kernel<int32_t><<<grid, 256, 0, st>>>((int32_t *)x, ld, rows, width, flag);
+    else B4C_REQUIRE(false, "poison_rows: dtype %d", dtype);
+    return b4c_check_launch("poison_rows");
 }
 
 // ------------------------------------------------------------------------------------------------------------------

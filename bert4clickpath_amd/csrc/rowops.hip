@@ -24,7 +24,7 @@ int b4c_check_launch(const char *what) {
     return B4C_OK;
 }
 extern "C" const char *b4c_last_error(void) { return g_err; }
-extern "C" int b4c_abi_version(void) { return 7; }
+extern "C" int b4c_abi_version(void) { return 8; }
 extern "C" int b4c_keep(uint64_t seed, uint64_t e, float rate) { return b4c_keep_elem(seed, e, rate) ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------
@@ -582,12 +582,14 @@ __global__ void __launch_bounds__(256) mask_count_kernel(const int64_t *__restri
     if (lane == 0) counts[wave] = c;
 }
 
-// clamp >= 0: offsets are clamped to it (the packed layout's caller-given token count: a wrong count must never index past
-// the tensors that were sized by it) and maxcount[0] is NEGATED when the true total differs from it (a poison flag the host
-// folds into the loss without a read-back)
+// clamp >= 0: offsets are clamped to it (a caller-given row count -- the packed layout's token count, the sync-free Cloze
+// path's B x max_masked_per_row -- must never index past the tensors that were sized by it) and maxcount[0] is NEGATED
+// when the true total differs from it (EXACT) or exceeds it (!EXACT): a poison flag the host folds into the loss without a
+// read-back; `poison` (optional) is set to -1 in the same case
+template <bool EXACT>
 __global__ void __launch_bounds__(1024) mask_scan_kernel(const int32_t *__restrict__ counts, int B,
                                                          int32_t *__restrict__ offsets, int32_t *__restrict__ maxcount,
-                                                         int32_t clamp = -1) {
+                                                         int32_t clamp, int32_t *__restrict__ poison) {
     __shared__ int32_t part[1024];
     __shared__ int32_t pmax[1024];
     const int tid = threadIdx.x;
@@ -609,7 +611,9 @@ __global__ void __launch_bounds__(1024) mask_scan_kernel(const int32_t *__restri
     if (tid == 1023) {
         const int32_t total = part[1023];
         offsets[B] = (clamp >= 0 && total > clamp) ? clamp : total;
-        if (maxcount) maxcount[0] = (clamp >= 0 && total != clamp) ? -pmax[1023] - 1 : pmax[1023];
+        const bool bad = clamp >= 0 && (EXACT ? total != clamp : total > clamp);
+        if (maxcount) maxcount[0] = bad ? -pmax[1023] - 1 : pmax[1023];
+        if (poison && bad) poison[0] = -1;
     }
 }
 
@@ -633,13 +637,14 @@ __global__ void __launch_bounds__(256) mask_write_kernel(const int64_t *__restri
 }
 
 extern "C" int b4c_mask_positions(const int64_t *ids, int B, int S, int64_t value, int32_t *counts, int32_t *offsets,
-                                  int32_t *flat_idx, int32_t cap, int32_t *maxcount, void *stream) {
+                                  int32_t *flat_idx, int32_t cap, int32_t *maxcount, int32_t *poison, void *stream) {
     B4C_REQUIRE(ids && counts && offsets && flat_idx && B > 0 && S > 0 && cap >= 0, "mask_positions: bad argument");
     B4C_REQUIRE((int64_t)B * S < (1ll << 31), "mask_positions: B*S must fit int32");
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)ceil_div64((int64_t)B * 64, 256);
     mask_count_kernel<false><<<grid, 256, 0, st>>>(ids, B, S, value, counts);
-    mask_scan_kernel<<<1, 1024, 0, st>>>(counts, B, offsets, maxcount);
+    // more matches than `cap` rows: the offsets stay inside the cap (consumers size their row tensors by it) and the flags say so
+    mask_scan_kernel<false><<<1, 1024, 0, st>>>(counts, B, offsets, maxcount, cap, poison);
     mask_write_kernel<false><<<grid, 256, 0, st>>>(ids, B, S, value, offsets, flat_idx, cap, nullptr);
     return b4c_check_launch("mask_positions");
 }
@@ -654,7 +659,7 @@ extern "C" int b4c_nonpad_positions(const int64_t *ids, int B, int S, int64_t pa
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)ceil_div64((int64_t)B * 64, 256);
     mask_count_kernel<true><<<grid, 256, 0, st>>>(ids, B, S, pad_value, counts);
-    mask_scan_kernel<<<1, 1024, 0, st>>>(counts, B, cu_seqlens, maxcount, cap);
+    mask_scan_kernel<true><<<1, 1024, 0, st>>>(counts, B, cu_seqlens, maxcount, cap, nullptr);
     mask_write_kernel<true><<<grid, 256, 0, st>>>(ids, B, S, pad_value, cu_seqlens, token_src, cap, packed_of);
     return b4c_check_launch("nonpad_positions");
 }

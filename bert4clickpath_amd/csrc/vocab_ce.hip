@@ -10,8 +10,9 @@
 //            attention with V = W): p' = 2^(x log2e - m2) feeds  U = P' W  from the accumulator registers (the
 //            P'^T tile is the B operand of the next MFMA); per row: m2, l = sum p', min x, max x -> lse, clip flag
 //   sweep 1b (vce_token_kernel<K,2>)  only for rows whose probabilities leave [1e-7, 1-1e-7] (TF's clip,
-//            backend.py sparse_categorical_crossentropy): Ud = P (1-u) W, S = sum clip(p), Pu = sum u p
-//   combine  (one wave per row)  loss, dh = gs (Uc / S - G U - yd W_y), row scalars for sweep 2
+//            backend.py sparse_categorical_crossentropy), against the row's final lse: Ud = P (1-u) W, Pc = sum (1-u) p,
+//            nu = sum u  (u = 1 inside the clip range);  Pu = 1 - Pc,  S = sum clip(p) = Pu + 1e-7 n_low + (1 - 1e-7) n_high
+//   combine  (one wave per row)  loss, dh = gs ((U - Ud) / S - G U - yd W_y), row scalars for sweep 2
 //   sweep 2  (vocabulary-owned, vce_dw_kernel)  dlogit = p (u a - b) feeds  dW^T = h^T dlogit  from registers;
 //            db = column sums
 //   label term  dW[:, y] -= yd h_row, db[y] -= yd  (coalesced scatter into a vocabulary-major scratch, added transposed)
@@ -127,20 +128,20 @@ struct VceArgs {
     const float *grad_scale;   // device scalar: d(total loss) / d(row loss)
     float *st1;           // [parts][R][4]: m2 (log2-domain reference), l = sum 2^(x log2e - m2), min x, max x
     float *u;             // [parts][R][KD]: sum 2^(x log2e - m2) W   (un-normalised P W)
-    float *ud;            // [parts][R][KD]: sum over clipped p of p W (normalised)
-    float *sp;            // [parts][R][2]: S, Pu
+    float *ud;            // [parts][R][KD]: Ud = sum over the p outside the clip range of p W (normalised)
+    float *sp;            // [parts][R][4]: nu (entries inside the clip range), Pc (sum of the p outside it), nhi (entries above it), -
     float *rowscal;       // [R][8]: lse2, c = a - b, nb = -b, lo (clip range, -inf / +inf on rows that stay inside), yd, hi, -, -
     float *item_loss;     // [R]
     bf16_t *dh;           // [R][ld_dh]
     int ld_h, ld_w, ld_dh;
     int64_t R;
     int V, parts, variant;
-    int tt0, ntt;         // the 128-token tiles [tt0, tt0 + ntt) this launch sweeps
+    int ntt;              // 128-token tiles
 };
 
 // merge the per-part statistics of one row: lse2 = log2 sum_j 2^(x_j log2e), clipped flag, and (optionally) the
 // factor f_p = 2^(m2_p - M2) / l that turns part p's un-normalised sums into probabilities
-__device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, float &lse2, bool &clipped) {
+__device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, float &lse2, bool &clipped, float &pmax) {
     float M = -INFINITY, l = 0.f, mn = INFINITY, mx = -INFINITY;
     for (int p = 0; p < a.parts; ++p) {
         const f32x4 s = *reinterpret_cast<const f32x4 *>(a.st1 + ((int64_t)p * a.R + row) * 4);
@@ -151,7 +152,8 @@ __device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, flo
         mx = fmaxf(mx, s[3]);
     }
     lse2 = M + __log2f(l);
-    const float pmin = __builtin_amdgcn_exp2f(mn * VCE_LOG2E - lse2), pmax = __builtin_amdgcn_exp2f(mx * VCE_LOG2E - lse2);
+    const float pmin = __builtin_amdgcn_exp2f(mn * VCE_LOG2E - lse2);
+    pmax = __builtin_amdgcn_exp2f(mx * VCE_LOG2E - lse2);
     clipped = (a.variant == B4C_CE_TF) && (pmin < VCE_EPS || pmax > 1.0f - VCE_EPS);
 }
 
@@ -161,44 +163,46 @@ __device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, flo
 //   MODE 1: online softmax (as flash attention with V = W): p' = 2^(x log2e - m2) against a lazily updated
 //           per-token reference m2 (raised, with U and l rescaled, only when a logit exceeds it by 2^12), P'^T
 //           feeds U += W^T P'^T from the accumulator registers.  One sweep gives lse and P W.
-//   MODE 2: second sweep for the tokens whose probabilities leave [1e-7, 1 - 1e-7]: Ud = P (1 - u) W, S, Pu.
+//   MODE 2: second sweep for the tokens whose probabilities leave [1e-7, 1 - 1e-7], against the row's final lse:
+//           Ud = P (1 - u) W (the part OUTSIDE the clip range), Pc = sum (1 - u) p, nu = sum u.  The clipped sum follows
+//           from the counts (Pu = 1 - Pc, S = Pu + eps n_low + (1 - eps) n_high: vce_combine_kernel) -- per entry: exp,
+//           compare, select, add, count (accumulating S, Pu and the clipped part took eight VALU instructions per entry,
+//           this takes six).  Ud and not Uu: in dh = ((U - Ud) / S - G U - ...) every product with U keeps ONE bf16
+//           rounding of P (sweep 1's), so the O(1) terms cancel exactly where the true gradient is ~0 (a confident wrong
+//           row: G ~ 1); with Uu from this sweep's own rounding of P they would leave 2^-9 |W| behind.
 //   MODE 0: the statistics of MODE 1 alone (m2, l -> lse; no U, no min / max): the lse sweep in front of the
 //           materialised softmax projection (b4c_vocab_lse).
 // ------------------------------------------------------------------------------------------
 #define VCE_LAZY 12.0f
+#ifndef VCE_FRAG_BATCH
+#define VCE_FRAG_BATCH 1
+#endif
 
-template <int KD, int MODE, int VH>
-__global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
-    // VH = 2: 8 waves = 4 token groups x the 2 vocabulary halves of each 128-row W tile, one (token tile, vocabulary part)
-    // unit per workgroup.  VH = 1 (background form, as vce_dw_kernel<KD, 1>): 4 waves, one per SIMD, each taking both
-    // halves in turn; at most one workgroup per CU walks the units of the token tiles [tt0, tt0 + ntt).
+template <int KD, int MODE>
+__global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NKS = KD / 16, NDT = KD / 32, STR = VTile<KD>::STR;
     constexpr int TILE_B = VTile<KD>::BYTES;
-    constexpr int NT = 256 * VH, NH = 2 / VH;                         // threads; W-tile halves per wave
     float *sBias = reinterpret_cast<float *>(smem + 2 * TILE_B);     // [2][128]
-    const int nunits = a.ntt * a.parts;
-    int unit = blockIdx.x;
-    do {          // VH = 2: one unit per workgroup, no loop
-    int opaque0 = 0;
-    if (VH == 1) asm volatile("s_mov_b32 %0, 0" : "=s"(opaque0));      // (see vce_dw_kernel)
-    const int tid = threadIdx.x + opaque0, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int unit = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int li = lane & 15, g = lane >> 4;
     const int tg = wave & 3, vh = wave >> 2;
-    const int64_t tok0 = (int64_t)(a.tt0 + unit % a.ntt) * 128;
+    const int64_t tok0 = (int64_t)(unit % a.ntt) * 128;
     const int64_t tok = tok0 + tg * 32 + r;
     const int part = unit / a.ntt;
     const int nvt = (a.V + 127) >> 7;
     const int vt0 = (int)((int64_t)nvt * part / a.parts), vt1 = (int)((int64_t)nvt * (part + 1) / a.parts);
 
     float lse2 = INFINITY;   // MODE 2: log2-domain lse of the lane's token
-    bool skip = false;
+    bool anyhi = false;      // MODE 2: some token of this tile has a probability above 1 - 1e-7
     if (MODE == 2) {
         bool clipped = false;
-        if (tok < a.R) vce_row_stats(a, tok, lse2, clipped);
-        skip = !__syncthreads_or(clipped);          // no clipped row in these 128 tokens
+        float pmax = 0.f;
+        if (tok < a.R) vce_row_stats(a, tok, lse2, clipped, pmax);
+        if (!__syncthreads_or(clipped)) return;          // no clipped row in these 128 tokens (block-uniform)
+        anyhi = __syncthreads_or(pmax > 1.0f - VCE_EPS);
     }
-    if (!skip) {
     bf16x8 hfr[NKS];
     vce_load_hfrag<KD>(a.h, a.ld_h, tok, a.R, hf, hfr);
     int foff[NKS], toff[NDT][2];
@@ -213,7 +217,7 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
     // tile vt -> LDS buffer `buf` (DMA), its bias -> a register (stored to LDS after the current tile's reads)
     float breg = 0.f;
     auto fetch = [&](int vt, int buf) {
-        VTile<KD>::template dma<NT>(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, smem + buf * TILE_B, tid);
+        VTile<KD>::template dma<512>(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, smem + buf * TILE_B, tid);
         if (tid < 128) {
             const int v = vt * 128 + tid;
             breg = (vt < vt1 && v < a.V) ? (a.bias ? a.bias[v] : 0.f) : -INFINITY;   // rows past V: logit = -inf
@@ -226,7 +230,8 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
 
     // running state of the lane's token over its (hf, vh) share of the vocabulary
     float m2 = -INFINITY, l = 0.f, mn = INFINITY, mx = -INFINITY;   // MODE 1
-    float S = 0.f, Pu = 0.f;                                        // MODE 2
+    float Pc = 0.f;                                                 // MODE 2: sum of the probabilities outside the clip range
+    unsigned nu = 0, nhi = 0;                                       // MODE 2: entries inside / above the clip range
     f32x16 U[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
@@ -238,17 +243,45 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
     auto tile = [&](auto BUF, int vt) {
         constexpr int buf = decltype(BUF)::value;
         fetch(vt + 1, buf ^ 1);        // the other buffer was last read one tile ago (behind the previous barrier)
-#pragma unroll
-        for (int hv = 0; hv < NH; ++hv) {            // VH = 1: the wave takes the tile's two 64-row halves in turn
-        const int vhe = VH == 2 ? vh : hv;           // which half (offsets of a VH = 1 wave carry vh = 0: + hv * 64 rows)
-        const char *w = smem + buf * TILE_B + (VH == 2 ? 0 : hv * 64 * STR);
+        const char *w = smem + buf * TILE_B;
         const float *bs = sBias + buf * 128;
         f32x16 acc[2];
+#if VCE_FRAG_BATCH
+        // The W fragments of a 32-row tile are fetched as a batch in front of its MFMA chain, and the second tile's while
+        // the first chain runs (left to itself the compiler sends every fragment through one register quad: ds_read_b128 ->
+        // s_waitcnt lgkmcnt(0) -> v_mfma, sixteen times).  Same MFMA order: bit-identical results; 1.5 - 3 % per sweep.
+        {
+            bf16x8 wfq[NKS];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vh * 64 + rt * 32 + 8 * tq + 4 * hf);
+                    acc[rt][4 * tq] = b4[0]; acc[rt][4 * tq + 1] = b4[1]; acc[rt][4 * tq + 2] = b4[2]; acc[rt][4 * tq + 3] = b4[3];
+                }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) wfq[ks] = *reinterpret_cast<const bf16x8 *>(w + foff[ks]);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfq[ks], hfr[ks], acc[0], 0, 0, 0);
+                wfq[ks] = *reinterpret_cast<const bf16x8 *>(w + 32 * STR + foff[ks]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfq[ks], hfr[ks], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 + NKS, 0);         // bias quads + the first tile's fragments
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NKS, 0);
+        }
+#else
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
             for (int tq = 0; tq < 4; ++tq) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vhe * 64 + rt * 32 + 8 * tq + 4 * hf);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vh * 64 + rt * 32 + 8 * tq + 4 * hf);
                 acc[rt][4 * tq] = b4[0]; acc[rt][4 * tq + 1] = b4[1]; acc[rt][4 * tq + 2] = b4[2]; acc[rt][4 * tq + 3] = b4[3];
             }
 #pragma unroll
@@ -257,9 +290,10 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
                 acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hfr[ks], acc[rt], 0, 0, 0);
             }
         }
-        const bool tail = (vt + 1) * 128 > a.V;      // some rows of this tile are past V (their logit is -inf)
+#endif
         float e2 = lse2;                             // the exponent reference of this tile
         if (MODE != 2) {
+            const bool tail = (vt + 1) * 128 > a.V;      // some rows of this tile are past V (their logit is -inf)
             float tm = -INFINITY;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -276,7 +310,7 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int t = 0; t < 16; ++t)
-                        if (vt * 128 + vhe * 64 + rt * 32 + vce_rowmap(t, hf) < a.V) mn = fminf(mn, acc[rt][t]);
+                        if (vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V) mn = fminf(mn, acc[rt][t]);
             }
             tm = fmaxf(tm, __shfl_xor(tm, 32));      // the two lanes of a token share the reference (their P mix in U)
             mx = fmaxf(mx, tm);
@@ -301,15 +335,15 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
         for (int rt = 0; rt < 2; ++rt) {
             __builtin_amdgcn_sched_barrier(0);       // keep one 32-row tile's temporaries live at a time
             float p[16];
-            if (MODE == 2 && tail) {                 // the last tile only (wave-uniform): rows past V must not count
+            if (MODE == 2 && anyhi) {                // (block-uniform, rare) a probability above 1 - 1e-7 is clipped as well
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
-                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -e2));
-                    const bool valid = vt * 128 + vhe * 64 + rt * 32 + vce_rowmap(t, hf) < a.V;
-                    const float pc = __builtin_amdgcn_fmed3f(pv, VCE_EPS, 1.0f - VCE_EPS);
-                    const bool un = pc == pv;              // inside the clip range
-                    if (valid) { S += pc; Pu += un ? pv : 0.f; }
-                    p[t] = (un || !valid) ? 0.f : pv;      // the clipped part feeds Ud
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -e2));
+                    const bool un = __builtin_amdgcn_fmed3f(pv, VCE_EPS, 1.0f - VCE_EPS) == pv;
+                    p[t] = un ? 0.f : pv;
+                    Pc += p[t];
+                    nu += un ? 1u : 0u;
+                    nhi += pv > 1.0f - VCE_EPS ? 1u : 0u;      // counted HERE, on the value the test above saw
                 }
             } else {
 #pragma unroll
@@ -319,13 +353,11 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
                         l += pv;
                         p[t] = pv;
                     } else {
-                        // the per-entry validity test of the tail path costs a compare, two selects and a spilled lane
-                        // mask per entry: with it the clipped sweep ran 18 VALU slots per entry, without it 11
-                        const float pc = __builtin_amdgcn_fmed3f(pv, VCE_EPS, 1.0f - VCE_EPS);
-                        const float pu = (pc == pv) ? pv : 0.f;    // inside the clip range
-                        S += pc;
-                        Pu += pu;
-                        p[t] = pv - pu;                            // the clipped part feeds Ud (exact: pv - pv or pv - 0)
+                        // rows past V carry logit -inf: p = 0, below the range, adds nothing, not counted -- no validity test
+                        const bool un = pv >= VCE_EPS;
+                        p[t] = un ? 0.f : pv;              // the part OUTSIDE the clip range feeds Ud
+                        Pc += p[t];
+                        nu += un ? 1u : 0u;
                     }
                 }
             }
@@ -342,7 +374,6 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
                 }
             }
         }
-        }
         if (tid < 128) sBias[(buf ^ 1) * 128 + tid] = breg;
         VCE_DMA_WAIT();
         B4C_LDS_BARRIER();
@@ -353,7 +384,7 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
     }
     __syncthreads();   // all tiles consumed: LDS is reused below
 
-    // U^T tiles -> LDS [token][d] per wave; per-lane scalars -> LDS; then the two vocabulary halves (VH = 2) and the two
+    // U^T tiles -> LDS [token][d] per wave; per-lane scalars -> LDS; then the two vocabulary halves and the two
     // lanes of each token are merged and stored row-major
     constexpr int USTR = KD + 4;                         // floats per token row
     float *sU = reinterpret_cast<float *>(smem) + wave * 32 * USTR;
@@ -365,26 +396,24 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
             const f32x4 v = {U[dt][4 * tq], U[dt][4 * tq + 1], U[dt][4 * tq + 2], U[dt][4 * tq + 3]};
             *reinterpret_cast<f32x4 *>(sU + r * USTR + dt * 32 + 8 * tq + 4 * hf) = v;
         }
-    f32x4 *sS = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(smem) + 4 * VH * 32 * USTR);   // [wave][lane]
-    sS[wave * 64 + lane] = (MODE != 2) ? (f32x4){m2, l, mn, mx} : (f32x4){S, Pu, 0.f, 0.f};
+    f32x4 *sS = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(smem) + 8 * 32 * USTR);   // [wave][lane]
+    sS[wave * 64 + lane] = (MODE != 2) ? (f32x4){m2, l, mn, mx} : (f32x4){(float)nu, Pc, (float)nhi, 0.f};
     __syncthreads();
-    // token t of the tile: waves (t >> 5) and, VH = 2, (t >> 5) + 4; lanes (t & 31) and (t & 31) + 32
+    // token t of the tile: waves (t >> 5) and (t >> 5) + 4; lanes (t & 31) and (t & 31) + 32
     float *dst = (MODE == 1 ? a.u : a.ud) + (int64_t)part * a.R * KD;
     if (MODE != 0)
-    for (int c = tid; c < 128 * (KD / 4); c += NT) {
+    for (int c = tid; c < 128 * (KD / 4); c += 512) {
         const int t = c / (KD / 4), q = c % (KD / 4);
         if (tok0 + t < a.R) {
             const float *p0 = reinterpret_cast<const float *>(smem) + t * USTR + q * 4;
             f32x4 v0 = *reinterpret_cast<const f32x4 *>(p0);
-            if (VH == 2) {
-                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(p0 + 4 * 32 * USTR);
-                if (MODE == 1) {
-                    const float ma = sS[(t >> 5) * 64 + (t & 31)][0], mb = sS[((t >> 5) + 4) * 64 + (t & 31)][0];
-                    const float M = fmaxf(ma, mb);
-                    v0 = v0 * __builtin_amdgcn_exp2f(ma - M) + v1 * __builtin_amdgcn_exp2f(mb - M);
-                } else {
-                    v0 = v0 + v1;
-                }
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(p0 + 4 * 32 * USTR);
+            if (MODE == 1) {
+                const float ma = sS[(t >> 5) * 64 + (t & 31)][0], mb = sS[((t >> 5) + 4) * 64 + (t & 31)][0];
+                const float M = fmaxf(ma, mb);
+                v0 = v0 * __builtin_amdgcn_exp2f(ma - M) + v1 * __builtin_amdgcn_exp2f(mb - M);
+            } else {
+                v0 = v0 + v1;
             }
             *reinterpret_cast<f32x4 *>(dst + (tok0 + t) * KD + q * 4) = v0;
         }
@@ -392,25 +421,18 @@ __global__ void __launch_bounds__(256 * VH, 2) vce_token_kernel(VceArgs a) {
     if (tid < 128 && tok0 + tid < a.R) {
         const int tgi = tid >> 5, ri = tid & 31;
         const f32x4 a0 = sS[tgi * 64 + ri], a1 = sS[tgi * 64 + ri + 32];
-        f32x4 b0 = {-INFINITY, 0.f, INFINITY, -INFINITY}, b1 = {-INFINITY, 0.f, INFINITY, -INFINITY};
-        if (VH == 2) { b0 = sS[(tgi + 4) * 64 + ri]; b1 = sS[(tgi + 4) * 64 + ri + 32]; }
-        else if (MODE == 2) { b0 = (f32x4){0.f, 0.f, 0.f, 0.f}; b1 = b0; }
+        const f32x4 b0 = sS[(tgi + 4) * 64 + ri], b1 = sS[(tgi + 4) * 64 + ri + 32];
         if (MODE != 2) {
             const float M = fmaxf(a0[0], b0[0]);     // the two lanes of a token share m2
-            const float fa = __builtin_amdgcn_exp2f(a0[0] - M), fb = VH == 2 ? __builtin_amdgcn_exp2f(b0[0] - M) : 0.f;
+            const float fa = __builtin_amdgcn_exp2f(a0[0] - M), fb = __builtin_amdgcn_exp2f(b0[0] - M);
             *reinterpret_cast<f32x4 *>(a.st1 + ((int64_t)part * a.R + tok0 + tid) * 4) =
                 (f32x4){M, (a0[1] + a1[1]) * fa + (b0[1] + b1[1]) * fb, fminf(fminf(a0[2], a1[2]), fminf(b0[2], b1[2])),
                         fmaxf(a0[3], b0[3])};
         } else {
-            float *o = a.sp + ((int64_t)part * a.R + tok0 + tid) * 2;
-            o[0] = a0[0] + a1[0] + b0[0] + b1[0];
-            o[1] = a0[1] + a1[1] + b0[1] + b1[1];
+            // (counts: exact in fp32)
+            *reinterpret_cast<f32x4 *>(a.sp + ((int64_t)part * a.R + tok0 + tid) * 4) = a0 + a1 + b0 + b1;
         }
     }
-    }
-    if (VH == 1) __syncthreads();        // the next unit's tiles land in the images this one read
-    unit += gridDim.x;
-    } while (VH == 1 && unit < nunits);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -439,9 +461,9 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
         }
         return;
     }
-    float lse2;
+    float lse2, pmax;
     bool clipped;
-    vce_row_stats(a, row, lse2, clipped);
+    vce_row_stats(a, row, lse2, clipped, pmax);
     const float lse = lse2 * VCE_LN2;
     float U[E], Ud[E], hv[E], wy[E];
     float dot = 0.f;
@@ -454,7 +476,7 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
             // part p's sums are relative to its own reference m2_p: 2^(m2_p - lse2) makes them probabilities
             const float f = __builtin_amdgcn_exp2f(a.st1[((int64_t)p * a.R + row) * 4] - lse2);
             U[e] += f * a.u[((int64_t)p * a.R + row) * KD + d];
-            if (clipped) Ud[e] += a.ud[((int64_t)p * a.R + row) * KD + d];
+            if (clipped) Ud[e] += a.ud[((int64_t)p * a.R + row) * KD + d];     // the second sweep ran against lse2 itself
         }
         hv[e] = (float)a.h[row * a.ld_h + d];
         wy[e] = (float)a.wt[(int64_t)y * a.ld_w + d];
@@ -466,11 +488,15 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
     const float gs = a.grad_scale[0];
     float loss, invS = 1.f, G = 0.f, yd = 1.f;
     if (clipped) {
-        float S = 0.f, Pu = 0.f;
+        float nu = 0.f, Pc = 0.f, nhi = 0.f;
         for (int p = 0; p < a.parts; ++p) {
-            S += a.sp[((int64_t)p * a.R + row) * 2];
-            Pu += a.sp[((int64_t)p * a.R + row) * 2 + 1];
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(a.sp + ((int64_t)p * a.R + row) * 4);
+            nu += q[0]; Pc += q[1]; nhi += q[2];
         }
+        const float Pu = 1.0f - Pc;          // the probabilities are normalised by the row's own lse: they sum to 1
+        // S = sum_j clip(p_j): the nu entries inside the range as they are, those above it (at most one) at 1 - 1e-7,
+        // every other entry at 1e-7
+        const float S = Pu + VCE_EPS * ((float)a.V - nu - nhi) + (1.0f - VCE_EPS) * nhi;
         const float pyc = __builtin_amdgcn_fmed3f(py, VCE_EPS, 1.0f - VCE_EPS);
         const float uy = (pyc == py) ? 1.f : 0.f;
         invS = 1.0f / S;
@@ -782,9 +808,9 @@ static bool vce_shape_ok(int K) { return K == 64 || K == 128; }
 template <typename Kern> static void vce_allow_lds(Kern k, size_t bytes) {
     (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
-template <int KD> static size_t vce_token_lds(int vh = 2) {
+template <int KD> static size_t vce_token_lds() {
     const size_t tiles = 2 * (size_t)VTile<KD>::BYTES + 2 * 128 * 4;
-    const size_t outs = (size_t)4 * vh * 32 * (KD + 4) * 4 + 4 * vh * 64 * 16;
+    const size_t outs = (size_t)8 * 32 * (KD + 4) * 4 + 8 * 64 * 16;
     return tiles > outs ? tiles : outs;
 }
 template <int KD> static size_t vce_dw_lds() {
@@ -795,7 +821,7 @@ template <int KD> static size_t vce_dw_lds() {
 
 extern "C" int64_t b4c_vocab_ce_workspace_bytes(int64_t R, int V, int K) {
     if (R <= 0 || V <= 0 || !vce_shape_ok(K)) return 0;
-    const int64_t fwd = (int64_t)8 * R * (4 + 2 * (int64_t)K + 2) * 4;   // 8 = the largest vocabulary split
+    const int64_t fwd = (int64_t)8 * R * (4 + 2 * (int64_t)K + 4) * 4;   // 8 = the largest vocabulary split
     const int64_t dw = (int64_t)V * K * 4;                              // vocabulary-major scratch of the label term
     return fwd > dw ? fwd : dw;
 }
@@ -812,11 +838,11 @@ static int vce_fwd_launch(VceArgs a, hipStream_t st) {
     const size_t lds = vce_token_lds<KD>();
     static thread_local bool done = false;
     if (!done) {
-        vce_allow_lds(vce_token_kernel<KD, 1, 2>, lds);
-        vce_allow_lds(vce_token_kernel<KD, 2, 2>, lds);
+        vce_allow_lds(vce_token_kernel<KD, 1>, lds);
+        vce_allow_lds(vce_token_kernel<KD, 2>, lds);
         done = true;
     }
-    a.tt0 = 0; a.ntt = (int)ntt;
+    a.ntt = (int)ntt;
     const unsigned grid = (unsigned)(ntt * a.parts);
     // B4C_VCE_TIMING=1: HIP events around the kernels, read back (without synchronising) at the next call
     static const bool dbg = getenv("B4C_VCE_TIMING") != nullptr;
@@ -831,9 +857,9 @@ static int vce_fwd_launch(VceArgs a, hipStream_t st) {
         if (!have) { for (auto &e : ev) (void)hipEventCreate(&e); have = true; }
         (void)hipEventRecord(ev[0], st);
     }
-    vce_token_kernel<KD, 1, 2><<<grid, 512, lds, st>>>(a);
+    vce_token_kernel<KD, 1><<<grid, 512, lds, st>>>(a);
     if (dbg) (void)hipEventRecord(ev[1], st);
-    if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2, 2><<<grid, 512, lds, st>>>(a);
+    if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2><<<grid, 512, lds, st>>>(a);
     if (dbg) (void)hipEventRecord(ev[2], st);
     vce_combine_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a);
     if (dbg) (void)hipEventRecord(ev[3], st);
@@ -858,77 +884,6 @@ extern "C" int b4c_vocab_ce_fwd(const void *h, int ld_h, const void *wt, int ld_
     return K == 128 ? vce_fwd_launch<128>(a, (hipStream_t)stream) : vce_fwd_launch<64>(a, (hipStream_t)stream);
 }
 
-// ---- b4c_vocab_ce_fwd in pieces (ABI 6): the two sweeps over a range of 128-token tiles, foreground or background form,
-// and the combine step; `parts` (1 .. 8, <= vocabulary tiles) is the caller's and the same for every piece and the combine
-template <int KD>
-static void vce_fwd_sweep_launch(VceArgs a, int tt0, int ntt, int background_wgs, hipStream_t st) {
-    a.u = a.st1 + (int64_t)a.parts * a.R * 4;
-    a.ud = a.u + (int64_t)a.parts * a.R * KD;
-    a.sp = a.ud + (int64_t)a.parts * a.R * KD;
-    a.tt0 = tt0; a.ntt = ntt;
-    const int64_t units = (int64_t)ntt * a.parts;
-    static thread_local bool done = false;
-    if (!done) {
-        vce_allow_lds(vce_token_kernel<KD, 1, 2>, vce_token_lds<KD>(2)); vce_allow_lds(vce_token_kernel<KD, 2, 2>, vce_token_lds<KD>(2));
-        vce_allow_lds(vce_token_kernel<KD, 1, 1>, vce_token_lds<KD>(1)); vce_allow_lds(vce_token_kernel<KD, 2, 1>, vce_token_lds<KD>(1));
-        done = true;
-    }
-    if (background_wgs > 0) {
-        const int64_t rounds = ceil_div64(units, background_wgs);
-        const unsigned grid = (unsigned)ceil_div64(units, rounds);
-        vce_token_kernel<KD, 1, 1><<<grid, 256, vce_token_lds<KD>(1), st>>>(a);
-        if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2, 1><<<grid, 256, vce_token_lds<KD>(1), st>>>(a);
-    } else {
-        vce_token_kernel<KD, 1, 2><<<(unsigned)units, 512, vce_token_lds<KD>(2), st>>>(a);
-        if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2, 2><<<(unsigned)units, 512, vce_token_lds<KD>(2), st>>>(a);
-    }
-}
-
-extern "C" int b4c_vocab_ce_fwd_sweep(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, void *workspace,
-                                      int64_t workspace_bytes, int64_t R, int V, int K, int variant, int parts, int tile_begin,
-                                      int tile_end, int background_workgroups, void *stream) {
-    B4C_REQUIRE(h && wt && workspace, "vocab_ce_fwd_sweep: null pointer");
-    B4C_REQUIRE(vce_shape_ok(K), "vocab_ce_fwd_sweep: K=%d unsupported (64 or 128)", K);
-    B4C_REQUIRE(variant == B4C_CE_TF || variant == B4C_CE_PLAIN, "vocab_ce_fwd_sweep: variant %d", variant);
-    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K, "vocab_ce_fwd_sweep: shape");
-    B4C_REQUIRE(ld_h % 8 == 0 && ld_w % 8 == 0 && ((((uintptr_t)h | (uintptr_t)wt | (uintptr_t)workspace) & 15) == 0),
-                "vocab_ce_fwd_sweep: operands must be 16-byte aligned with pitches %% 8 == 0");
-    B4C_REQUIRE(workspace_bytes >= b4c_vocab_ce_workspace_bytes(R, V, K), "vocab_ce_fwd_sweep: workspace too small");
-    const int64_t ntt = ceil_div64(R, 128);
-    B4C_REQUIRE(parts >= 1 && parts <= 8 && parts <= (V + 127) / 128, "vocab_ce_fwd_sweep: parts %d", parts);
-    B4C_REQUIRE(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= ntt, "vocab_ce_fwd_sweep: tiles [%d, %d) of %lld", tile_begin, tile_end, (long long)ntt);
-    B4C_REQUIRE(background_workgroups >= 0, "vocab_ce_fwd_sweep: background_workgroups %d", background_workgroups);
-    if (R == 0 || tile_begin == tile_end) return B4C_OK;
-    VceArgs a = {};
-    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.st1 = (float *)workspace;
-    a.ld_h = ld_h; a.ld_w = ld_w; a.R = R; a.V = V; a.variant = variant; a.parts = parts;
-    if (K == 128) vce_fwd_sweep_launch<128>(a, tile_begin, tile_end - tile_begin, background_workgroups, (hipStream_t)stream);
-    else vce_fwd_sweep_launch<64>(a, tile_begin, tile_end - tile_begin, background_workgroups, (hipStream_t)stream);
-    return b4c_check_launch("vocab_ce_fwd_sweep");
-}
-
-extern "C" int b4c_vocab_ce_fwd_combine(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels, const float *grad_scale,
-                                        float *item_loss, void *dh, int ld_dh, float *rowscal, void *workspace,
-                                        int64_t workspace_bytes, int64_t R, int V, int K, int variant, int parts, void *stream) {
-    B4C_REQUIRE(h && wt && labels && grad_scale && item_loss && dh && rowscal && workspace, "vocab_ce_fwd_combine: null pointer");
-    B4C_REQUIRE(vce_shape_ok(K), "vocab_ce_fwd_combine: K=%d unsupported (64 or 128)", K);
-    B4C_REQUIRE(variant == B4C_CE_TF || variant == B4C_CE_PLAIN, "vocab_ce_fwd_combine: variant %d", variant);
-    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K && ld_dh >= K, "vocab_ce_fwd_combine: shape");
-    B4C_REQUIRE(workspace_bytes >= b4c_vocab_ce_workspace_bytes(R, V, K), "vocab_ce_fwd_combine: workspace too small");
-    B4C_REQUIRE(parts >= 1 && parts <= 8, "vocab_ce_fwd_combine: parts %d", parts);
-    if (R == 0) return B4C_OK;
-    VceArgs a = {};
-    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.labels = labels; a.grad_scale = grad_scale;
-    a.st1 = (float *)workspace; a.rowscal = rowscal; a.item_loss = item_loss; a.dh = (bf16_t *)dh;
-    a.ld_h = ld_h; a.ld_w = ld_w; a.ld_dh = ld_dh; a.R = R; a.V = V; a.variant = variant; a.parts = parts;
-    a.u = a.st1 + (int64_t)parts * R * 4;
-    a.ud = a.u + (int64_t)parts * R * K;
-    a.sp = a.ud + (int64_t)parts * R * K;
-    if (K == 128) vce_combine_kernel<128><<<(unsigned)ceil_div64(R, 4), 256, 0, (hipStream_t)stream>>>(a);
-    else vce_combine_kernel<64><<<(unsigned)ceil_div64(R, 4), 256, 0, (hipStream_t)stream>>>(a);
-    return b4c_check_launch("vocab_ce_fwd_combine");
-}
-
 template <int KD>
 static int vce_lse_launch(VceArgs a, float *lse2, hipStream_t st) {
     const int64_t ntt = ceil_div64(a.R, 128);
@@ -936,9 +891,9 @@ static int vce_lse_launch(VceArgs a, float *lse2, hipStream_t st) {
     a.parts = vce_pick_split(ntt, nvt, 0.005);
     const size_t lds = vce_token_lds<KD>();
     static thread_local bool done = false;
-    if (!done) { vce_allow_lds(vce_token_kernel<KD, 0, 2>, lds); done = true; }
-    a.tt0 = 0; a.ntt = (int)ntt;
-    vce_token_kernel<KD, 0, 2><<<(unsigned)(ntt * a.parts), 512, lds, st>>>(a);
+    if (!done) { vce_allow_lds(vce_token_kernel<KD, 0>, lds); done = true; }
+    a.ntt = (int)ntt;
+    vce_token_kernel<KD, 0><<<(unsigned)(ntt * a.parts), 512, lds, st>>>(a);
     vce_lse_kernel<<<(unsigned)ceil_div64(a.R, 256), 256, 0, st>>>(a, lse2);
     return b4c_check_launch("vocab_lse");
 }

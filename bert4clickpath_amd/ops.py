@@ -437,32 +437,64 @@ def flush_pending_dw():
         _ready(*it[6])
 
 
-# ---- in-place gradient accumulation (arena mode, optim.FlatArena): weight-gradient kernels add with float
-# atomics anyway, so they add straight into param.grad and autograd receives None for those inputs.
-inplace_grads = False
+# ---- per-arena host state ------------------------------------------------------------------------------------------
+# optim.FlatArena re-homes parameters and their gradients into two flat buffers; the weight-gradient kernels then add
+# straight into param.grad (autograd receives None for those inputs).  Everything the host keeps about such a training
+# step -- who is told when a gradient is complete, and the side-stream work of the backward pass in flight -- lives in
+# the arena's ArenaContext, reachable from every parameter of the arena as `p._b4c_ctx`.  Nothing here is process
+# state: two models, with or without an arena, train side by side in one process (tests/test_gpu_context.py).
 flash_ce = True          # bf16 training: vocabulary projection + CE without the (R x V) logits (csrc/vocab_ce.hip)
-_grad_ready_cb = None       # parallel.GradReducer: called with each parameter whose gradient has just been produced
 
 
-def set_grad_ready_callback(cb):
-    global _grad_ready_cb
-    _grad_ready_cb = cb
+class ArenaContext:
+    def __init__(self):
+        self.grad_ready_cb = None     # parallel.GradReducer: called with each parameter whose gradient has just been produced
+        # side-stream work (the vocabulary head's background dW sweep, see "Vocabulary-head weight gradient BESIDE ...")
+        self.queue = []               # closures to run on the side stream, in order: pieces of sweeps, label terms, event records
+        self.pending = []             # (event recorded on the side stream, parameters whose gradient it completes, main stream)
+        self.slots = 0                # launch opportunities left in the current plan (one now, one per attention backward expected)
+        self.counting = False         # inside a backward pass that feeds the queue
+        self.kicks = 0                # attention-backward launches seen in this pass
+        self.kicks_expected = 0       # ... in the previous backward pass: the plan of the next one
+
+    def reset(self):
+        """Drop side-stream work that a failed step left behind (closures hold that step's tensors and would add a stale
+        gradient into the next one).  Called at the start of every step: FlatArena.zero_grad, GradReducer.begin_backward."""
+        global _active_ctx
+        del self.queue[:]
+        del self.pending[:]
+        self.slots = self.kicks = 0
+        self.counting = False
+        if _active_ctx is self:
+            _active_ctx = None
+
+
+_active_ctx = None        # the context whose backward pass is feeding side-stream work right now (attn_bwd -> _background_kick)
+
+
+def arena_context(*params):
+    """The ArenaContext shared by all of `params` whose .grad is a live view of that arena's gradient buffer, else None."""
+    ctx = None
+    for p in params:
+        c = getattr(p, '_b4c_ctx', None)
+        g = p.grad
+        if c is None or (ctx is not None and c is not ctx):
+            return None
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or g.device != p.device:
+            return None
+        ctx = c
+    return ctx
 
 
 def _inplace_ok(*params):
-    if not inplace_grads:
-        return False
-    for p in params:
-        g = p.grad
-        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or g.device != p.device:
-            return False
-    return True
+    return arena_context(*params) is not None
 
 
 def _ready(*params):
-    if _grad_ready_cb is not None and not _ready_gate:
-        for p in params:
-            _grad_ready_cb(p)
+    for p in params:
+        c = getattr(p, '_b4c_ctx', None)
+        if c is not None and c.grad_ready_cb is not None:
+            c.grad_ready_cb(p)
 
 
 def attn_mq_fwd(q, kv, cu, moff, B, max_len, H, dh, key_pad=None):
@@ -621,8 +653,9 @@ def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed, into=None):
     return dz, (dy if dy is not None else dz), dgamma, dbeta
 
 
-def mask_positions(ids, value, cap=None):
-    """-> counts[B], offsets[B+1], flat_idx[cap], maxcount[1] (all int32, device)."""
+def mask_positions(ids, value, cap=None, poison=None):
+    """-> counts[B], offsets[B+1], flat_idx[cap], maxcount[1] (all int32, device).  More matches than `cap`: offsets stay
+    within cap, maxcount comes back negated and the int32 flag `poison` (optional) is set to -1 (include/b4c.h)."""
     _cuda(ids)
     B, S = ids.shape
     cap = B * S if cap is None else cap
@@ -631,9 +664,20 @@ def mask_positions(ids, value, cap=None):
     offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
     flat = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
     mx = torch.empty(1, dtype=torch.int32, device=dev)
-    L.check(L.lib().b4c_mask_positions(_p(ids), B, S, value, _p(counts), _p(offsets), _p(flat), cap, _p(mx), _st()),
+    L.check(L.lib().b4c_mask_positions(_p(ids), B, S, value, _p(counts), _p(offsets), _p(flat), cap, _p(mx), _p(poison), _st()),
             'mask_positions')
     return counts, offsets, flat, mx
+
+
+def poison_rows(x, flag):
+    """x (contiguous last dim) := NaN, in place, when the device flag (int32 [1]) is negative; untouched otherwise."""
+    x2 = x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
+    if x2.numel() and (x2.data_ptr() != x.data_ptr() or x2.stride(1) != 1):
+        raise B4CError('poison_rows: needs a tensor whose leading dimensions merge into rows (got strides %s)' % (x.stride(),))
+    if x2.numel() and flag is not None:
+        code = 2 if x2.dtype == torch.int32 else dt_code(x2.dtype)          # B4C_I32: rows of ids, poisoned with -1
+        L.check(L.lib().b4c_poison_rows(_p(x2), x2.stride(0), x2.shape[0], x2.shape[1], _p(flag), code, _st()), 'poison_rows')
+    return x
 
 
 def padded_index(counts, offsets, flat, B, M):
@@ -755,34 +799,6 @@ def vocab_ce_fwd(h, wt, bias, labels_i32, grad_scale, V, variant=L.CE_TF):
         L.check(L.lib().b4c_vocab_ce_fwd(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(grad_scale),
                                          _p(item), _p(dh), dh.stride(0), _p(rowscal), ws.data_ptr(), ws.numel(), R, V, K,
                                          variant, _st()), 'vocab_ce_fwd')
-    return item, dh, rowscal
-
-
-def vocab_ce_fwd_sweep(h, wt, bias, V, variant, parts, tile_begin, tile_end, background_workgroups=0):
-    """the two sweeps of vocab_ce_fwd for the 128-token tiles [tile_begin, tile_end) of h (partial results in the device's
-    vocabulary-head workspace, laid out for `parts` vocabulary parts); background_workgroups > 0: background kernels"""
-    R, K = h.shape
-    if R == 0 or tile_end <= tile_begin:
-        return
-    ws = _vce_workspace(h, R, V, K)
-    rows = min(R, tile_end * 128) - tile_begin * 128
-    with _record('vocab_ce_fwd_bg' if background_workgroups > 0 else 'vocab_ce_fwd', rows * K * 2 * 2 + V * K * 2, 4 * rows * V * K):
-        L.check(L.lib().b4c_vocab_ce_fwd_sweep(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), ws.data_ptr(), ws.numel(), R, V, K,
-                                               variant, parts, tile_begin, tile_end, background_workgroups, _st()), 'vocab_ce_fwd_sweep')
-
-
-def vocab_ce_fwd_combine(h, wt, bias, labels_i32, grad_scale, V, variant, parts):
-    """-> item_loss [R], dh [R, K], rowscal [R, 8] from the swept partial results (every token tile must have been swept)"""
-    R, K = h.shape
-    item = torch.empty(R, dtype=torch.float32, device=h.device)
-    dh = torch.empty(R, K, dtype=h.dtype, device=h.device)
-    rowscal = torch.empty(R, 8, dtype=torch.float32, device=h.device)
-    if R == 0:
-        return item, dh, rowscal
-    ws = _vce_workspace(h, R, V, K)
-    L.check(L.lib().b4c_vocab_ce_fwd_combine(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(grad_scale),
-                                             _p(item), _p(dh), dh.stride(0), _p(rowscal), ws.data_ptr(), ws.numel(), R, V, K,
-                                             variant, parts, _st()), 'vocab_ce_fwd_combine')
     return item, dh, rowscal
 
 
@@ -1481,6 +1497,10 @@ class MLPFn(torch.autograd.Function):
 # B4C_OVERLAP_DW=0 switches it off (the sweep then runs in the foreground, first thing in backward).
 overlap_vocab_dw = os.environ.get('B4C_OVERLAP_DW', '1') == '1'
 background_workgroups = int(os.environ.get('B4C_VCE_DW_BG', '0'))      # 0: one per CU of the device
+# deterministic_vocab_dw: the projection's dW / db are summed in a fixed order (no float atomics: one workgroup per
+# vocabulary tile walks every token, the label term goes through a stable sort of the rows by label) -- two identical steps
+# give bit-identical arenas.  Default off: the split sweep fills the CUs better (B4C_DETERMINISTIC_DW=1 switches it on).
+deterministic_vocab_dw = os.environ.get('B4C_DETERMINISTIC_DW', '0') == '1'
 
 
 def background_wgs(device):
@@ -1494,14 +1514,6 @@ def background_wgs(device):
 # one (half a layer + the embedding backward)
 background_weights = tuple(float(x) for x in os.environ.get('B4C_VCE_DW_WEIGHTS', '2.2,1.0,0.6').split(','))
 _side_streams = {}
-_side_pending = []          # (event recorded on the side stream, parameters whose gradient it completes)
-_bg_queue = []              # closures to run on the side stream, in order: pieces of sweeps, label terms, event records
-_bg_slots = 0               # launch opportunities left in the current plan (one now, one per attention backward expected)
-_bg_future = 0              # closures the running step will still append (they count when the slots are shared out)
-_bg_counting = False        # inside a backward pass that feeds the queue
-_bg_kicks = 0               # attention-backward launches seen in this pass
-_bg_kicks_expected = 0      # ... in the previous backward pass
-_ready_gate = False         # True: gradients are not announced (an earlier pass of a step that has several)
 
 
 def _side_stream(device):
@@ -1523,74 +1535,71 @@ def _background_plan(n_tiles, kicks):
     return cuts + [n_tiles]
 
 
-def _background_slot():
+def _background_slot(c):
     """One launch opportunity: the queue's head goes out on the side stream, behind everything the main stream has been
-    given so far.  The closures still to come (queued + announced) are shared out evenly over the opportunities left."""
-    global _bg_slots
-    left = max(_bg_slots, 1)
-    _bg_slots = max(_bg_slots - 1, 0)
-    if not _bg_queue:
+    given so far.  The closures still queued are shared out evenly over the opportunities left."""
+    left = max(c.slots, 1)
+    c.slots = max(c.slots - 1, 0)
+    if not c.queue:
         return
-    n = max(1, min(len(_bg_queue), -(-(len(_bg_queue) + _bg_future) // left)))
+    n = max(1, min(len(c.queue), -(-len(c.queue) // left)))
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         for _ in range(n):
-            _bg_queue.pop(0)()
+            c.queue.pop(0)()
 
 
 def _background_kick():
-    global _bg_kicks
-    if not _bg_counting:
+    c = _active_ctx
+    if c is None or not c.counting:
         return
-    _bg_kicks += 1
-    _background_slot()
+    c.kicks += 1
+    _background_slot(c)
 
 
-def _background_drain(until=None):
-    """everything queued (or everything up to and including the closure `until`) goes out on the side stream now"""
-    if not _bg_queue or (until is not None and until not in _bg_queue):
+def _background_drain(c):
+    """everything queued goes out on the side stream now"""
+    if not c.queue:
         return
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        while _bg_queue:
-            c = _bg_queue.pop(0)
-            c()
-            if c is until:
-                break
+        while c.queue:
+            c.queue.pop(0)()
 
 
-def background_pass_begin():
-    global _bg_counting, _bg_kicks
-    _bg_counting, _bg_kicks = True, 0
-
-
-def background_pass_end():
-    """the pass is over: its number of attention launches is the plan of the next one"""
-    global _bg_counting, _bg_kicks_expected
-    if _bg_counting:
-        _bg_counting, _bg_kicks_expected = False, _bg_kicks
-
-
-def join_side_work():
-    """The current stream waits for everything issued on the side stream; the gradients that work produced are then
-    announced (grad-ready callback).  Runs at the end of every backward pass that used the side stream (autograd engine
-    callback); optimizers and reducers call it too -- it is a no-op when nothing is pending."""
-    global _bg_slots, _bg_future
-    background_pass_end()
-    _background_drain()             # fewer attention launches than planned: what is left of the sweeps goes out now
-    _bg_slots = _bg_future = 0
-    while _side_pending:
-        ev, params, stream = _side_pending.pop(0)
+def join_side_work(c):
+    """The current stream waits for everything context `c` issued on the side stream; the gradients that work produced are
+    then announced (grad-ready callback), each parameter once and only after EVERY piece has been waited for.  Runs at the
+    end of every backward pass that used the side stream (autograd engine callback); optimizers and reducers call it too --
+    it is a no-op when nothing is pending."""
+    global _active_ctx
+    if c is None:
+        return
+    if c.counting:                  # the pass is over: its number of attention launches is the plan of the next one
+        c.counting, c.kicks_expected = False, c.kicks
+    _background_drain(c)            # fewer attention launches than planned: what is left of the sweeps goes out now
+    c.slots = 0
+    if _active_ctx is c:
+        _active_ctx = None
+    done, c.pending[:] = list(c.pending), []
+    cur = torch.cuda.current_stream() if done else None
+    for ev, _, stream in done:
         stream.wait_event(ev)               # the stream backward ran on (this may be the engine's thread, with another current stream)
-        torch.cuda.current_stream().wait_event(ev)
-        _ready(*params)
+        cur.wait_event(ev)
+    seen, params = set(), []
+    for _, ps, _ in done:
+        for p in ps:
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+    _ready(*params)
 
 
-def _dw_pieces(h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts):
+def _dw_pieces(c, h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts):
     """closures for the vocabulary tiles cuts[i] .. cuts[i + 1]; the last one adds the label term and records the event that
     completes the projection's gradient"""
     dW, db = kernel.grad, bias.grad
@@ -1606,23 +1615,24 @@ def _dw_pieces(h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts):
             vocab_ce_dw_sweep(h, wt, b, rowscal, V, dW, db, lo, hi, background_wgs(h.device))
             if last:
                 vocab_ce_dw_labels(h, labels_i32, rowscal, V, dW, db)
-                _side_pending.append((torch.cuda.current_stream().record_event(), (kernel, bias), main))
+                c.pending.append((torch.cuda.current_stream().record_event(), (kernel, bias), main))
         return run
     return [piece(lo, hi, i == len(spans) - 1) for i, (lo, hi) in enumerate(spans)]
 
 
-def _queue_background_dw(h, wt, b, labels_i32, rowscal, V, kernel, bias):
+def _queue_background_dw(c, h, wt, b, labels_i32, rowscal, V, kernel, bias):
     """(inside a backward pass) the dW sweep of the vocabulary head as kicks + 1 background pieces: one now, one behind
     every attention backward launch of this pass"""
-    global _bg_slots
-    if _bg_counting or _bg_queue:   # a second head in the same backward pass: finish the first one's sweep first
-        join_side_work()
-    cuts = _background_plan((V + 127) // 128, _bg_kicks_expected)
-    _bg_queue.extend(_dw_pieces(h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts))
-    _bg_slots = len(_bg_queue)
-    background_pass_begin()
-    _background_slot()
-    torch.autograd.Variable._execution_engine.queue_callback(join_side_work)
+    global _active_ctx
+    if _active_ctx is not None and (_active_ctx.counting or _active_ctx.queue):
+        join_side_work(_active_ctx)     # a second head in the same backward pass: finish the first one's sweep first
+    cuts = _background_plan((V + 127) // 128, c.kicks_expected)
+    c.queue.extend(_dw_pieces(c, h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts))
+    c.slots = len(c.queue)
+    c.counting, c.kicks = True, 0
+    _active_ctx = c
+    _background_slot(c)
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: join_side_work(c))
 
 
 class VocabCEFn(torch.autograd.Function):
@@ -1664,9 +1674,10 @@ class VocabCEFn(torch.autograd.Function):
                 _ready(bias)        # the table is announced by the embedding backward, which runs last
                 return dh, None, None, None, None, None, None, None, None
             return dh, None, None, None, None, None, dtab, db, None
-        if _inplace_ok(kernel, bias):
+        actx = arena_context(kernel, bias)
+        if actx is not None:
             if overlap_vocab_dw and h.is_cuda:
-                _queue_background_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel, bias)
+                _queue_background_dw(actx, h, wt, b, labels_i32, rowscal, ctx.V, kernel, bias)
             else:
                 vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel.grad, bias.grad)
                 _ready(kernel, bias)

@@ -28,6 +28,9 @@ class FlatArena:
         self.offsets = offs
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        # host state of this arena's training step (grad-ready callback of a reducer, side-stream work of the backward pass
+        # in flight): per arena, not per process -- ops.ArenaContext
+        self.ctx = ops.ArenaContext()
         with torch.no_grad():
             for p, o in zip(params, offs):
                 if p.dtype != torch.float32:
@@ -36,14 +39,16 @@ class FlatArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
-        # weight-gradient kernels may now add straight into these views (ops.inplace_grads)
-        ops.inplace_grads = True
+                # the weight-gradient kernels may now add straight into this view (ops.arena_context finds the arena's
+                # context through the parameter; a parameter outside any arena gets its gradient through autograd as usual)
+                p._b4c_ctx = self.ctx
 
     def slice_of(self, p):
         i = next(k for k, q in enumerate(self.params) if q is p)
         return self.offsets[i], self.offsets[i] + p.numel()
 
     def zero_grad(self):
+        self.ctx.reset()          # side-stream work a failed step left behind must not add into this step's gradients
         ops.zero_(self.grad)
 
 
@@ -64,7 +69,7 @@ class Adam:
         if not a.flat.is_cuda:
             raise ops.B4CError('Adam.step runs on the HIP device only')
         ops.flush_pending_dw()
-        ops.join_side_work()
+        ops.join_side_work(a.ctx)
         self.iterations += 1
         t = self.iterations
         lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)

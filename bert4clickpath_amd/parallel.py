@@ -106,14 +106,13 @@ class GradReducer:
         self._sizes = [sum(1 for b in self._bucket_of if b == i) for i in range(len(self.buckets))]
         self.overlap = overlap and self.world > 1
         if self.overlap:
-            # gradients reach the arena either through autograd (hook) or straight from the HIP kernels
-            # (ops.inplace_grads -> ops callback); both count a parameter exactly once per backward
-            from . import ops
+            # gradients reach the arena either through autograd (hook) or straight from the HIP kernels (which add in
+            # place and announce through the arena's context); both count a parameter exactly once per backward
             hooks = {}
             for p, b in zip(dense_params, self._bucket_of):
                 hooks[id(p)] = self._make_hook(b)
                 p.register_post_accumulate_grad_hook(hooks[id(p)])
-            ops.set_grad_ready_callback(lambda p: hooks[id(p)](p) if id(p) in hooks else None)
+            arena.ctx.grad_ready_cb = lambda p: hooks[id(p)](p) if id(p) in hooks else None
 
     @property
     def grad_mul(self):
@@ -124,9 +123,6 @@ class GradReducer:
             # a parameter may be announced twice in one backward (by the HIP kernels' in-place callback AND by
             # autograd's post-accumulate hook): count it once, or a bucket would be reduced before it is complete
             if self._pending is None or id(param) in self._seen:
-                return
-            from . import ops
-            if ops._ready_gate:      # an earlier pass of a step that runs several backward passes: not complete yet
                 return
             self._seen.add(id(param))
             self._pending[b] -= 1
@@ -147,6 +143,7 @@ class GradReducer:
 
     def begin_backward(self):
         """Call before loss.backward(): arms the per-bucket countdowns."""
+        self.arena.ctx.reset()        # (a failed step's leftover side-stream work must not announce into this one)
         self._handles = []
         self._seen = set()
         self._next = 0
@@ -156,7 +153,7 @@ class GradReducer:
         """Call after loss.backward(): reduces whatever has not been launched and waits."""
         from . import ops
         ops.flush_pending_dw()          # queued weight-gradient GEMMs (ops.queue_dw) must land before their bucket is reduced
-        ops.join_side_work()            # and so must what runs on the side stream (the vocabulary head's dW sweep)
+        ops.join_side_work(self.arena.ctx)     # and so must what runs on the side stream (the vocabulary head's dW sweep)
         if self.world <= 1:
             self._touched.clear()
             return

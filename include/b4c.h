@@ -29,6 +29,7 @@ extern "C" {
 
 #define B4C_F32 0
 #define B4C_BF16 1
+#define B4C_I32 2    /* (b4c_poison_rows only: int32 rows, poisoned with -1) */
 
 #define B4C_OK 0
 #define B4C_EINVAL (-1)   /* bad argument (shape / alignment / dtype)              */
@@ -204,9 +205,12 @@ int b4c_add_dropout_layernorm_bwd(const void *dout, const void *z, const float *
  * replaces _gather_output_by_raw_value (clickstream_transformer.py:260-297):
  * tf.where(raw == value) row-major, ragged per batch row, gather_nd, to_tensor(0).
  * counts[B], offsets[B+1] (exclusive scan; offsets[B] = R), flat_idx[cap] = b*S+s in row-major
- * order (entries >= R untouched), maxcount[1].  All int32 except ids (int64). */
+ * order (entries >= R untouched), maxcount[1].  All int32 except ids (int64).
+ * More matches than `cap` (a caller-limited row count, e.g. B x max_masked_per_row of the sync-free Cloze path): the
+ * offsets are clamped to cap -- consumers that size their row tensors by cap never index past them -- maxcount[0] comes
+ * back NEGATED and `poison` (optional int32 flag) is set to -1, for the caller to fold into the loss as NaN. */
 int b4c_mask_positions(const int64_t *ids, int B, int S, int64_t value, int32_t *counts, int32_t *offsets,
-                       int32_t *flat_idx, int32_t cap, int32_t *maxcount, void *stream);
+                       int32_t *flat_idx, int32_t cap, int32_t *maxcount, int32_t *poison, void *stream);
 /* padded_idx[B*M] = flat index of the m-th match of row b, or -1 (pad slot). */
 int b4c_padded_index(const int32_t *counts, const int32_t *offsets, const int32_t *flat_idx, int B, int M,
                      int32_t *padded_idx, void *stream);
@@ -263,19 +267,6 @@ int b4c_vocab_ce_dw_sweep(const void *h, int ld_h, const void *wt, int ld_w, con
                           int background_workgroups, void *stream);
 int b4c_vocab_ce_dw_labels(const void *h, int ld_h, const int32_t *labels, const float *rowscal, float *dW, int ldw,
                            float *db, void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, void *stream);
-/* (ABI version 6) b4c_vocab_ce_fwd in pieces, for the same purpose: b4c_vocab_ce_fwd_sweep runs the two sweeps (online
- * softmax + P W; the clipped-row sweep of the TF variant) for the 128-token tiles [tile_begin, tile_end) of h, as the
- * foreground kernels (background_workgroups = 0) or as background kernels (at most that many 256-thread workgroups, one
- * wave per SIMD, walking the (token tile, vocabulary part) units); the partial results go to `workspace`, laid out for
- * `parts` vocabulary parts (1 .. 8, the same value in every piece and in the combine).  b4c_vocab_ce_fwd_combine, once
- * every tile has been swept, writes item_loss, dh and rowscal exactly as b4c_vocab_ce_fwd does. */
-int b4c_vocab_ce_fwd_sweep(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, void *workspace,
-                           int64_t workspace_bytes, int64_t R, int V, int K, int variant, int parts, int tile_begin,
-                           int tile_end, int background_workgroups, void *stream);
-int b4c_vocab_ce_fwd_combine(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
-                             const float *grad_scale, float *item_loss, void *dh, int ld_dh, float *rowscal, void *workspace,
-                             int64_t workspace_bytes, int64_t R, int V, int K, int variant, int parts, void *stream);
-
 /* ---- (ABI version 4) R12 for scoring: Dense(V, softmax) (head.py:36) with ONE pass over the (R x V) tensor ------------------
  * replaces the materialised projection + softmax (b4c_gemm_nt + b4c_softmax_rows: write, read, write) of the
  * bf16 path: b4c_vocab_lse recomputes the logits in MFMA accumulators (nothing reaches HBM) and leaves
@@ -457,6 +448,12 @@ int b4c_chain_ids(const int64_t *const *seqs, const int *lens, const int *pitche
 int b4c_rows_add(void *dst, int ld_dst, const int32_t *idx, const void *src, int ld_src, int64_t n_src, int width, int dtype,
                  int src_dtype, void *stream);   /* dst[idx[r]] += src[r] (idx distinct, < 0 skipped; src may be fp32 beside a
                                                   * bf16 dst): the query rows' gradient joins that of all token rows */
+int b4c_poison_rows(void *x, int ld, int64_t rows, int width, const int32_t *flag, int dtype, void *stream);
+                                                 /* x[rows][width] := NaN (B4C_I32: -1) when flag[0] < 0 (the negated maxcount of
+                                                  * b4c_nonpad_positions / b4c_mask_positions: a caller-given count that the
+                                                  * device's own contradicts), untouched otherwise: the scoring paths' answer to
+                                                  * a wrong n_real_tokens, without a read-back (the loss paths fold the flag
+                                                  * into the loss: b4c_sum_scaled) */
 int b4c_attn_mq_fwd(const void *q, int ld_q, const void *kv, int ld_kv, const uint8_t *key_pad, const int32_t *cu_seqlens,
                     const int32_t *q_offsets, void *o, int ld_o, float *lse, int B, int max_len, int H, int dh, int dtype,
                     void *stream);

@@ -25,8 +25,8 @@ dW, db = torch.zeros(K, V, device=dev), torch.zeros(V, device=dev)
 side = torch.cuda.Stream()
 main = torch.cuda.current_stream()
 nt, nv = (R + 127) // 128, (V + 127) // 128
-bgs = {'dW sweep (vocabulary-owned)': lambda: ops.vocab_ce_dw_sweep(h, wt, bv, rowscal, V, dW, db, 0, nv, 256),
-       'forward sweeps (token-owned)': lambda: ops.vocab_ce_fwd_sweep(h, wt, bv, V, L.CE_TF, 8, 0, nt, 256)}
+# (the token-owned forward sweeps had a background form too until round 3: b4c_vocab_ce_fwd_sweep, retired with cloze_step)
+bgs = {'dW sweep (vocabulary-owned)': lambda: ops.vocab_ce_dw_sweep(h, wt, bv, rowscal, V, dW, db, 0, nv, 256)}
 fgs = {'gemm_nt QKV (T x 384 x 128)': lambda: ops.gemm_nt(x, w384, 384, bias),
        'gemm_nt T x 128 x 128': lambda: ops.gemm_nt(x, w128, 128, bias[:128]),
        'add_ln_fwd': lambda: ops.add_dropout_layernorm_fwd(x, y, gam, bet, 0.1, 7),

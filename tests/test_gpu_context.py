@@ -1,0 +1,135 @@
+"""Host state of a training step is per arena, not per process (bert4clickpath_amd.ops.ArenaContext): who is told when a
+gradient is complete, the side-stream queue of the vocabulary head's background dW sweep, its plan.  Two models -- one
+whose optimizer re-homed it into an arena (in-place weight gradients, background sweep), one trained through plain autograd
+gradients -- take turns in one process and must end where each ends when trained alone.  Also: the device-side guards of the
+sync-free Cloze path (more [MASK] positions than the caller's cap; a wrong n_real_tokens on the scoring paths)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+V, B, S = 3000, 48, 40
+
+
+def _model(seed, layers):
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    torch.manual_seed(seed)
+    return ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': 128},
+                                  SoftMaxHead([64, 128], V), value_to_head='[MASK]', num_encoder_layers=layers,
+                                  num_attention_heads=2, dropout_rate=0.0, compute_dtype=torch.bfloat16).to('cuda')
+
+
+def _batch(seed):
+    from bert4clickpath_amd import input_pipeline
+    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=seed, min_len=6)
+    return (torch.from_numpy(b['ids'])[:, 2:S - 1].contiguous().cuda(), torch.from_numpy(b['labels_padded']).cuda(),
+            int((b['ids'] != 0).sum()))
+
+
+class _PlainAdam:
+    """torch.optim.Adam over the model's own parameters: gradients arrive through autograd (no arena, no in-place kernels)"""
+
+    def __init__(self, model):
+        self.model = model
+        self.opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-9)
+
+    def step_on(self, items, labels, n_real):
+        from bert4clickpath_amd import ops
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.model.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, n_real_tokens=n_real)
+        loss.backward()
+        assert all(getattr(p, '_b4c_ctx', None) is None for p in self.model.parameters())
+        self.opt.step()
+        ops.bump_weights_epoch()            # (torch's optimizer writes the masters behind the packed copies' back)
+        return float(loss)
+
+
+class _ArenaAdam:
+    def __init__(self, model):
+        from bert4clickpath_amd import optim
+        self.model = model
+        self.opt = optim.Adam(model.parameters())
+
+    def step_on(self, items, labels, n_real):
+        self.opt.zero_grad()
+        loss = self.model.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, n_real_tokens=n_real)
+        loss.backward()
+        self.opt.step()
+        return float(loss)
+
+
+def _weights(model):
+    return {n: p.detach().float().clone() for n, p in model.named_parameters()}
+
+
+def test_two_models_take_turns_in_one_process():
+    from bert4clickpath_amd import ops
+    prev = ops.background_workgroups
+    ops.background_workgroups = 8          # (small batch: keep the background sweep's pieces meaningful)
+    try:
+        batches = [_batch(31), _batch(32)]
+        alone = {}
+        for kind, cls, seed, layers in (('arena', _ArenaAdam, 0, 3), ('plain', _PlainAdam, 1, 2)):
+            t = cls(_model(seed, layers))
+            losses = [t.step_on(*batches[i % 2]) for i in range(3)]
+            torch.cuda.synchronize()
+            alone[kind] = (losses, _weights(t.model))
+        a, p = _ArenaAdam(_model(0, 3)), _PlainAdam(_model(1, 2))
+        la, lp = [], []
+        for i in range(3):                   # A, P, A, P, A, P -- and a third model's arena created in between
+            la.append(a.step_on(*batches[i % 2]))
+            if i == 1:
+                _ArenaAdam(_model(2, 1))     # constructing an arena must not change how P (no arena) gets its gradients
+            lp.append(p.step_on(*batches[i % 2]))
+        torch.cuda.synchronize()
+        c = a.opt.arena.ctx
+        assert not c.queue and not c.pending and not c.counting and ops._active_ctx is None
+        assert c.kicks_expected == (2 if ops.mq_last_layer else 3) and c.grad_ready_cb is None
+        for kind, losses, model in (('arena', la, a.model), ('plain', lp, p.model)):
+            l0, w0 = alone[kind]
+            # the arena model's projection gradient is summed with float atomics (background sweep): last bits differ between
+            # runs; everything else is order-fixed
+            assert np.allclose(losses, l0, rtol=1e-4, atol=0), (kind, losses, l0)
+            for n, w in _weights(model).items():
+                if n.endswith('mha.wk.bias'):      # identically-zero gradient (a softmax row is invariant to the key bias):
+                    continue                       # Adam's 1e-9 epsilon turns its rounding noise into +-lr steps
+                assert float((w - w0[n]).abs().max()) <= 2.5e-3, (kind, n)      # <= a couple of Adam steps of lr 1e-3 on noise-sized gradients
+                assert float((w - w0[n]).norm()) <= 2e-2 * float((w0[n]).norm()) + 1e-6, (kind, n)
+    finally:
+        ops.background_workgroups = prev
+
+
+@pytest.mark.parametrize('packed', [True, False])
+def test_more_masks_than_the_cap_poisons_the_loss(packed):
+    """max_masked_per_row smaller than what the batch holds: the masked-query kernels index rows by the [MASK] offsets, which
+    must stay inside the B x max_masked_per_row rows that were allocated (advisor finding, round 2) -- and the loss says so."""
+    from bert4clickpath_amd import ops
+    items, labels, n_real = _batch(41)
+    m = _model(3, 2)
+    assert int((items == 1).sum(1).max()) > 2
+    loss = m.cloze_loss({'asin': items}, labels[:, :2].contiguous(), training=True, max_masked_per_row=2,
+                        n_real_tokens=n_real if packed else None, packed=None if packed else False)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.isnan(float(loss))
+    counts, offsets, flat, mx = ops.mask_positions(torch.cat([items, items], 1).contiguous(), 1, cap=B * 2)
+    assert int(offsets.max()) == B * 2 and int(mx) < 0
+    # within the cap nothing changes
+    loss = m.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, n_real_tokens=n_real if packed else None,
+                        packed=None if packed else False)
+    assert np.isfinite(float(loss))
+
+
+def test_wrong_n_real_tokens_poisons_the_scoring_paths():
+    items, labels, n_real = _batch(43)
+    m = _model(4, 2)
+    with torch.no_grad():
+        good = m({'asin': items}, training=False, max_matches=10, n_real_tokens=n_real)
+        bad = m({'asin': items}, training=False, max_matches=10, n_real_tokens=n_real - 3)
+        top_good, _, _ = m.predict_topk({'asin': items}, 5, labels, n_real_tokens=n_real)
+        top_bad, hit_bad, _ = m.predict_topk({'asin': items}, 5, labels, n_real_tokens=n_real + 5)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(good.float()).all()) and int(top_good.min()) >= 0
+    assert bool(torch.isnan(bad.float()).all())
+    assert bool(torch.isnan(hit_bad).all()) and bool((top_bad == -1).all())

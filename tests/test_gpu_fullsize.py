@@ -303,4 +303,4 @@ def test_c5_shape_slice_runs_on_the_mfma_and_sampled_paths(gpu):
         opt.step()
         assert bool(torch.isfinite(opt.arena.flat).all())
     finally:
-        ops.inplace_grads = False
+        pass          # (an arena no longer changes process state: nothing to restore)

@@ -238,7 +238,6 @@ def test_background_dw_sweep_gives_the_foreground_gradients():
         for layers in (3, 1):               # 1 layer + masked-query last layer: no resident attention backward at all
             for mode in (False, True):
                 ops.overlap_vocab_dw, ops.background_workgroups = mode, 8
-                ops._bg_kicks_expected = 0
                 torch.manual_seed(0)
                 head = SoftMaxHead([64, 128], V)
                 m = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': 128}, head,
@@ -250,12 +249,13 @@ def test_background_dw_sweep_gives_the_foreground_gradients():
                     opt.zero_grad()
                     loss = m.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, n_real_tokens=n_real)
                     loss.backward()
-                    ops.join_side_work()
+                    c = opt.arena.ctx             # the arena's host state: side-stream queue, plan of the next pass
+                    ops.join_side_work(c)
                     torch.cuda.synchronize()
                     out.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
                     if mode:
-                        assert not ops._bg_queue and not ops._bg_counting and not ops._side_pending
-                        assert ops._bg_kicks_expected == (layers - 1 if ops.mq_last_layer else layers)
+                        assert not c.queue and not c.counting and not c.pending and ops._active_ctx is None
+                        assert c.kicks_expected == (layers - 1 if ops.mq_last_layer else layers)
                 grads[(layers, mode)] = out
             for step in range(3):
                 for n, g in grads[(layers, False)][step].items():
@@ -263,86 +263,6 @@ def test_background_dw_sweep_gives_the_foreground_gradients():
                     assert float((g - gb).abs().max()) <= 2e-5 * float(g.abs().max()) + 1e-9, (layers, step, n)
     finally:
         ops.overlap_vocab_dw, ops.background_workgroups = prev
-
-
-@pytest.mark.parametrize('layers,row_parts', [(3, 2), (2, 3), (1, 2)])
-def test_cloze_step_in_row_parts_equals_loss_backward(layers, row_parts):
-    """model.cloze_step: the batch moves through forward and backward in row parts (the vocabulary head's sweeps of one part
-    as background kernels beside the encoder work of the other).  Same loss (mean over the masked items of the WHOLE
-    batch) and the same gradients as cloze_loss(...).backward() on the whole batch -- per-sequence results do not depend
-    on what else is in the batch; only the order of the fp32 sums over rows differs."""
-    from bert4clickpath_amd import input_pipeline, ops, optim
-    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
-    V, B, S = 3000, 50, 40
-    batch = input_pipeline.synthetic_cloze_batch(B, S, V, seed=13, min_len=6)
-    items = torch.from_numpy(batch['ids'])[:, 2:S - 1].contiguous().cuda()
-    labels = torch.from_numpy(batch['labels_padded']).cuda()
-    bounds = [B * i // row_parts for i in range(row_parts + 1)]
-    counts = [int((batch['ids'][bounds[i]:bounds[i + 1]] != 0).sum()) for i in range(row_parts)]
-    prev = ops.background_workgroups
-    ops.background_workgroups = 8
-    try:
-        res = {}
-        for mode in ('whole', 'parts'):
-            torch.manual_seed(0)
-            head = SoftMaxHead([64, 128], V)
-            m = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': 128}, head,
-                                       value_to_head='[MASK]', num_encoder_layers=layers, num_attention_heads=2, dropout_rate=0.0,
-                                       compute_dtype=torch.bfloat16).to('cuda')
-            opt = optim.Adam(m.parameters())
-            out = []
-            for step in range(3):
-                opt.zero_grad()
-                if mode == 'whole':
-                    loss = m.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, n_real_tokens=sum(counts))
-                    loss.backward()
-                    ops.join_side_work()
-                else:
-                    loss = m.cloze_step({'asin': items}, labels, 10, n_real_tokens=counts, row_parts=row_parts)
-                    assert not ops._bg_queue and not ops._bg_counting and not ops._side_pending and not ops._ready_gate
-                torch.cuda.synchronize()
-                out.append((float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
-                opt.step()
-            res[mode] = out
-        for step in range(3):
-            lw, gw = res['whole'][step]
-            lp, gp = res['parts'][step]
-            # steps 1, 2 run on weights that an Adam step (eps 1e-9: +-lr whatever the gradient's size) has moved apart
-            # wherever the gradient is noise-sized: they check the loss and that the machinery keeps running
-            assert abs(lw - lp) <= (2e-5 if step == 0 else 1e-2) * abs(lw), (step, lw, lp)
-            for n, g in (gw.items() if step == 0 else ()):
-                # step 0: identical weights; the sums over the vocabulary run in another order (8 parts, one wave per token
-                # group), so some entries of the bf16 dh round the other way (2^-8) and a few 1e-4 of that reach the summed
-                # gradients, a few 1e-3 of it the first layers (bf16 activations gradients in between).
-                # A missing part or a wrong 1 / n_valid would be O(1).
-                # (the key bias' gradient is identically zero -- a softmax row is invariant to it --: rounding noise on both
-                # sides, compared against the scale of the query bias')
-                tol = 1e-2
-                ref = float(gw[n.replace('wk.bias', 'wq.bias')].abs().max())
-                assert float((g - gp[n]).abs().max()) <= tol * ref + 1e-9, (step, n)
-    finally:
-        ops.background_workgroups = prev
-
-
-def test_cloze_step_falls_back_to_the_plain_calls():
-    """fp32 model (no logits-free head): cloze_step == cloze_loss + backward, through the same code"""
-    from bert4clickpath_amd import input_pipeline
-    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
-    V, B, S = 200, 8, 20
-    batch = input_pipeline.synthetic_cloze_batch(B, S, V, seed=5, min_len=5)
-    items = torch.from_numpy(batch['ids'])[:, 2:S - 1].contiguous().cuda()
-    labels = torch.from_numpy(batch['labels_padded']).cuda()
-    torch.manual_seed(0)
-    m = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': 32}, SoftMaxHead([16], V),
-                               value_to_head='[MASK]', num_encoder_layers=1, num_attention_heads=2, dropout_rate=0.0).to('cuda')
-    l1 = m.cloze_step({'asin': items}, labels, 10, row_parts=2)
-    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
-    m.zero_grad()
-    l2 = m.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10)
-    l2.backward()
-    assert float(l1) == float(l2)
-    for n, p in m.named_parameters():       # (the LayerNorm / bias column sums meet through float atomics: last bits differ)
-        assert float((p.grad - g1[n]).abs().max()) <= 1e-5 * float(g1[n].abs().max()) + 1e-12, n
 
 
 def test_background_dw_sweep_on_a_user_stream():

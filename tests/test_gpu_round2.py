@@ -620,7 +620,6 @@ def test_sampled_softmax_head_matches_fp64_restatement(gpu, dtype):
     for n, p in head.named_parameters():
         a = 0.5 * g_plain[n].float()
         assert float((p.grad.float() - a).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2) * float(a.abs().max()) + 1e-9, n
-    ops.inplace_grads = False
 
 
 def test_sampled_head_in_the_model_trains(gpu):
@@ -647,8 +646,6 @@ def test_sampled_head_in_the_model_trains(gpu):
     assert not torch.equal(seen[0], seen[1])
     top, hit, _ = model.predict_topk({'asin': items}, 10, labels)
     assert top.shape[1] == 10 and float(hit.mean()) > 0.3        # it memorises the one batch it saw
-    from bert4clickpath_amd import ops
-    ops.inplace_grads = False
 
 
 @pytest.mark.gpu

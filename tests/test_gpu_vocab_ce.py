@@ -165,43 +165,3 @@ def test_vocab_ce_dw_in_pieces_equals_the_whole(ops, R, V, K, scale, bg):
         assert float((db - db0).abs().max()) <= 1e-5 * scale_b + 1e-9, background
     with pytest.raises(L.B4CError):
         ops.vocab_ce_dw_sweep(hd, wt, bd, rowscal, V, dW, db, 0, nt + 1, 0)
-
-
-@pytest.mark.parametrize('R,V,K,scale,variant,parts,bg', [(700, 1000, 128, 1.6, 'tf', 4, 3), (300, 1301, 128, 0.3, 'tf', 8, 256),
-                                                         (333, 700, 64, 1.2, 'plain', 2, 7), (5000, 2100, 128, 1.0, 'tf', 8, 16),
-                                                         (130, 129, 64, 2.0, 'tf', 1, 5)])
-def test_vocab_ce_fwd_in_pieces_equals_the_whole(ops, R, V, K, scale, variant, parts, bg):
-    """b4c_vocab_ce_fwd_sweep over any partition of the token tiles (foreground kernels; background kernels: persistent
-    one-wave-per-SIMD workgroups, each wave taking both halves of a W tile in turn) + b4c_vocab_ce_fwd_combine against
-    b4c_vocab_ce_fwd: the same products; the order of the fp32 sums over the vocabulary differs with `parts` and with the
-    form, hence 2e-5 on the loss and the bf16 quantum on dh."""
-    from bert4clickpath_amd import _lib as L
-    h, W, b, y = _case(R, V, K, scale, seed=R + 3 * V, n_ignored=4)
-    dev = 'cuda'
-    hd = torch.tensor(h, device=dev).bfloat16()
-    Vp = (V + 7) // 8 * 8
-    wt = torch.zeros(Vp, K, device=dev, dtype=torch.bfloat16)
-    wt[:V] = torch.tensor(W, device=dev).bfloat16()
-    bd = torch.zeros(Vp, device=dev)
-    bd[:V] = torch.tensor(b, device=dev)
-    yd = torch.tensor(y, device=dev)
-    gs = torch.tensor([1.0 / R], device=dev)
-    code = L.CE_TF if variant == 'tf' else L.CE_PLAIN
-    item0, dh0, rs0 = ops.vocab_ce_fwd(hd, wt, bd, yd, gs, V, code)
-    nt = (R + 127) // 128
-    cuts = sorted({0, 1, nt // 3, (2 * nt) // 3, nt})
-    for background in (bg, 0):
-        for lo, hi in zip(cuts[:-1], cuts[1:]):
-            ops.vocab_ce_fwd_sweep(hd, wt, bd, V, code, parts, lo, hi, background)
-        item, dh, rs = ops.vocab_ce_fwd_combine(hd, wt, bd, yd, gs, V, code, parts)
-        ok = torch.isfinite(item0)
-        assert torch.equal(torch.isfinite(item), ok)
-        assert float((item[ok] - item0[ok]).abs().max()) <= 2e-5 * max(1.0, float(item0[ok].abs().max())), background
-        scale_dh = float(dh0.float().abs().max())
-        assert float((dh.float() - dh0.float()).abs().max()) <= 2 ** -7 * scale_dh + 1e-12, background
-        # the row scalars of the dW sweep: lse2, c, nb, lo | yd, hi
-        fin = torch.isfinite(rs0)
-        assert torch.equal(torch.isfinite(rs), fin)
-        assert float((rs[fin] - rs0[fin]).abs().max()) <= 2e-5 * max(1.0, float(rs0[fin].abs().max())), background
-    with pytest.raises(L.B4CError):
-        ops.vocab_ce_fwd_sweep(hd, wt, bd, V, code, 9, 0, nt, 0)
