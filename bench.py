@@ -13,7 +13,7 @@ d_model 128, 4 layers, 2 heads, dff 100 (reference-hard-coded), head [1024,512,2
 batch 4096 sequences per GPU (weak scaling), 10 masked items per sequence, dropout 0.1, bf16
 storage / fp32 accumulate / fp32 master weights.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without WORLD_SIZE in the environment: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for roofline / cpu_baseline).
@@ -61,8 +61,8 @@ def parse():
                     'layout then equals the dense one)')
     ap.add_argument('--host_flat_idx', action='store_true', help='A/B: hand the step host-precomputed [MASK] indices (round-1 bench)')
     ap.add_argument('--record_steps', type=int, default=3,
-                    help='timed steps (the first N of the timed region) whose launches are bracketed by HIP events for the roofline; '
-                         '-1 = all (costs ~0.4 ms/step of event overhead), 0 = none')
+                    help='timed steps (the LAST N of the timed region: the steady state) whose launches are bracketed by HIP events for the '
+                         'roofline; -1 = all (costs ~0.4 ms/step of event overhead), 0 = none')
     ap.add_argument('--ops_flags', default='', help='A/B switches of bert4clickpath_amd.ops, e.g. "fused_ln=0,sorted_embed_bwd=0"')
     ap.add_argument('--materialised_logits', action='store_true',
                     help='A/B: vocabulary projection writes the (R x V) logits and the CE reads them (ops.flash_ce = False)')
@@ -141,6 +141,10 @@ def make_batches(a, rank, device):
                     # host-side batch metadata, as the input pipeline has it when it pads (input_pipeline.py:198-214):
                     # number of non-pad positions of the chained batch ([CLS] [SEP] items [SEP])
                     'n_real': int((b['ids'] != 0).sum()),
+                    # for the launch recorder's algorithmic FLOP counts only: sum of len^2 over the sequences (len = real tokens,
+                    # specials included) and sum of (masked positions x len)
+                    'sum_len_sq': int(((b['lens'] + 3).astype(np.int64) ** 2).sum()),
+                    'sum_q_len': int((np.minimum((2 * b['lens']) // 5, 10).astype(np.int64) * (b['lens'] + 3)).sum()),
                     'R': int(b['labels'].shape[0])})
     return out
 
@@ -183,7 +187,10 @@ def cpu_baseline(a):
 
 
 KERNEL_OF = {   # launch family (ops recorder) -> kernel symbol(s) in the rocprofv3 trace
-    'gemm_nt': 'gemm_nt_kernel (dense fwd + dX)', 'gemm_tn': 'gemm_tn_bf16_kernel (dW)',
+    'gemm_nt': 'gemm_nt_kernel (dense fwd + dX on the token-sized tensors)', 'gemm_tn': 'gemm_tn_bf16_kernel (dW)',
+    'gemm_nt_rows': 'gemm_nt_kernel on the [MASK] rows only (head trunk, rows-only last layer: a few us per launch)',
+    'gemm_tn_rows': 'gemm_tn kernels on the [MASK] rows only', 'gemm_nt_ln_rows': 'gemm_nt_ln_kernel on the [MASK] rows only',
+    'add_ln_bwd_rows': 'add_ln_bwd_kernel on the [MASK] rows only',
     'attn_fwd': 'attn_fwd_mfma_kernel', 'attn_bwd': 'attn_bwd_resident_kernel',
     'attn_mq_fwd': 'attn_mq_fwd_mfma_kernel (last layer: the [MASK] rows against all keys, one wave per (sequence, head))',
     'attn_mq_bwd': 'attn_mq_bwd_mfma_kernel', 'softmax_ce': 'softmax_ce_bf16_kernel',
@@ -246,6 +253,7 @@ def eval_leg(model, batches, a, peak_tf):
 
     def score(i):
         b = batches[i % len(batches)]
+        ops.set_record_hints(token_rows=a.batch * a.seq if a.dense else b['n_real'], sum_len_sq=b['sum_len_sq'], sum_q_len=b['sum_q_len'])
         with torch.no_grad():
             probs = model(b['feats'], training=False, max_matches=10, packed=False if a.dense else None,
                           n_real_tokens=None if a.dense else b['n_real'])       # (B, 10, V), no host sync
@@ -272,15 +280,85 @@ def eval_leg(model, batches, a, peak_tf):
             'roofline': roof}
 
 
+class Training:
+    """bench.py's training step as an object (tests/test_gpu_parallel.py runs the very same step at 2 ranks): the model of
+    the workload, the optimizer over an arena in BACKWARD order, the gradient reducer with the late bucket, the resident
+    batches of this rank, and step(i)."""
+
+    def __init__(self, a, rank, world, device):
+        from bert4clickpath_amd import ops, optim, parallel
+        self.a, self.rank, self.world, self.device = a, rank, world, device
+        self.model = build_model(a, device)
+        self.opt = optim.Adam(self.model.parameters(), order=backward_order(self.model))
+        arena = self.opt.arena
+        model = self.model
+        emb_start = min(arena.slice_of(p)[0] for n, p in model.named_parameters() if 'embedding_layers' in n)
+        # (head parameters placed behind the tables -- the projection under ops.overlap_vocab_dw -- belong to the last bucket)
+        head_end = max(arena.slice_of(p)[1] for n, p in model.named_parameters()
+                       if n.startswith('head.') and n != 'head.output_embedding' and arena.slice_of(p)[0] < emb_start)
+        self.tables = [p for n, p in model.named_parameters() if 'embedding_layers' in n]
+        # config 5: the 2M-row tables' gradients travel as (indices, rows) instead of a 2 GB dense all-reduce (SURVEY 8e / H4)
+        self.sparse = (self.tables + [model.head.output_embedding]) if (a.sampled and world > 1) else []
+        self.reducer = parallel.GradReducer(arena, bucket_bounds=[head_end, emb_start], reduce='sum', sparse_params=self.sparse)
+        self.specials = torch.tensor([3, 4], device=device)
+        self.one = torch.ones((), dtype=torch.float32, device=device)   # d loss / d loss, built once (backward() would fill one per step)
+        self.batches = make_batches(a, rank, device)
+        self.ops = ops
+
+    def step(self, i):
+        a, b = self.a, self.batches[i % len(self.batches)]
+        model, reducer = self.model, self.reducer
+        # host-side facts the launch recorder's algorithmic counts use (nothing on the device depends on them)
+        self.ops.set_record_hints(token_rows=a.batch * a.seq if a.dense else b['n_real'], sum_len_sq=b['sum_len_sq'],
+                                  sum_q_len=b['sum_q_len'])
+        self.opt.zero_grad()
+        reducer.begin_backward()
+        if a.host_flat_idx:
+            loss = model.cloze_loss(b['feats'], b['labels'], training=True, flat_idx=b['flat_idx'], packed=False)
+        else:       # device-side index generation + label compaction, cap = 10 rows per sequence, no host sync
+            loss = model.cloze_loss(b['feats'], b['labels_padded'], training=True, max_masked_per_row=10,
+                                    packed=False if a.dense else None, n_real_tokens=None if a.dense else b['n_real'])
+        loss.backward(self.one)
+        if self.sparse:
+            for t, f in zip(self.tables, b['feats'].values()):
+                reducer.set_touched_rows(t, torch.cat([f.reshape(-1), self.specials]))
+            reducer.set_touched_rows(model.head.output_embedding, model.head.touched_rows())
+        reducer.finish()
+        self.opt.step(reducer.grad_mul)
+        return loss
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process -- which has made no GPU call -- starts
+    the N ranks (torch.distributed.run on 127.0.0.1, one process per GPU over RCCL) as a child, passes its output through
+    and exits with its code.  Fewer devices than ranks (a one-GPU box): the ranks share the devices round-robin and the
+    exchange goes over gloo -- a rehearsal of the N-rank path, labelled as such in the line's `config.parallelism`."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', B4C_SELF_LAUNCHED='1')
+    if ndev < a.gpus:
+        env.setdefault('B4C_DIST_BACKEND', 'gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
-    from bert4clickpath_amd import ops, optim, parallel
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a))
+    from bert4clickpath_amd import ops, parallel
     rank, local, world = parallel.init_distributed()
     if world != a.gpus:
-        if rank == 0:
-            print('warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (a.gpus, world), file=sys.stderr)
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU fallback)'
-    local = local % torch.cuda.device_count()      # (rehearsals with more ranks than GPUs share a device)
+    ndev = torch.cuda.device_count()
+    local = local % ndev      # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
 
@@ -290,58 +368,26 @@ def main():
         k, v = kv.split('=')
         assert hasattr(ops, k), 'unknown ops flag %s' % k
         setattr(ops, k, bool(int(v)))
-    model = build_model(a, device)
-    opt = optim.Adam(model.parameters(), order=backward_order(model))
-    arena = opt.arena
-    emb_start = min(arena.slice_of(p)[0] for n, p in model.named_parameters() if 'embedding_layers' in n)
-    # (head parameters placed behind the tables -- the projection under ops.overlap_vocab_dw -- belong to the last bucket)
-    head_end = max(arena.slice_of(p)[1] for n, p in model.named_parameters()
-                   if n.startswith('head.') and n != 'head.output_embedding' and arena.slice_of(p)[0] < emb_start)
-    tables = [p for n, p in model.named_parameters() if 'embedding_layers' in n]
-    # config 5: the 2M-row tables' gradients travel as (indices, rows) instead of a 2 GB dense all-reduce
-    sparse = (tables + [model.head.output_embedding]) if (a.sampled and world > 1) else []
-    reducer = parallel.GradReducer(arena, bucket_bounds=[head_end, emb_start], reduce='sum', sparse_params=sparse)
-    specials = torch.tensor([3, 4], device=device)
-    one = torch.ones((), dtype=torch.float32, device=device)       # d loss / d loss, built once (backward() would fill one per step)
-    batches = make_batches(a, rank, device)
-
-    def step(i):
-        b = batches[i % len(batches)]
-        opt.zero_grad()
-        reducer.begin_backward()
-        if a.host_flat_idx:
-            loss = model.cloze_loss(b['feats'], b['labels'], training=True, flat_idx=b['flat_idx'], packed=False)
-        else:       # device-side index generation + label compaction, cap = 10 rows per sequence, no host sync
-            loss = model.cloze_loss(b['feats'], b['labels_padded'], training=True, max_masked_per_row=10,
-                                    packed=False if a.dense else None, n_real_tokens=None if a.dense else b['n_real'])
-            loss.backward(one)
-        if a.host_flat_idx:
-            loss.backward(one)
-        if sparse:
-            for t, f in zip(tables, b['feats'].values()):
-                reducer.set_touched_rows(t, torch.cat([f.reshape(-1), specials]))
-            reducer.set_touched_rows(model.head.output_embedding, model.head.touched_rows())
-        reducer.finish()
-        opt.step(reducer.grad_mul)
-        return loss
+    tr = Training(a, rank, world, device)
+    model, batches, step = tr.model, tr.batches, tr.step
 
     for i in range(a.warmup):
         loss = step(i)
+    # HIP events around every hot-path launch of the LAST nrec timed steps (rank 0): the steady state, whatever the run's
+    # length (the first steps of a run are not yet in the clip regime of the vocabulary head)
     nrec = a.steps if a.record_steps < 0 else min(a.record_steps, a.steps)
-    if rank == 0 and nrec > 0:
-        ops.start_recording()      # HIP events around every hot-path launch of the first nrec timed steps (rank 0)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # one event per step boundary
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    fams = None
     marks[0].record()
     for i in range(a.steps):
-        if i == nrec and rank == 0 and nrec > 0:
-            fams = ops.pause_recording()
+        if i == a.steps - nrec and rank == 0 and nrec > 0:
+            ops.start_recording()
         loss = step(a.warmup + i)
         marks[i + 1].record()
+    fams = ops.pause_recording() if (rank == 0 and nrec > 0) else None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -354,25 +400,32 @@ def main():
     dt, items = float(tt[0]), float(rr[0])
 
     if rank == 0:
-        fams = ops.stop_recording(fams)
+        fams = ops.stop_recording(fams) if fams is not None else None
         peak_tf = MFMA_BF16_PEAK_TF if a.dtype == 'bf16' else 157.3
         roof = roofline_from(fams, max(nrec, 1), peak_tf) if fams else None
         tj = a.traffic_json or os.path.join(ROOT, 'profiles', 'traffic.json')
+        traffic = None
         if roof and os.path.exists(tj):      # rocprofv3 PMC passes (separate runs), HBM bytes per launch of each family
             with open(tj) as f:
                 traffic = json.load(f)
             cfg = traffic.get('_config', {})
             mine = {'vocab': a.vocab, 'batch': a.batch, 'seq': a.seq, 'd_model': a.d_model, 'layers': a.layers, 'dtype': a.dtype}
-            if a.traffic_json or all(cfg.get(k) == v for k, v in mine.items()):     # counters are valid for that config only
-                roof['traffic'] = traffic.get(roof['family'])
+            if not (a.traffic_json or all(cfg.get(k) == v for k, v in mine.items())):     # counters are valid for that config only
+                traffic = None
+        if roof and traffic:
+            roof['traffic'] = traffic.get(roof['family'])
+            if 'beside' in roof:        # the background sweep's measured HBM bytes beside its algorithmic bytes
+                for f, row in roof['beside']['families'].items():
+                    row['traffic'] = traffic.get(f)
         # per-step durations on the device timeline (events at the step boundaries; steps with the launch recorder on are
         # ~0.4 ms longer): SURVEY 8d asks for the median and p10 / p90
         raw_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
-        step_ms = sorted(raw_ms)
+        step_ms = sorted(raw_ms[:a.steps - nrec] or raw_ms)       # (the unrecorded steps when there are any)
         slowest = max(range(a.steps), key=lambda i: raw_ms[i])
 
         def pct(q):
             return step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))]
+        shared = ndev < world
         out = {
             'metric': 'masked-items/sec (whole node)', 'value': items / dt, 'unit': 'masked-items/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
@@ -393,21 +446,26 @@ def main():
                                          (', last layer evaluated at the [MASK] rows only' if ops.mq_last_layer else '') +
                                          (', vocabulary dW sweep as a background kernel beside the encoder backward'
                                           if ops.overlap_vocab_dw and ops.flash_ce and not a.sampled else ''))),
-                       'global_batch': a.batch * world, 'seq_len': a.seq, 'parallelism': 'dp%d' % world,
+                       'global_batch': a.batch * world, 'seq_len': a.seq,
+                       'parallelism': ('dp%d' % world) + (' (REHEARSAL: %d ranks share %d device(s), gradient exchange over gloo -- not an '
+                                                           'RCCL / xGMI measurement)' % (world, ndev) if shared else ''),
                        'grad_reduce': 'sum (reference semantics)'},
             'tokens_per_s': a.batch * world * a.seq * a.steps / dt,
-            'step_ms': {'median': pct(0.5), 'p10': pct(0.1), 'p90': pct(0.9), 'min': step_ms[0], 'max': step_ms[-1], 'slowest_step': slowest},
+            'step_ms': {'median': pct(0.5), 'p10': pct(0.1), 'p90': pct(0.9), 'min': step_ms[0], 'max': step_ms[-1], 'slowest_step': slowest,
+                        'recorded_steps': 'the last %d of the %d timed steps carry the launch recorder (+~0.4 ms each) and are left out of '
+                                          'these percentiles' % (nrec, a.steps) if 0 < nrec < a.steps else None},
             'final_loss': float(loss.detach()),
             'roofline': roof,
         }
         if roof and roof['bound'] == 'mfma':
             # the step's largest HBM-bound family next to it (the two lead the table within a few percent of each other)
             bal = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
-            hb = {f: v for f, v in fams.items() if v['bytes'] > 0 and v['flops'] / v['bytes'] <= bal}
+            hb = {f: v for f, v in fams.items() if v['bytes'] > 0 and v['flops'] / v['bytes'] <= bal and not f.endswith('_bg')}
             if hb:
                 r2 = roofline_from(fams, max(nrec, 1), peak_tf, dom=max(hb, key=lambda f: hb[f]['ms']))
                 r2.pop('families', None)
-                if os.path.exists(tj) and roof.get('traffic') is not None:
+                r2.pop('beside', None)
+                if traffic:
                     r2['traffic'] = traffic.get(r2['family'])
                 out['roofline_largest_hbm_family'] = r2
         if world == 1 and a.eval_steps > 0:

@@ -28,6 +28,18 @@ def rup8(n):
 # kernels, with the algorithmic bytes / flops of that launch, so the dominant kernel family and its roofline
 # fraction are measured live inside the timed region -------------------------------------------------------
 _rec = None        # None = off; else dict family -> [ms_events..., bytes, flops, launches]
+# host-side facts about the batch in flight that the recorder's ALGORITHMIC counts need and the launch sites cannot see
+# (the sequence lengths live on the device): bench.py sets them per step.
+#   token_rows: rows of the token-sized tensors (T): GEMMs with fewer than half of them are booked as `gemm_nt_rows`
+#   sum_len_sq: sum over sequences of len^2 -- the real work of the packed attention (T x S is an upper bound)
+#   sum_q_len:  sum over sequences of (masked query rows x len) -- the masked-query attention of the last layer
+rec_hints = {}
+
+
+def set_record_hints(**kw):
+    rec_hints.clear()
+    rec_hints.update(kw)
+
 
 
 def start_recording():
@@ -327,6 +339,10 @@ def gemm_nt(a, bt, n, bias=None, act=L.ACT_NONE, gate=None, residual=None, out_d
     # the materialised vocabulary projection (wide kernel: bf16, K <= 128, N >= 2048, plain epilogue) is its own family
     fam = 'vocab_proj' if (n >= 2048 and K <= 128 and a.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and
                            act == L.ACT_NONE and gate is None and residual is None) else 'gemm_nt'
+    # token-sized launches ([T] rows: HBM-bound at 60 - 130 us each) and row-sized ones ([R] rows of the head trunk and of
+    # the rows-only last layer: a few us each, launch-bound) are two families: one number would describe neither
+    if fam == 'gemm_nt' and 2 * M < rec_hints.get('token_rows', 0):
+        fam = 'gemm_nt_rows'
     with _record(fam, nbytes, 2 * M * n * K):
         L.check(L.lib().b4c_gemm_nt(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(out), out.stride(0), M, n, K, _p(bias), act,
                                     _p(gate), gate.stride(0) if gate is not None else 0,
@@ -341,7 +357,8 @@ def gemm_tn(a, g, K, N, want_bias=True, into=None):
     segments of equal width) instead of allocating zeros; returns (None, None) then."""
     M = a.shape[0]
     if M > 0 and _rec is not None:
-        with _record('gemm_tn', M * (K + N) * a.element_size() + K * N * 4, 2 * M * K * N):
+        with _record('gemm_tn' if 2 * M >= rec_hints.get('token_rows', 0) else 'gemm_tn_rows',
+                     M * (K + N) * a.element_size() + K * N * 4, 2 * M * K * N):
             return _gemm_tn_impl(a, g, K, N, want_bias, into)
     return _gemm_tn_impl(a, g, K, N, want_bias, into)
 
@@ -431,7 +448,7 @@ def flush_pending_dw():
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=dev)
         _tn_ws[dev] = ws
-    with _record('gemm_tn', nbytes, flops):
+    with _record('gemm_tn' if 2 * M >= rec_hints.get('token_rows', 0) else 'gemm_tn_rows', nbytes, flops):
         L.check(L.lib().b4c_gemm_tn_group(descs, len(items), M, L.BF16, ws.data_ptr(), ws.numel(), _st()), 'gemm_tn_group')
     for it in items:
         _ready(*it[6])
@@ -507,7 +524,8 @@ def attn_mq_fwd(q, kv, cu, moff, B, max_len, H, dh, key_pad=None):
     if R == 0:
         return o, lse
     es = q.element_size()
-    with _record('attn_mq_fwd', kv.shape[0] * 2 * H * dh * es + 2 * R * H * dh * es, 4 * R * max_len * H * dh):
+    # algorithmic work: every query row against the keys of its own sequence (host hint; R x max_len is an upper bound)
+    with _record('attn_mq_fwd', kv.shape[0] * 2 * H * dh * es + 2 * R * H * dh * es, 4 * rec_hints.get('sum_q_len', R * max_len) * H * dh):
         L.check(L.lib().b4c_attn_mq_fwd(_p(q), q.stride(0), _p(kv), kv.stride(0), _p(key_pad), _p(cu), _p(moff), _p(o), o.stride(0),
                                         _p(lse), B, max_len, H, dh, dt_code(q.dtype), _st()), 'attn_mq_fwd')
     return o, lse
@@ -523,7 +541,7 @@ def attn_mq_bwd(q, kv, cu, moff, o, d_o, lse, B, max_len, H, dh, key_pad=None):
     if kv.shape[0] == 0:
         return dq, dkv
     es = q.element_size()
-    with _record('attn_mq_bwd', kv.shape[0] * 4 * H * dh * es + 4 * R * H * dh * es, 10 * R * max_len * H * dh):
+    with _record('attn_mq_bwd', kv.shape[0] * 4 * H * dh * es + 4 * R * H * dh * es, 10 * rec_hints.get('sum_q_len', R * max_len) * H * dh):
         L.check(L.lib().b4c_attn_mq_bwd(_p(q), q.stride(0), _p(kv), kv.stride(0), _p(key_pad), _p(cu), _p(moff), _p(o), o.stride(0),
                                         _p(d_o), d_o.stride(0), _p(lse), _p(dq), dq.stride(0), _p(dkv), dkv.stride(0), B, max_len,
                                         H, dh, dt_code(q.dtype), _st()), 'attn_mq_bwd')
@@ -536,8 +554,10 @@ def attn_fwd(qkv, key_pad, B, S, H, dh, cu=None):
     T_tok = qkv.shape[0]
     o = torch.empty(T_tok, d, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
-    # algorithmic work of the packed layout is counted with the mean squared length bounded by T * S (an upper bound)
-    with _record('attn_fwd', T_tok * 4 * d * qkv.element_size(), 4 * T_tok * S * d):
+    # algorithmic work of the packed layout: sum over sequences of len^2 (host hint; T x S is an upper bound and what the
+    # padded layout computes)
+    pairs = rec_hints.get('sum_len_sq', T_tok * S) if cu is not None else T_tok * S
+    with _record('attn_fwd', T_tok * 4 * d * qkv.element_size(), 4 * pairs * d):
         if cu is None:
             L.check(L.lib().b4c_attn_fwd(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), d, _p(lse), B, S, H, dh,
                                          dt_code(qkv.dtype), _st()), 'attn_fwd')
@@ -561,7 +581,8 @@ def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, cu=None):
             ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
             _attn_ws[qkv.device] = ws
     T_tok = qkv.shape[0]
-    with _record('attn_bwd', T_tok * 8 * H * dh * qkv.element_size(), 10 * T_tok * S * H * dh):
+    pairs = rec_hints.get('sum_len_sq', T_tok * S) if cu is not None else T_tok * S
+    with _record('attn_bwd', T_tok * 8 * H * dh * qkv.element_size(), 10 * pairs * H * dh):
         if cu is None:
             L.check(L.lib().b4c_attn_bwd_ws(_p(qkv), qkv.stride(0), _p(key_pad), _p(o), o.stride(0), _p(d_o), d_o.stride(0),
                                             _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, _p(ws), need,
@@ -605,7 +626,8 @@ def gemm_nt_add_ln(a, bt, bias, x, gamma, beta, rate, seed, save=True):
     if M == 0:
         return z, out, stats
     es = a.element_size()
-    with _record('gemm_nt_ln', M * K * es + n * K * es + M * n * es * (3 if save else 2), 2 * M * n * K):
+    with _record('gemm_nt_ln' if 2 * M >= rec_hints.get('token_rows', 0) else 'gemm_nt_ln_rows',
+                 M * K * es + n * K * es + M * n * es * (3 if save else 2), 2 * M * n * K):
         L.check(L.lib().b4c_gemm_nt_add_ln(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(bias), _p(x), x.stride(0), _p(gamma),
                                            _p(beta), _p(z), _p(out), _p(stats), M, n, K, LN_EPS, rate, seed,
                                            dt_code(a.dtype), _st()), 'gemm_nt_add_ln')
@@ -646,7 +668,8 @@ def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed, into=None):
         dbeta = torch.zeros(d, dtype=torch.float32, device=z.device)
     if rows == 0:          # no row at all (a batch without a [MASK]): nothing to add to dgamma / dbeta
         return dz, (dy if dy is not None else dz), dgamma, dbeta
-    with _record('add_ln_bwd', rows * d * z.element_size() * (4 if rate > 0 else 3)):
+    with _record('add_ln_bwd' if 2 * rows >= rec_hints.get('token_rows', 0) else 'add_ln_bwd_rows',
+                 rows * d * z.element_size() * (4 if rate > 0 else 3)):
         L.check(L.lib().b4c_add_dropout_layernorm_bwd(_p(dout), _p(z), _p(stats), _p(gamma), _p(dz), _p(dy), _p(dgamma),
                                                       _p(dbeta), rows, d, rate, seed, dt_code(z.dtype), _st()),
                 'add_dropout_layernorm_bwd')

@@ -1,4 +1,5 @@
-"""Data-parallel training step on the GPU box: 2 ranks (gloo transport, both on cuda:0 -- the box has one GPU)
+"""Data-parallel training step on the GPU box: 2 ranks (nccl = RCCL with one device per rank when the box has two; else gloo
+transport, both ranks on cuda:0)
 run the real HIP step with the bucketed, hook-overlapped gradient all-reduce; afterwards the replicas must hold
 identical weights, equal to ONE process trained on both shards with the reference's semantics (sum over
 replicas of each replica's mean loss, losses.py:17,80-91)."""
@@ -115,3 +116,95 @@ def test_two_rank_step_matches_single_process(tmp_path, sparse):
             lo, hi = opt.arena.slice_of(p)
             diff[lo:hi] = 0
     assert float(diff.max()) < 2e-5
+
+
+# ---- the step bench.py times, at 2 ranks ------------------------------------------------------------------------------
+BENCH_ARGS = ['--batch', '64', '--seq', '40', '--vocab', '3000', '--d_model', '128', '--layers', '3', '--heads', '2',
+              '--n_batches', '2', '--no_cpu_baseline', '--eval_steps', '0', '--full_steps', '0']
+
+
+def _bench_args(dropout):
+    import sys
+    import bench
+    old = sys.argv
+    sys.argv = ['bench.py'] + BENCH_ARGS + ['--dropout', str(dropout)]
+    try:
+        return bench, bench.parse()
+    finally:
+        sys.argv = old
+
+
+def _bench_worker(rank, world, port, out_dir, dropout):
+    multi = torch.cuda.device_count() >= world
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank if multi else 0), B4C_DIST_BACKEND='nccl' if multi else 'gloo',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from bert4clickpath_amd import ops, parallel
+    parallel.init_distributed()
+    torch.cuda.set_device(rank if multi else 0)
+    ops.background_workgroups = 8          # (a 64-sequence batch: keep the background sweep in several pieces)
+    bench, a = _bench_args(dropout)
+    tr = bench.Training(a, rank, world, torch.device('cuda', rank if multi else 0))
+    # what bench.py runs at N > 1: bf16, padding-free layout, arena in backward order, the projection's dW as a background
+    # sweep announced when backward ends, its gradient in the LAST bucket, hook-overlapped reducer
+    assert tr.model.compute_dtype == torch.bfloat16 and ops.overlap_vocab_dw and ops.flash_ce and ops.mq_last_layer
+    assert tr.reducer.overlap and len(tr.reducer.buckets) == 3
+    proj = tr.model.head.output_layer.kernel
+    assert tr.opt.arena.slice_of(proj)[0] >= tr.reducer.buckets[2][0], 'the projection belongs to the last bucket'
+    for i in range(3):
+        tr.step(i)
+        assert tr.model._packed is not None
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, 'bench_rank%d.npy' % rank), tr.opt.arena.flat.cpu().numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('dropout', [0.0, 0.1])
+def test_bench_step_at_two_ranks(tmp_path, dropout):
+    """bench.py's own training step (bench.Training) at world size 2 -- nccl (= RCCL) with one device per rank when the box
+    has two, else both ranks on cuda:0 over gloo: the replicas must stay BIT-identical over 3 steps, and (without dropout,
+    whose seed stream a single process would consume twice as fast) equal one process that takes both shards per step."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs the MI355X')
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, str(tmp_path), dropout)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    w0, w1 = np.load(tmp_path / 'bench_rank0.npy'), np.load(tmp_path / 'bench_rank1.npy')
+    assert np.array_equal(w0, w1), 'replicas diverged: %d of %d elements differ' % ((w0 != w1).sum(), w0.size)
+    if dropout > 0:
+        return
+    from bert4clickpath_amd import ops
+    prev = ops.background_workgroups
+    ops.background_workgroups = 8
+    try:
+        bench, a = _bench_args(dropout)
+        dev = torch.device('cuda', 0)
+        tr = bench.Training(a, 0, 1, dev)
+        other = bench.make_batches(a, 1, dev)
+        for i in range(3):
+            tr.opt.zero_grad()
+            tr.reducer.begin_backward()
+            for b in (tr.batches[i % 2], other[i % 2]):         # loss = mean(shard 0) + mean(shard 1): gradients summed
+                loss = tr.model.cloze_loss(b['feats'], b['labels_padded'], training=True, max_masked_per_row=10, n_real_tokens=b['n_real'])
+                loss.backward(tr.one)
+            tr.reducer.finish()
+            tr.opt.step()
+        torch.cuda.synchronize()
+        ref = tr.opt.arena.flat.cpu().numpy()
+        assert ref.shape == w0.shape
+        diff = np.abs(ref - w0)
+        for n, p in tr.model.named_parameters():
+            if n.endswith('mha.wk.bias'):      # identically-zero gradient: Adam's 1e-9 epsilon turns rounding noise into steps
+                lo, hi = tr.opt.arena.slice_of(p)
+                diff[lo:hi] = 0
+        # the two shards' gradients meet in another order (all-reduce of two arenas / two passes into one arena; float atomics
+        # in the background sweep): last-bit differences, which three Adam steps carry into the weights
+        assert float(diff.max()) < 2e-4 and float(np.linalg.norm(ref - w0)) < 1e-4 * float(np.linalg.norm(ref)), float(diff.max())
+    finally:
+        ops.background_workgroups = prev
