@@ -202,7 +202,9 @@ KERNEL_OF = {   # launch family (ops recorder) -> kernel symbol(s) in the rocpro
                       'beside the encoder backward; its time is NOT additive to the step)',
     'vocab_proj': 'gemm_nt_wide2_kernel<true> (vocabulary projection with the softmax epilogue: probabilities R x V out)',
     'vocab_lse': 'vce_token_kernel<128,0> + vce_lse_kernel (row lse of the logits, recomputed in registers)',
-    'softmax_rows': 'softmax_rows_bf16_kernel (row in registers: one read, one write)', 'topk_rows': 'topk_rows_kernel'}
+    'softmax_rows': 'softmax_rows_bf16_kernel (row in registers: one read, one write)', 'topk_rows': 'topk_rows_kernel',
+    'vocab_rank': 'vce_label_logit_kernel + vce_scan_kernel<128, RANK> (rank of the true item, logits recomputed in registers)',
+    'vocab_topk': 'vce_scan_kernel<128, CLASSMAX | COLLECT> + vce_tau_kernel + vce_select_kernel (top-k ids, logits recomputed in registers)'}
 
 
 def roofline_from(fams, steps, peak_tf, dom=None):
@@ -246,38 +248,50 @@ def eval_leg(model, batches, a, peak_tf):
     """Scoring leg (reference: evaluate / predict): forward without dropout -> (B, M, V) probabilities materialised as
     SoftMaxHead returns them (head.py:36-47) -> ClozeMaskedRecall(10) / ClozeMaskedNDCG(10) update (utils.py:161-190,
     225-255).  Timed on the device timeline; the vocabulary projection's own roofline is reported (north_star: >= 60 %
-    of HBM peak on the vocab-projection at batch 4096 x seq 200)."""
+    of HBM peak on the vocab-projection at batch 4096 x seq 200).
+    `fused_topk`: the same batches and metrics with the scores never in memory -- model(x, scores='lazy') hands the metrics
+    the rows the projection would be applied to, and they rank through b4c_vocab_rank (one sweep, logits in accumulators)."""
     from bert4clickpath_amd import ops
     from bert4clickpath_amd.cloze import ClozeMaskedNDCG, ClozeMaskedRecall
-    rec, ndcg = ClozeMaskedRecall(10), ClozeMaskedNDCG(10)
 
-    def score(i):
-        b = batches[i % len(batches)]
-        ops.set_record_hints(token_rows=a.batch * a.seq if a.dense else b['n_real'], sum_len_sq=b['sum_len_sq'], sum_q_len=b['sum_q_len'])
-        with torch.no_grad():
-            probs = model(b['feats'], training=False, max_matches=10, packed=False if a.dense else None,
-                          n_real_tokens=None if a.dense else b['n_real'])       # (B, 10, V), no host sync
-            rec.update_state(b['labels_padded'], probs)
-            ndcg.update_state(b['labels_padded'], probs)
-    for i in range(2):
-        score(i)
-    rec.reset_states()
-    ndcg.reset_states()
-    torch.cuda.synchronize()
-    ops.start_recording()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.eval_steps + 1)]
-    ev[0].record()
-    for i in range(a.eval_steps):
-        score(i)
-        ev[i + 1].record()
-    fams = ops.stop_recording()
-    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.eval_steps))
-    R = sum(batches[i % len(batches)]['R'] for i in range(a.eval_steps))
-    roof = roofline_from(fams, a.eval_steps, peak_tf, dom='vocab_proj' if 'vocab_proj' in fams else None)
-    return {'what': 'forward -> materialised (B, 10, V) probabilities -> HitRate@10 + NDCG@10 update, batch %d' % a.batch,
-            'batches': a.eval_steps, 'ms_per_batch': sum(ms) / len(ms), 'ms_median': ms[len(ms) // 2],
-            'masked_items_per_s': R / (sum(ms) / 1e3), 'hit_rate_at_10': float(rec.result()), 'ndcg_at_10': float(ndcg.result()),
-            'roofline': roof}
+    def leg(lazy):
+        rec, ndcg = ClozeMaskedRecall(10), ClozeMaskedNDCG(10)
+
+        def score(i):
+            b = batches[i % len(batches)]
+            ops.set_record_hints(token_rows=a.batch * a.seq if a.dense else b['n_real'], sum_len_sq=b['sum_len_sq'], sum_q_len=b['sum_q_len'])
+            with torch.no_grad():
+                scores = model(b['feats'], training=False, max_matches=10, packed=False if a.dense else None,
+                               n_real_tokens=None if a.dense else b['n_real'], scores='lazy' if lazy else None)   # (B, 10, V), no host sync
+                rec.update_state(b['labels_padded'], scores)
+                ndcg.update_state(b['labels_padded'], scores)
+        for i in range(2):
+            score(i)
+        rec.reset_states()
+        ndcg.reset_states()
+        torch.cuda.synchronize()
+        ops.start_recording()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.eval_steps + 1)]
+        ev[0].record()
+        for i in range(a.eval_steps):
+            score(i)
+            ev[i + 1].record()
+        fams = ops.stop_recording()
+        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.eval_steps))
+        R = sum(batches[i % len(batches)]['R'] for i in range(a.eval_steps))
+        dom = ('vocab_rank' if lazy else 'vocab_proj')
+        roof = roofline_from(fams, a.eval_steps, peak_tf, dom=dom if dom in fams else None)
+        return {'batches': a.eval_steps, 'ms_per_batch': sum(ms) / len(ms), 'ms_median': ms[len(ms) // 2],
+                'masked_items_per_s': R / (sum(ms) / 1e3), 'hit_rate_at_10': float(rec.result()), 'ndcg_at_10': float(ndcg.result()),
+                'roofline': roof}
+
+    out = leg(False)
+    out['what'] = 'forward -> materialised (B, 10, V) probabilities -> HitRate@10 + NDCG@10 update, batch %d' % a.batch
+    if a.dtype == 'bf16' and not a.sampled:
+        out['fused_topk'] = leg(True)
+        out['fused_topk']['what'] = ('forward -> HitRate@10 + NDCG@10 update through the logits-free ranking sweep (scores never in memory; ranks '
+                                     'the fp32 logits, where the materialised leg ranks bf16 probabilities), batch %d' % a.batch)
+    return out
 
 
 class Training:

@@ -1,5 +1,5 @@
 from .clickstream_transformer import ClickstreamTransformer, TransformerInputPrep   # noqa: F401
-from .head import (BinaryClassificationHead, ClozeMaskedItemPrediction,             # noqa: F401
+from .head import (BinaryClassificationHead, ClozeMaskedItemPrediction, ClozeScores,  # noqa: F401
                    MultiLabel_MultiClass_classification, SampledSoftmaxHead, SoftMaxHead)
 from .losses import MaskedLoss, binary_crossentropy, sparse_categorical_crossentropy  # noqa: F401
 from .metrics import F1Score, MaskedMetric, PositiveRate, PredictedPositives          # noqa: F401

@@ -239,10 +239,29 @@ class ClickstreamTransformer(nn.Module):
         return ops.poison_rows(out, self._packed.ids_packed)
 
     # ---- reference call ------------------------------------------------------------------------
-    def forward(self, inputs, training=None, mask=None, max_matches=None, packed=None, n_real_tokens=None):
+    def forward(self, inputs, training=None, mask=None, max_matches=None, packed=None, n_real_tokens=None, scores=None):
         """inputs: dict feature-name -> (B, Li) strings or int64 ids (+ optional 'instance_id').
         Returns head_unit(head_input), or {'instance_id', 'logits'} when 'instance_id' is present.
-        packed / n_real_tokens: as in cloze_loss (value_to_head models only)."""
+        packed / n_real_tokens: as in cloze_loss (value_to_head models only).
+        scores='lazy' (scoring only, value_to_head models): the head's (B, M, V) output as a head.ClozeScores -- the rows the
+        projection would be applied to, not its result; cloze.ClozeMaskedRecall / NDCG rank through it without the scores
+        ever reaching memory, `.probabilities()` materialises them.  Heads without that form return their usual output."""
+        self._lazy = scores == 'lazy' and hasattr(self.head, 'lazy_scores') and not (training and torch.is_grad_enabled())
+        try:
+            return self._forward(inputs, training, mask, max_matches, packed, n_real_tokens)
+        finally:
+            self._lazy = False
+
+    def _head_out(self, head_input, n_real_tokens):
+        if self._lazy:
+            out = self.head.lazy_scores(head_input)
+            if out is not None:
+                if self._packed is not None and n_real_tokens is not None:
+                    out.flag = self._packed.ids_packed
+                return out
+        return self._poisoned(self.head(head_input), n_real_tokens)
+
+    def _forward(self, inputs, training, mask, max_matches, packed, n_real_tokens):
         feats = {k: v for k, v in inputs.items() if k != 'instance_id'}
         pack = self._use_packed(feats, packed, n_real_tokens)
         if self.segment_to_head is None and self.value_to_head is not None and ops.mq_last_layer and \
@@ -267,12 +286,12 @@ class ClickstreamTransformer(nn.Module):
                 M, keep = self._rows_extra
                 B = ids_first.shape[0]
                 enc = ops.GatherRowsFn.apply(enc, keep, B * M)
-                logits = self._poisoned(self.head(enc.view(B, M, enc.shape[-1])), n_real_tokens)
+                logits = self._head_out(enc.view(B, M, enc.shape[-1]), n_real_tokens)
                 if 'instance_id' in inputs.keys():
                     return {'instance_id': inputs['instance_id'], 'logits': logits}
                 return logits
             head_input = enc.new_zeros(ids_first.shape[0], 0, enc.shape[-1])       # no position matches anywhere
-            logits = self._poisoned(self.head(head_input), n_real_tokens)
+            logits = self._head_out(head_input, n_real_tokens)
             if 'instance_id' in inputs.keys():
                 return {'instance_id': inputs['instance_id'], 'logits': logits}
             return logits
@@ -293,7 +312,7 @@ class ClickstreamTransformer(nn.Module):
                 head_input = ops.GatherRowsFn.apply(enc.reshape(-1, d), pidx, B * M).view(B, M, d)
         else:
             raise ValueError("One of value_to_head and segment_to_head must be provided.")
-        logits = self._poisoned(self.head(head_input), n_real_tokens)
+        logits = self._head_out(head_input, n_real_tokens)
         if 'instance_id' in inputs.keys():
             return {'instance_id': inputs['instance_id'], 'logits': logits}
         return logits
@@ -386,14 +405,16 @@ class ClickstreamTransformer(nn.Module):
         latter two when labels are given."""
         rows, _ = self._masked_rows(inputs, False, flat_idx, pack=self._use_packed(inputs, packed, n_real_tokens),
                                     n_real_tokens=n_real_tokens)
-        logits = self.head.logits(rows, out_fp32=True)
         lab = None
         if labels is not None:
             lab = torch.as_tensor(labels, device=rows.device)
             if lab.dim() == 2:
                 lab = lab[lab != -1.0]
             lab = lab.to(torch.int32).contiguous()
-        idx, hit, ndcg = ops.topk_rows(logits, self.head.output_vocab_size, k, lab)
+        if hasattr(self.head, 'topk'):           # logits-free where the head's kernels cover it (head.SoftMaxHead.topk)
+            idx, hit, ndcg = self.head.topk(rows, k, lab)
+        else:
+            idx, hit, ndcg = ops.topk_rows(self.head.logits(rows, out_fp32=True), self.head.output_vocab_size, k, lab)
         if self._packed is not None and n_real_tokens is not None:
             # a caller-given token count that the device's own contradicts: ids -1, hit / ndcg NaN (no read-back)
             flag = self._packed.ids_packed

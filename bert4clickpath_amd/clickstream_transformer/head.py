@@ -83,6 +83,44 @@ class SoftMaxHead(nn.Module):
         K, kernel, bias = self._proj()
         return ops.MLPFn.apply(h, self._packs[-1:], torch.is_grad_enabled(), out_fp32, kernel, bias)
 
+    def _rank_supported(self, h):
+        """the logits-free ranking kernels: bf16 trunk output of width 64 / 128"""
+        K, _, _ = self._proj()
+        return ops.fused_rank and h.is_cuda and h.dtype == torch.bfloat16 and K in (64, 128) and h.shape[1] == K
+
+    def lazy_scores(self, inputs):
+        """inputs (B, M, d) -> ClozeScores standing for the (B, M, V) probabilities (None when the logits-free ranking
+        kernels do not cover this head: fp32, or a projection input that is not 64 / 128 wide)"""
+        shp = inputs.shape
+        x2d = inputs.reshape(-1, shp[-1])
+        if not self._built():
+            self.build(x2d.shape[-1])
+            self.to(x2d.device)
+        with torch.no_grad():
+            h = self.trunk(x2d).contiguous()
+        return ClozeScores(self, h, shp[:-1], inputs) if self._rank_supported(h) else None
+
+    def topk(self, x2d, k, labels_i32=None, trunk_done=False):
+        """-> (ids [R, k] int32, hit [R], ndcg [R]) of the V scores of every row, ranked as tf.math.top_k ranks (ties -> lower
+        index first).  bf16 / 64- or 128-wide projection input: the scores never reach memory (b4c_vocab_topk); rows with
+        mass ties at the selection threshold, and every other configuration, are ranked on materialised fp32 logits."""
+        V = self.output_vocab_size
+        with torch.no_grad():
+            h = x2d if trunk_done else self.trunk(x2d)
+            if self._rank_supported(h):
+                K, _, _ = self._proj()
+                wt, _, b = self._packs[-1].get(h.dtype, K, False)
+                idx, hit, ndcg, overflow = ops.vocab_topk(h.contiguous(), wt, b, V, k, labels_i32)
+                if int(overflow.item()):          # (one 4-byte read-back per call; the ids are read by the host anyway)
+                    bad = (idx[:, 0] < 0).nonzero().reshape(-1)
+                    i2, h2, n2 = ops.topk_rows(self._project(h[bad].contiguous(), out_fp32=True), V, k,
+                                               labels_i32[bad].contiguous() if labels_i32 is not None else None)
+                    idx[bad] = i2
+                    if hit is not None:
+                        hit[bad], ndcg[bad] = h2, n2
+                return idx, hit, ndcg
+            return ops.topk_rows(self._project(h, out_fp32=True), V, k, labels_i32)
+
     def forward(self, inputs, **kwargs):
         """inputs (B, M, d) -> probabilities (B, M, V), materialised as the reference does."""
         shp = inputs.shape
@@ -101,6 +139,41 @@ class SoftMaxHead(nn.Module):
         if probs is None:
             probs = ops.SoftmaxRowsFn.apply(self.logits(x2d), V)
         return probs.view(*shp[:-1], probs.shape[-1])[..., :V]
+
+
+class ClozeScores:
+    """The head's (B, M, V) scores WITHOUT the scores: the trunk output rows and the projection they would go through.
+    `model(x, scores='lazy')` returns one in place of the materialised probabilities; the ranking metrics
+    (cloze.ClozeMaskedRecall / ClozeMaskedNDCG.update_state) take it as y_pred and rank through the logits-free kernels
+    (b4c_vocab_rank: 12.8 MB of weights read instead of 4.1 GB of probabilities written and read back at C2).
+    probabilities() materialises what SoftMaxHead.forward returns (head.py:36-47)."""
+
+    def __init__(self, head, h2d, lead_shape, inputs=None):
+        self.head, self.h2d, self.inputs = head, h2d, inputs
+        self.shape = tuple(lead_shape) + (head.output_vocab_size,)
+        self.device, self.dtype = h2d.device, h2d.dtype
+        self.flag = None          # int32 device flag of a caller-given token count the device contradicts (negative -> NaN metrics)
+        self._rank = None
+
+    def _operands(self):
+        K, _, _ = self.head._proj()
+        wt, _, b = self.head._packs[-1].get(self.h2d.dtype, K, False)
+        return wt, b
+
+    def rank_of(self, labels_i32):
+        """items ranked before the label, per row (ties -> lower index first); negative where the label is a pad"""
+        key = (labels_i32.data_ptr(), labels_i32._version, tuple(labels_i32.shape))
+        if self._rank is None or self._rank[0] != key:
+            wt, b = self._operands()
+            self._rank = (key, ops.vocab_rank(self.h2d, wt, b, labels_i32, self.head.output_vocab_size), labels_i32)
+        return self._rank[1]
+
+    def topk(self, k, labels_i32=None):
+        return self.head.topk(self.h2d, k, labels_i32, trunk_done=True)
+
+    def probabilities(self):
+        """the (B, M, V) tensor this object stands for: what the head returns when called as the reference calls it"""
+        return self.head(self.inputs)
 
 
 class _DenseStackHead(nn.Module):

@@ -41,6 +41,22 @@ class _ClozeRankMetric:
         self.total = None
 
     def _rows(self, y_true, y_pred):
+        if hasattr(y_pred, 'rank_of'):
+            # head.ClozeScores (model(x, scores='lazy')): rank of the true item through the logits-free sweep; one sweep
+            # serves every k and both metrics (the scores object caches the rank of a label tensor)
+            yt = torch.as_tensor(y_true, device=y_pred.device).reshape(-1)
+            key = ('lazy', id(y_pred), yt.data_ptr(), yt._version, tuple(yt.shape))
+            if _last_rank['key'] == key and _last_rank['ref']() is y_pred:
+                lab, valid = _last_rank['val']
+            else:
+                valid = yt != LABEL_PAD
+                lab = torch.where(valid, yt, torch.full_like(yt, -1)).to(torch.int32).contiguous()
+                _last_rank.update(key=key, val=(lab, valid), ref=weakref.ref(y_pred))
+            hit, ndcg = ops.rank_metrics(y_pred.rank_of(lab), self.k)
+            if y_pred.flag is not None:
+                ops.poison_rows(hit.view(-1, 1), y_pred.flag)
+                ops.poison_rows(ndcg.view(-1, 1), y_pred.flag)
+            return hit, ndcg, valid
         ops._cuda(y_pred)
         V = y_pred.shape[-1]
         yp = y_pred.reshape(-1, V)

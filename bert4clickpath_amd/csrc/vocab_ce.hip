@@ -178,7 +178,24 @@ __device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, flo
 #define VCE_FRAG_BATCH 1
 #endif
 
-template <int KD, int MODE>
+#ifdef VCE_SCAN_STAMPS
+// diagnostic build only (scratch/scan_stamps.py): cycles per phase of the tile loop, summed per wave
+__device__ unsigned long long g_vce_stamps[2048 * 8 * 6];
+extern "C" int b4c_debug_vce_stamps(void *dst, size_t nbytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_vce_stamps), nbytes < sizeof(g_vce_stamps) ? nbytes : sizeof(g_vce_stamps));
+}
+#define VCE_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[k] += t_ - t0_; t0_ = t_; } while (0)
+#else
+#define VCE_STAMP(k) do { } while (0)
+#endif
+
+// NH = 1: 128 tokens per workgroup, 8 waves = 4 token groups x the 2 halves of each 128-row W tile.
+// NH = 2: 256 tokens per workgroup, 8 token groups, every wave takes both halves in turn.  A 32 KB W tile takes a CU about
+// 2,900 cycles to pull in by LDS-DMA (~11 B / clock / CU, whatever the source: the per-CU load path, MI355X_MICROARCH.md
+// 'ldsdma-fill'), and at 128 tokens the two waves of a SIMD have 2 x 32 MFMAs = 2,048 cycles of matrix work per tile: the
+// sweep waits for its tiles (per-phase stamps, scratch/token_stamps.py: 20 - 34 % of a wave's cycles at the end-of-tile
+// wait).  At 256 tokens the tile's matrix work (4,096 cycles) covers its arrival.
+template <int KD, int MODE, int NH>
 __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NKS = KD / 16, NDT = KD / 32, STR = VTile<KD>::STR;
@@ -187,8 +204,8 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
     const int unit = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int li = lane & 15, g = lane >> 4;
-    const int tg = wave & 3, vh = wave >> 2;
-    const int64_t tok0 = (int64_t)(unit % a.ntt) * 128;
+    const int tg = NH == 2 ? wave : (wave & 3), vh = NH == 2 ? 0 : (wave >> 2);
+    const int64_t tok0 = (int64_t)(unit % a.ntt) * (128 * NH);
     const int64_t tok = tok0 + tg * 32 + r;
     const int part = unit / a.ntt;
     const int nvt = (a.V + 127) >> 7;
@@ -238,12 +255,20 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) U[dt][t] = 0.f;
 
+#ifdef VCE_SCAN_STAMPS
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
+#endif
     // one vocabulary tile; the LDS buffer index is a compile-time constant (the loop is unrolled by two) so that every
     // LDS address is a per-lane VGPR + an immediate
     auto tile = [&](auto BUF, int vt) {
         constexpr int buf = decltype(BUF)::value;
+        VCE_STAMP(5);
         fetch(vt + 1, buf ^ 1);        // the other buffer was last read one tile ago (behind the previous barrier)
-        const char *w = smem + buf * TILE_B;
+        VCE_STAMP(0);
+#pragma unroll
+        for (int hv = 0; hv < NH; ++hv) {            // NH = 2: the wave takes the tile's two 64-row halves in turn
+        const int vhe = NH == 2 ? hv : vh;           // which half
+        const char *w = smem + buf * TILE_B + (NH == 2 ? hv * 64 * STR : 0);
         const float *bs = sBias + buf * 128;
         f32x16 acc[2];
 #if VCE_FRAG_BATCH
@@ -256,7 +281,7 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int tq = 0; tq < 4; ++tq) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vh * 64 + rt * 32 + 8 * tq + 4 * hf);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vhe * 64 + rt * 32 + 8 * tq + 4 * hf);
                     acc[rt][4 * tq] = b4[0]; acc[rt][4 * tq + 1] = b4[1]; acc[rt][4 * tq + 2] = b4[2]; acc[rt][4 * tq + 3] = b4[3];
                 }
 #pragma unroll
@@ -281,7 +306,7 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
         for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
             for (int tq = 0; tq < 4; ++tq) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vh * 64 + rt * 32 + 8 * tq + 4 * hf);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vhe * 64 + rt * 32 + 8 * tq + 4 * hf);
                 acc[rt][4 * tq] = b4[0]; acc[rt][4 * tq + 1] = b4[1]; acc[rt][4 * tq + 2] = b4[2]; acc[rt][4 * tq + 3] = b4[3];
             }
 #pragma unroll
@@ -291,6 +316,7 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
             }
         }
 #endif
+        VCE_STAMP(1);
         float e2 = lse2;                             // the exponent reference of this tile
         if (MODE != 2) {
             const bool tail = (vt + 1) * 128 > a.V;      // some rows of this tile are past V (their logit is -inf)
@@ -310,9 +336,15 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int t = 0; t < 16; ++t)
-                        if (vt * 128 + vh * 64 + rt * 32 + vce_rowmap(t, hf) < a.V) mn = fminf(mn, acc[rt][t]);
+                        if (vt * 128 + vhe * 64 + rt * 32 + vce_rowmap(t, hf) < a.V) mn = fminf(mn, acc[rt][t]);
             }
-            tm = fmaxf(tm, __shfl_xor(tm, 32));      // the two lanes of a token share the reference (their P mix in U)
+            // the two lanes of a token share the reference (their P mix in U): lanes l and l + 32 exchange through
+            // v_permlane32_swap (one VALU instruction; __shfl_xor is a ds_bpermute: an LDS round trip on the critical path
+            // of every tile)
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tm), __builtin_bit_cast(unsigned, tm), false, false);
+                tm = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            }
             mx = fmaxf(mx, tm);
             const float tm2 = tm * VCE_LOG2E;
             const bool raise = tm2 > m2 + VCE_LAZY;
@@ -331,6 +363,7 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
             }
             e2 = (m2 == -INFINITY) ? 0.f : m2;      // no finite logit seen yet (a tail half-tile past V): p = 2^(-inf) = 0
         }
+        VCE_STAMP(2);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             __builtin_amdgcn_sched_barrier(0);       // keep one 32-row tile's temporaries live at a time
@@ -374,17 +407,24 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
                 }
             }
         }
+        }
+        VCE_STAMP(3);
         if (tid < 128) sBias[(buf ^ 1) * 128 + tid] = breg;
         VCE_DMA_WAIT();
         B4C_LDS_BARRIER();
+        VCE_STAMP(4);
     };
     for (int vt = vt0; vt < vt1; vt += 2) {
         tile(std::integral_constant<int, 0>{}, vt);
         if (vt + 1 < vt1) tile(std::integral_constant<int, 1>{}, vt + 1);
     }
+#ifdef VCE_SCAN_STAMPS
+    if (lane == 0 && blockIdx.x < 2048)
+        for (int k = 0; k < 6; ++k) g_vce_stamps[(blockIdx.x * 8 + wave) * 6 + k] = st_[k];
+#endif
     __syncthreads();   // all tiles consumed: LDS is reused below
 
-    // U^T tiles -> LDS [token][d] per wave; per-lane scalars -> LDS; then the two vocabulary halves and the two
+    // U^T tiles -> LDS [token][d] per wave; per-lane scalars -> LDS; then the two vocabulary halves (NH = 1) and the two
     // lanes of each token are merged and stored row-major
     constexpr int USTR = KD + 4;                         // floats per token row
     float *sU = reinterpret_cast<float *>(smem) + wave * 32 * USTR;
@@ -399,29 +439,33 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
     f32x4 *sS = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(smem) + 8 * 32 * USTR);   // [wave][lane]
     sS[wave * 64 + lane] = (MODE != 2) ? (f32x4){m2, l, mn, mx} : (f32x4){(float)nu, Pc, (float)nhi, 0.f};
     __syncthreads();
-    // token t of the tile: waves (t >> 5) and (t >> 5) + 4; lanes (t & 31) and (t & 31) + 32
+    // token t of the tile: NH = 1: waves (t >> 5) and (t >> 5) + 4; NH = 2: wave t >> 5; lanes (t & 31) and (t & 31) + 32
     float *dst = (MODE == 1 ? a.u : a.ud) + (int64_t)part * a.R * KD;
     if (MODE != 0)
-    for (int c = tid; c < 128 * (KD / 4); c += 512) {
+    for (int c = tid; c < 128 * NH * (KD / 4); c += 512) {
         const int t = c / (KD / 4), q = c % (KD / 4);
         if (tok0 + t < a.R) {
             const float *p0 = reinterpret_cast<const float *>(smem) + t * USTR + q * 4;
             f32x4 v0 = *reinterpret_cast<const f32x4 *>(p0);
-            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(p0 + 4 * 32 * USTR);
-            if (MODE == 1) {
-                const float ma = sS[(t >> 5) * 64 + (t & 31)][0], mb = sS[((t >> 5) + 4) * 64 + (t & 31)][0];
-                const float M = fmaxf(ma, mb);
-                v0 = v0 * __builtin_amdgcn_exp2f(ma - M) + v1 * __builtin_amdgcn_exp2f(mb - M);
-            } else {
-                v0 = v0 + v1;
+            if (NH == 1) {
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(p0 + 4 * 32 * USTR);
+                if (MODE == 1) {
+                    const float ma = sS[(t >> 5) * 64 + (t & 31)][0], mb = sS[((t >> 5) + 4) * 64 + (t & 31)][0];
+                    const float M = fmaxf(ma, mb);
+                    v0 = v0 * __builtin_amdgcn_exp2f(ma - M) + v1 * __builtin_amdgcn_exp2f(mb - M);
+                } else {
+                    v0 = v0 + v1;
+                }
             }
             *reinterpret_cast<f32x4 *>(dst + (tok0 + t) * KD + q * 4) = v0;
         }
     }
-    if (tid < 128 && tok0 + tid < a.R) {
+    if (tid < 128 * NH && tok0 + tid < a.R) {
         const int tgi = tid >> 5, ri = tid & 31;
         const f32x4 a0 = sS[tgi * 64 + ri], a1 = sS[tgi * 64 + ri + 32];
-        const f32x4 b0 = sS[(tgi + 4) * 64 + ri], b1 = sS[(tgi + 4) * 64 + ri + 32];
+        // NH = 2: no second wave for the token: neutral elements
+        const f32x4 nb = (MODE != 2) ? (f32x4){-INFINITY, 0.f, INFINITY, -INFINITY} : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 b0 = NH == 1 ? sS[(tgi + 4) * 64 + ri] : nb, b1 = NH == 1 ? sS[(tgi + 4) * 64 + ri + 32] : nb;
         if (MODE != 2) {
             const float M = fmaxf(a0[0], b0[0]);     // the two lanes of a token share m2
             const float fa = __builtin_amdgcn_exp2f(a0[0] - M), fb = __builtin_amdgcn_exp2f(b0[0] - M);
@@ -813,6 +857,13 @@ template <int KD> static size_t vce_token_lds() {
     const size_t outs = (size_t)8 * 32 * (KD + 4) * 4 + 8 * 64 * 16;
     return tiles > outs ? tiles : outs;
 }
+// tokens per workgroup of the token-owned sweeps: 256 once there are enough token tiles to fill the chip
+// (B4C_VCE_TOKENS=128|256 overrides: A/B)
+static int vce_token_nh(int64_t R) {
+    static const char *e = getenv("B4C_VCE_TOKENS");
+    if (e) return atoi(e) >= 256 ? 2 : 1;
+    return R >= 256 * 64 ? 2 : 1;
+}
 template <int KD> static size_t vce_dw_lds() {
     const size_t tiles = 2 * (size_t)VTile<KD>::BYTES + 2 * 128 * 32;
     const size_t outs = (size_t)4 * (KD * 32 + 32) * 4;
@@ -828,7 +879,8 @@ extern "C" int64_t b4c_vocab_ce_workspace_bytes(int64_t R, int V, int K) {
 
 template <int KD>
 static int vce_fwd_launch(VceArgs a, hipStream_t st) {
-    const int64_t ntt = ceil_div64(a.R, 128);
+    const int nh = vce_token_nh(a.R);
+    const int64_t ntt = ceil_div64(a.R, 128 * nh);
     const int nvt = (a.V + 127) / 128;
     a.parts = vce_pick_split(ntt, nvt, 0.005);
     float *ws = a.st1;
@@ -838,8 +890,8 @@ static int vce_fwd_launch(VceArgs a, hipStream_t st) {
     const size_t lds = vce_token_lds<KD>();
     static thread_local bool done = false;
     if (!done) {
-        vce_allow_lds(vce_token_kernel<KD, 1>, lds);
-        vce_allow_lds(vce_token_kernel<KD, 2>, lds);
+        vce_allow_lds(vce_token_kernel<KD, 1, 1>, lds); vce_allow_lds(vce_token_kernel<KD, 2, 1>, lds);
+        vce_allow_lds(vce_token_kernel<KD, 1, 2>, lds); vce_allow_lds(vce_token_kernel<KD, 2, 2>, lds);
         done = true;
     }
     a.ntt = (int)ntt;
@@ -857,9 +909,11 @@ static int vce_fwd_launch(VceArgs a, hipStream_t st) {
         if (!have) { for (auto &e : ev) (void)hipEventCreate(&e); have = true; }
         (void)hipEventRecord(ev[0], st);
     }
-    vce_token_kernel<KD, 1><<<grid, 512, lds, st>>>(a);
+    if (nh == 2) vce_token_kernel<KD, 1, 2><<<grid, 512, lds, st>>>(a); else vce_token_kernel<KD, 1, 1><<<grid, 512, lds, st>>>(a);
     if (dbg) (void)hipEventRecord(ev[1], st);
-    if (a.variant == B4C_CE_TF) vce_token_kernel<KD, 2><<<grid, 512, lds, st>>>(a);
+    if (a.variant == B4C_CE_TF) {
+        if (nh == 2) vce_token_kernel<KD, 2, 2><<<grid, 512, lds, st>>>(a); else vce_token_kernel<KD, 2, 1><<<grid, 512, lds, st>>>(a);
+    }
     if (dbg) (void)hipEventRecord(ev[2], st);
     vce_combine_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a);
     if (dbg) (void)hipEventRecord(ev[3], st);
@@ -886,14 +940,16 @@ extern "C" int b4c_vocab_ce_fwd(const void *h, int ld_h, const void *wt, int ld_
 
 template <int KD>
 static int vce_lse_launch(VceArgs a, float *lse2, hipStream_t st) {
-    const int64_t ntt = ceil_div64(a.R, 128);
+    const int nh = vce_token_nh(a.R);
+    const int64_t ntt = ceil_div64(a.R, 128 * nh);
     const int nvt = (a.V + 127) / 128;
     a.parts = vce_pick_split(ntt, nvt, 0.005);
     const size_t lds = vce_token_lds<KD>();
     static thread_local bool done = false;
-    if (!done) { vce_allow_lds(vce_token_kernel<KD, 0>, lds); done = true; }
+    if (!done) { vce_allow_lds(vce_token_kernel<KD, 0, 1>, lds); vce_allow_lds(vce_token_kernel<KD, 0, 2>, lds); done = true; }
     a.ntt = (int)ntt;
-    vce_token_kernel<KD, 0><<<(unsigned)(ntt * a.parts), 512, lds, st>>>(a);
+    if (nh == 2) vce_token_kernel<KD, 0, 2><<<(unsigned)(ntt * a.parts), 512, lds, st>>>(a);
+    else vce_token_kernel<KD, 0, 1><<<(unsigned)(ntt * a.parts), 512, lds, st>>>(a);
     vce_lse_kernel<<<(unsigned)ceil_div64(a.R, 256), 256, 0, st>>>(a, lse2);
     return b4c_check_launch("vocab_lse");
 }
@@ -1002,4 +1058,480 @@ extern "C" int b4c_vocab_ce_dw_labels(const void *h, int ld_h, const int32_t *la
     if (K == 128) vce_dw_label_launch<128>(a, labels, (float *)workspace, (hipStream_t)stream);
     else vce_dw_label_launch<64>(a, labels, (float *)workspace, (hipStream_t)stream);
     return b4c_check_launch("vocab_ce_dw_labels");
+}
+
+// ==========================================================================================================
+// Logits-free RANKING over the vocabulary (R15: tf.math.top_k + Recall / NDCG, utils.py:161-190, 225-255) for the bf16
+// scoring path: the (R x V) scores never reach HBM.  Softmax is monotone, so the logits rank as the probabilities do.
+//   b4c_vocab_rank   the metrics need one number per row: how many items rank before the true one,
+//                    rank = #{j : x_j > x_y} + #{j < y : x_j == x_y}   (tf.math.top_k: ties -> lower index first);
+//                    HitRate@k = [rank < k], NDCG@k = [rank < k] / log2(rank + 2) for EVERY k from one sweep.
+//                    x_y is produced first by the same MFMA chain on gathered label rows (bit-identical to the sweep's
+//                    own value of that entry), then one sweep counts.
+//   b4c_vocab_topk   the ids: sweep A keeps, per lane, the running maximum of each of its 16 accumulator slots (16 disjoint
+//                    classes of the lane's share of the vocabulary; parts x 4 lanes per token -> 16 x parts x 4 disjoint
+//                    classes per row); the k-th largest class maximum tau is a lower bound of the row's k-th largest
+//                    score (k distinct entries reach it).  Sweep B recomputes the logits and appends every entry >= tau
+//                    to the row's candidate list (about k + 1 of them); one wave per row orders the candidates (score
+//                    descending, index ascending).  Rows with more than VCE_CAND candidates (mass ties) are reported in
+//                    `overflow` with ids -1: the caller ranks those rows on materialised scores.
+// The logits are formed as b4c_gemm_nt forms them (accumulate from zero over k, add the bias last), so that on operands
+// whose products are exact the ids are those of b4c_topk_rows on the materialised fp32 logits.
+// ==========================================================================================================
+#define VCE_CAND 128
+enum { SCAN_RANK = 0, SCAN_CLASSMAX = 1, SCAN_COLLECT = 2 };
+
+struct VceScanArgs {
+    const bf16_t *h;
+    const bf16_t *wt;
+    const float *bias;
+    const int32_t *labels;    // RANK
+    const float *xy;          // RANK: the label's logit per row (+inf: row ignored)
+    int32_t *rank;            // RANK: += counts (pre-set by vce_label_logit_kernel)
+    float *cm;                // CLASSMAX: [parts * 4][R][16]
+    const float *tau;         // COLLECT: [R]
+    int32_t *cnt;             // COLLECT: [R] candidates so far
+    float *cand_v;            // COLLECT: [R][VCE_CAND]
+    int32_t *cand_i;
+    int ld_h, ld_w;
+    int64_t R;
+    int V, parts, ntt;
+};
+
+// x_y[row] = h_row . W[y] + b[y] through the MFMA chain of the sweeps (32 rows per wave: A = the 32 label rows of W gathered
+// straight from memory, B = the 32 token rows; the diagonal of the 32 x 32 tile).  Rows without a valid label: +inf, rank -1.
+template <int KD>
+__global__ void __launch_bounds__(64) vce_label_logit_kernel(VceScanArgs a, float *__restrict__ xy, int32_t *__restrict__ rank) {
+    constexpr int NKS = KD / 16;
+    const int lane = threadIdx.x, r = lane & 31, hf = lane >> 5;
+    const int64_t tok = (int64_t)blockIdx.x * 32 + r;
+    const int y = tok < a.R ? a.labels[tok] : -1;
+    const bool valid = y >= 0 && y < a.V;
+    bf16x8 hfr[NKS];
+    vce_load_hfrag<KD>(a.h, a.ld_h, tok, a.R, hf, hfr);
+    f32x16 acc;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        vu32x4 q = {0u, 0u, 0u, 0u};
+        if (valid) q = *reinterpret_cast<const vu32x4 *>(a.wt + (int64_t)y * a.ld_w + ks * 16 + hf * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q), hfr[ks], acc, 0, 0, 0);
+    }
+    // D[row i][col j] = W[y_i] . h_j: the diagonal element of token r sits in the lane with hf = (r >> 2) & 1, register
+    // (r & 3) + 4 (r >> 3)
+    const int t_diag = (r & 3) + 4 * (r >> 3);
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v = (t == t_diag) ? acc[t] : v;
+    if (hf == ((r >> 2) & 1) && tok < a.R) {
+        xy[tok] = valid ? v + (a.bias ? a.bias[y] : 0.f) : INFINITY;
+        rank[tok] = valid ? 0 : -(1 << 30);
+    }
+}
+
+// NH = 1: 128 tokens per workgroup, 8 waves = 4 token groups x the 2 halves of each 128-row W tile;
+// NH = 2: 256 tokens per workgroup, 8 token groups, every wave takes both halves in turn -- each W tile (32 KB by LDS-DMA
+// from L2 / Infinity Cache: the sweeps stream the whole of W once per token tile, 4.1 GB per sweep at C2, and that stream, not
+// the matrix pipe, paces them) serves twice the tokens.
+template <int KD, int OP, int NH>
+__global__ void __launch_bounds__(512, 2) vce_scan_kernel(VceScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NKS = KD / 16, STR = VTile<KD>::STR;
+    constexpr int TILE_B = VTile<KD>::BYTES;
+    float *sBias = reinterpret_cast<float *>(smem + 2 * TILE_B);     // [3][128]: a ring -- the scores of a tile's second half are
+                                                                     // formed one tile later, while the next bias arrives
+    const int unit = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int tg = NH == 2 ? wave : (wave & 3), vh = NH == 2 ? 0 : (wave >> 2);
+    const int64_t tok0 = (int64_t)(unit % a.ntt) * (128 * NH);
+    const int64_t tok = tok0 + tg * 32 + r;
+    const int part = unit / a.ntt;
+    const int nvt = (a.V + 127) >> 7;
+    const int vt0 = (int)((int64_t)nvt * part / a.parts), vt1 = (int)((int64_t)nvt * (part + 1) / a.parts);
+    const bool live = tok < a.R;
+
+    bf16x8 hfr[NKS];
+    vce_load_hfrag<KD>(a.h, a.ld_h, tok, a.R, hf, hfr);
+    int foff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) foff[ks] = VTile<KD>::frag_off(r, ks, hf) + vh * 64 * STR;
+
+    // per-lane state
+    float ref = INFINITY;          // RANK: x_y;  COLLECT: tau  (+inf: nothing counts / nothing is collected)
+    int y = -1;
+    if (OP == SCAN_RANK && live) { ref = a.xy[tok]; y = a.labels[tok]; }
+    if (OP == SCAN_COLLECT && live) ref = a.tau[tok];
+    unsigned n_before = 0;         // RANK
+    float cm[16];                  // CLASSMAX
+#pragma unroll
+    for (int t = 0; t < 16; ++t) cm[t] = -INFINITY;
+
+    float breg = 0.f;
+    auto fetch = [&](int vt, int buf) {
+        VTile<KD>::template dma<512>(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, smem + buf * TILE_B, tid);
+        if (tid < 128) {
+            const int v = vt * 128 + tid;
+            breg = (vt < vt1 && v < a.V) ? (a.bias ? a.bias[v] : 0.f) : -INFINITY;   // rows past V: score = -inf
+        }
+    };
+    fetch(vt0, 0);
+    if (tid < 128) sBias[tid] = breg;
+    VCE_DMA_WAIT();
+    __syncthreads();
+
+    // One half-tile (64 vocabulary rows x the wave's 32 tokens) = 16 MFMAs into acc, then ~4 VALU instructions per entry
+    // on the result.  A VALU wave-instruction holds the SIMD's issue port for 4 cycles, an MFMA for 8 of its 32: run one
+    // after the other the two phases add up (measured: matrix pipe 36 % busy, VALU issue 43 %, sum 79 % of the kernel's
+    // cycles); interleaved -- the MFMA chain of one half-tile issued between the VALU instructions of the previous one --
+    // they overlap.  So the loop is software-pipelined by half a tile: `scores` of half-tile i runs inside the instruction
+    // stream of `chain` of half-tile i + 1 (sched_group_barrier pins the interleave), on two accumulator sets.
+    // one entry of a half-tile's scores: x = accumulator + bias (the bias last, as the materialising GEMM adds it; rows past
+    // V: -inf); RANK: count it if it beats x_y, note an equal one; CLASSMAX: the running maximum of its accumulator slot;
+    // COLLECT: note one that reaches tau
+    bool hot = false;
+    auto entry = [&](f32x16 (&acc)[2], int rt, int t, float bj) __attribute__((always_inline)) {
+        const float x = acc[rt][t] + bj;
+        acc[rt][t] = x;
+        if (OP == SCAN_RANK) {
+            n_before += x > ref ? 1u : 0u;
+            hot |= x == ref;
+        } else if (OP == SCAN_CLASSMAX) {
+            cm[t] = fmaxf(cm[t], x);
+        } else {
+            hot |= x >= ref;
+        }
+    };
+    // The 16 MFMAs of a half-tile's chain into accN, and -- WITH = true -- between them the scores of the half-tile before
+    // it (accP: 32 entries per lane, two per MFMA).  sched_barrier(0) after every MFMA's group pins the interleave (left to
+    // itself, or to sched_group_barrier, the compiler issues the sixteen MFMAs first and the VALU after them).
+    auto chain = [&](auto WITH, f32x16 (&accN)[2], const char *w, f32x16 (&accP)[2], const float *bs, int vhe) __attribute__((always_inline)) {
+        constexpr bool with = decltype(WITH)::value;
+        bf16x8 wfq[NKS];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) accN[rt][t] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) wfq[ks] = *reinterpret_cast<const bf16x8 *>(w + foff[ks]);
+        hot = false;
+        // the eight bias quads of the previous half-tile are requested up front, with the first fragments: a quad requested
+        // where it is used parks the wave for a full LDS round trip (~130 cycles) sixteen times per tile
+        f32x4 bq[8];
+        if (with) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bq[q] = *reinterpret_cast<const f32x4 *>(bs + vhe * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hf);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NKS; ++i) {
+            const int rt = i / NKS, ks = i % NKS;
+            __builtin_amdgcn_sched_barrier(0);
+            accN[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfq[ks], hfr[ks], accN[rt], 0, 0, 0);
+            if (rt == 0) wfq[ks] = *reinterpret_cast<const bf16x8 *>(w + 32 * STR + foff[ks]);
+            if (with) {
+                // entries 2 i, 2 i + 1 of the previous half-tile (NKS = 8: all 32; NKS = 4: the rest follows the chain)
+#pragma unroll
+                for (int e = 2 * i; e < 2 * i + 2; ++e) entry(accP, e >> 4, e & 15, bq[e >> 2][e & 3]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (with && NKS < 8) {
+#pragma unroll
+            for (int e = 4 * NKS; e < 32; ++e) entry(accP, e >> 4, e & 15, bq[e >> 2][e & 3]);
+        }
+    };
+    // the scores of a half-tile on their own (NH = 1; the last half-tile of NH = 2)
+    auto scores = [&](f32x16 (&acc)[2], const float *bs, int vhe) __attribute__((always_inline)) {
+        hot = false;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bs + vhe * 64 + rt * 32 + 8 * tq + 4 * hf);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) entry(acc, rt, 4 * tq + k, b4[k]);
+            }
+    };
+    auto rare = [&](f32x16 (&acc)[2], int vt, int vhe) __attribute__((always_inline)) {       // the half-tile that holds the label / a candidate
+        const int row0 = vt * 128 + vhe * 64 + 4 * hf;
+        int slot = 0;
+        if (OP == SCAN_COLLECT) {          // the lane's candidates of this half-tile take consecutive slots: one atomic
+            int n = 0;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    n += (acc[rt][t] >= ref && row0 + rt * 32 + (t & 3) + 8 * (t >> 2) < a.V) ? 1 : 0;
+            if (n) slot = atomicAdd(a.cnt + tok, n);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = row0 + rt * 32 + (t & 3) + 8 * (t >> 2);
+                const float x = acc[rt][t];
+                if (OP == SCAN_RANK) {
+                    n_before += (x == ref && j < y) ? 1u : 0u;        // ties: the lower index ranks first
+                } else if (x >= ref && j < a.V) {
+                    if (slot < VCE_CAND) {
+                        a.cand_v[tok * VCE_CAND + slot] = x;
+                        a.cand_i[tok * VCE_CAND + slot] = j;
+                    }
+                    ++slot;
+                }
+            }
+    };
+    f32x16 accA[2], accB[2];
+    int vt_prev = vt0;
+    bool have_prev = false;
+    int bcur = 0, bprev = 2;           // bias ring slots of this tile and of the previous one; the next one's goes to the third
+#ifdef VCE_SCAN_STAMPS
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
+#endif
+    constexpr std::integral_constant<bool, true> YES{};
+    constexpr std::integral_constant<bool, false> NO{};
+    auto tile = [&](auto BUF, int vt) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::value;
+        VCE_STAMP(5);
+        fetch(vt + 1, buf ^ 1);
+        VCE_STAMP(0);
+        const char *w = smem + buf * TILE_B;
+        const int bnext = 3 - bcur - bprev;
+        if (NH == 2) {
+            // accA <- half 0 of this tile, beside the scores of the previous tile's half 1 (accB)
+            if (have_prev) {
+                chain(YES, accA, w, accB, sBias + bprev * 128, 1);
+                if (OP != SCAN_CLASSMAX && __any(hot)) rare(accB, vt_prev, 1);
+            } else {
+                chain(NO, accA, w, accB, sBias, 0);
+            }
+            VCE_STAMP(1);
+            // accB <- half 1, beside the scores of half 0
+            chain(YES, accB, w + 64 * STR, accA, sBias + bcur * 128, 0);
+            if (OP != SCAN_CLASSMAX && __any(hot)) rare(accA, vt, 0);
+            VCE_STAMP(2);
+            have_prev = true;
+            vt_prev = vt;
+        } else {
+            chain(NO, accA, w, accB, sBias, 0);
+            scores(accA, sBias + bcur * 128, vh);
+            if (OP != SCAN_CLASSMAX && __any(hot)) rare(accA, vt, vh);
+        }
+        if (tid < 128) sBias[bnext * 128 + tid] = breg;
+        bprev = bcur;
+        bcur = bnext;
+        VCE_DMA_WAIT();
+        VCE_STAMP(3);
+        B4C_LDS_BARRIER();
+        VCE_STAMP(4);
+    };
+    for (int vt = vt0; vt < vt1; vt += 2) {
+        tile(std::integral_constant<int, 0>{}, vt);
+        if (vt + 1 < vt1) tile(std::integral_constant<int, 1>{}, vt + 1);
+    }
+    if (NH == 2 && have_prev) {          // the last half-tile's scores
+        scores(accB, sBias + bprev * 128, 1);
+        if (OP != SCAN_CLASSMAX && __any(hot)) rare(accB, vt_prev, 1);
+    }
+#ifdef VCE_SCAN_STAMPS
+    if (lane == 0 && blockIdx.x < 2048)
+        for (int k = 0; k < 6; ++k) g_vce_stamps[(blockIdx.x * 8 + wave) * 6 + k] = st_[k];
+#endif
+    if (!live) return;
+    if (OP == SCAN_RANK) {
+        if (n_before) atomicAdd(a.rank + tok, (int)n_before);          // integer adds: any order gives the same count
+    } else if (OP == SCAN_CLASSMAX) {
+        // sub-list index: (part, half of the tile, lane half) for NH = 1; (part, lane half) for NH = 2 (a.nsub_per_part of them)
+        const int sub = NH == 2 ? part * 2 + hf : part * 4 + vh * 2 + hf;
+        float *o = a.cm + ((int64_t)sub * a.R + tok) * 16;
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) *reinterpret_cast<f32x4 *>(o + 4 * tq) = (f32x4){cm[4 * tq], cm[4 * tq + 1], cm[4 * tq + 2], cm[4 * tq + 3]};
+    }
+}
+
+// tau[row] = k-th largest of the row's nsub * 16 class maxima (one wave per row; k rounds of "take the maximum out")
+__global__ void __launch_bounds__(256) vce_tau_kernel(const float *__restrict__ cm, int nsub, int64_t R, int k, float *__restrict__ tau,
+                                                      int32_t *__restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    // nsub <= 32 -> at most 512 values, 8 per lane: value e of the row lives in sub-list e / 16, slot e % 16
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = e < nsub * 16 ? cm[((int64_t)(e >> 4) * R + row) * 16 + (e & 15)] : -INFINITY;
+    }
+    float kth = -INFINITY;
+    for (int round = 0; round < k; ++round) {
+        float m = v[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) m = fmaxf(m, v[i]);
+        const float wm = wave_max(m);
+        kth = wm;
+        const unsigned long long owners = __ballot(m == wm);
+        if (lane == __ffsll((long long)owners) - 1) {          // one instance leaves
+            bool done = false;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (!done && v[i] == wm) { v[i] = -INFINITY; done = true; }
+        }
+    }
+    if (lane == 0) { tau[row] = kth; cnt[row] = 0; }
+}
+
+// one wave per row: the candidates in order (score descending, index ascending) -> ids [k], optional hit / ndcg of the label
+__global__ void __launch_bounds__(256) vce_select_kernel(const float *__restrict__ cand_v, const int32_t *__restrict__ cand_i,
+                                                         const int32_t *__restrict__ cnt, int64_t R, int V, int k, int32_t *__restrict__ idx,
+                                                         const int32_t *__restrict__ labels, float *__restrict__ hit, float *__restrict__ ndcg,
+                                                         int32_t *__restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int n = cnt[row];
+    const int y = labels ? labels[row] : -1;
+    if (n > VCE_CAND) {            // mass ties: the caller ranks this row on materialised scores
+        if (lane < k) idx[row * k + lane] = -1;
+        if (lane == 0) {
+            atomicAdd(overflow, 1);
+            if (hit) { hit[row] = __builtin_nanf(""); ndcg[row] = __builtin_nanf(""); }
+        }
+        return;
+    }
+    float v[2];
+    int id[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = e < n ? cand_v[row * VCE_CAND + e] : -INFINITY;
+        id[i] = e < n ? cand_i[row * VCE_CAND + e] : 0x7fffffff;
+    }
+    int rk[2] = {0, 0};
+    for (int j = 0; j < n; ++j) {          // wave-uniform trip count
+        const float vj = __shfl(j < 64 ? v[0] : v[1], j & 63);
+        const int ij = __shfl(j < 64 ? id[0] : id[1], j & 63);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rk[i] += (vj > v[i] || (vj == v[i] && ij < id[i])) ? 1 : 0;
+    }
+    float h = 0.f, g = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = lane + 64 * i;
+        if (e < n && rk[i] < k) {
+            idx[row * k + rk[i]] = id[i];
+            if (id[i] == y) { h = 1.f; g = 1.0f / (logf((float)(rk[i] + 2)) / logf(2.0f)); }
+        }
+    }
+    if (n < k && lane >= n && lane < k) idx[row * k + lane] = -1;          // fewer than k items in all
+    if (hit) {
+        h = wave_sum(h);
+        g = wave_sum(g);
+        if (lane == 0) { hit[row] = h; ndcg[row] = g; }
+    }
+}
+
+// hit@k / ndcg@k from the rank of the true item (utils.py:176-190, 245-255); rows with rank < 0 (no valid label): 0
+__global__ void __launch_bounds__(256) vce_rank_metrics_kernel(const int32_t *__restrict__ rank, int64_t R, int k, float *__restrict__ hit,
+                                                               float *__restrict__ ndcg) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= R) return;
+    const int rk = rank[i];
+    const bool in = rk >= 0 && rk < k;
+    hit[i] = in ? 1.f : 0.f;
+    ndcg[i] = in ? 1.0f / (logf((float)(rk + 2)) / logf(2.0f)) : 0.f;
+}
+
+extern "C" int64_t b4c_vocab_rank_workspace_bytes(int64_t R, int V, int K) {
+    if (R <= 0 || V <= 0 || !vce_shape_ok(K)) return 0;
+    // class maxima [32][R][16] | tau [R] | cnt [R] | candidates [R][VCE_CAND] x (score, id) | x_y [R]
+    return R * ((int64_t)32 * 16 * 4 + 4 + 4 + (int64_t)VCE_CAND * 8 + 4) + 256;
+}
+
+static int vce_scan_check(const void *h, int ld_h, const void *wt, int ld_w, void *workspace, int64_t workspace_bytes, int64_t R, int V,
+                          int K, const char *who) {
+    B4C_REQUIRE(h && wt && workspace, "%s: null pointer", who);
+    B4C_REQUIRE(vce_shape_ok(K), "%s: K=%d unsupported (64 or 128)", who, K);
+    B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ld_w >= K, "%s: shape", who);
+    B4C_REQUIRE(ld_h % 8 == 0 && ld_w % 8 == 0 && ((((uintptr_t)h | (uintptr_t)wt | (uintptr_t)workspace) & 15) == 0),
+                "%s: operands must be 16-byte aligned with pitches %% 8 == 0", who);
+    B4C_REQUIRE(workspace_bytes >= b4c_vocab_rank_workspace_bytes(R, V, K), "%s: workspace too small", who);
+    return B4C_OK;
+}
+
+// tokens per workgroup of the scans: 256 (each W tile serves twice the tokens) once there are enough token tiles to fill the
+// chip; B4C_VCE_SCAN_TOKENS=128|256 overrides (A/B)
+static int vce_scan_nh(int64_t R) {
+    static const char *e = getenv("B4C_VCE_SCAN_TOKENS");
+    if (e) return atoi(e) >= 256 ? 2 : 1;
+    return R >= 256 * 64 ? 2 : 1;
+}
+static void vce_scan_geometry(VceScanArgs &a, int nh) {
+    a.ntt = (int)ceil_div64(a.R, 128 * nh);
+    a.parts = vce_pick_split(a.ntt, (a.V + 127) / 128, 0.005);
+}
+template <int KD, int OP>
+static void vce_scan_launch(VceScanArgs a, int nh, hipStream_t st) {
+    const size_t lds = 2 * (size_t)VTile<KD>::BYTES + 3 * 128 * 4;
+    static thread_local bool done = false;
+    if (!done) { vce_allow_lds(vce_scan_kernel<KD, OP, 1>, lds); vce_allow_lds(vce_scan_kernel<KD, OP, 2>, lds); done = true; }
+    if (nh == 2) vce_scan_kernel<KD, OP, 2><<<(unsigned)(a.ntt * a.parts), 512, lds, st>>>(a);
+    else vce_scan_kernel<KD, OP, 1><<<(unsigned)(a.ntt * a.parts), 512, lds, st>>>(a);
+}
+
+extern "C" int b4c_vocab_rank(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels, int32_t *rank,
+                              void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, void *stream) {
+    if (int rc = vce_scan_check(h, ld_h, wt, ld_w, workspace, workspace_bytes, R, V, K, "vocab_rank")) return rc;
+    B4C_REQUIRE(labels && rank, "vocab_rank: null pointer");
+    if (R == 0) return B4C_OK;
+    hipStream_t st = (hipStream_t)stream;
+    VceScanArgs a = {};
+    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias; a.labels = labels; a.rank = rank;
+    a.ld_h = ld_h; a.ld_w = ld_w; a.R = R; a.V = V;
+    const int nh = vce_scan_nh(R);
+    vce_scan_geometry(a, nh);
+    float *xy = (float *)workspace;
+    a.xy = xy;
+    if (K == 128) {
+        vce_label_logit_kernel<128><<<(unsigned)ceil_div64(R, 32), 64, 0, st>>>(a, xy, rank);
+        vce_scan_launch<128, SCAN_RANK>(a, nh, st);
+    } else {
+        vce_label_logit_kernel<64><<<(unsigned)ceil_div64(R, 32), 64, 0, st>>>(a, xy, rank);
+        vce_scan_launch<64, SCAN_RANK>(a, nh, st);
+    }
+    return b4c_check_launch("vocab_rank");
+}
+
+extern "C" int b4c_rank_metrics(const int32_t *rank, int64_t R, int k, float *hit, float *ndcg, void *stream) {
+    B4C_REQUIRE(rank && hit && ndcg && R >= 0 && k >= 1, "rank_metrics: bad argument");
+    if (R == 0) return B4C_OK;
+    vce_rank_metrics_kernel<<<(unsigned)ceil_div64(R, 256), 256, 0, (hipStream_t)stream>>>(rank, R, k, hit, ndcg);
+    return b4c_check_launch("rank_metrics");
+}
+
+extern "C" int b4c_vocab_topk(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, int k, int32_t *idx,
+                              const int32_t *labels, float *hit, float *ndcg, int32_t *overflow, void *workspace,
+                              int64_t workspace_bytes, int64_t R, int V, int K, void *stream) {
+    if (int rc = vce_scan_check(h, ld_h, wt, ld_w, workspace, workspace_bytes, R, V, K, "vocab_topk")) return rc;
+    B4C_REQUIRE(idx && overflow && k >= 1 && k <= B4C_MAX_TOPK, "vocab_topk: k = %d (1 .. %d)", k, B4C_MAX_TOPK);
+    B4C_REQUIRE(!labels || (hit && ndcg), "vocab_topk: labels need hit and ndcg");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(overflow, 0, 4, st);
+    if (R == 0) return B4C_OK;
+    VceScanArgs a = {};
+    a.h = (const bf16_t *)h; a.wt = (const bf16_t *)wt; a.bias = bias;
+    a.ld_h = ld_h; a.ld_w = ld_w; a.R = R; a.V = V;
+    const int nh = vce_scan_nh(R);
+    vce_scan_geometry(a, nh);
+    char *ws = (char *)workspace;
+    a.cm = (float *)ws;                         ws += (size_t)R * 32 * 16 * 4;
+    float *tau = (float *)ws;                   ws += (size_t)R * 4;
+    a.cnt = (int32_t *)ws;                      ws += (size_t)R * 4;
+    a.cand_v = (float *)ws;                     ws += (size_t)R * VCE_CAND * 4;
+    a.cand_i = (int32_t *)ws;
+    a.tau = tau;
+    if (K == 128) vce_scan_launch<128, SCAN_CLASSMAX>(a, nh, st); else vce_scan_launch<64, SCAN_CLASSMAX>(a, nh, st);
+    vce_tau_kernel<<<(unsigned)ceil_div64(R, 4), 256, 0, st>>>(a.cm, a.parts * (nh == 2 ? 2 : 4), R, k, tau, a.cnt);
+    if (K == 128) vce_scan_launch<128, SCAN_COLLECT>(a, nh, st); else vce_scan_launch<64, SCAN_COLLECT>(a, nh, st);
+    vce_select_kernel<<<(unsigned)ceil_div64(R, 4), 256, 0, st>>>(a.cand_v, a.cand_i, a.cnt, R, V, k, idx, labels, hit, ndcg, overflow);
+    return b4c_check_launch("vocab_topk");
 }

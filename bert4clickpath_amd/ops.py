@@ -882,6 +882,63 @@ def vocab_softmax(h, wt, bias, Np, V):
     return probs
 
 
+fused_rank = True      # bf16 scoring path: ranks / top-k ids without the (R x V) scores in memory (b4c_vocab_rank, b4c_vocab_topk)
+_rank_ws = {}
+
+
+def _rank_workspace(h, R, V, K):
+    need = L.lib().b4c_vocab_rank_workspace_bytes(R, V, K)
+    ws = _rank_ws.get(h.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=h.device)
+        _rank_ws[h.device] = ws
+    return ws
+
+
+def vocab_rank(h, wt, bias, labels_i32, V):
+    """rank [R] int32 of the label among the V scores h wt^T + bias (items ranked before it; ties -> lower index first;
+    negative: no valid label).  The scores never exist in memory."""
+    _cuda(h)
+    R, K = h.shape
+    rank = torch.empty(R, dtype=torch.int32, device=h.device)
+    if R == 0:
+        return rank
+    ws = _rank_workspace(h, R, V, K)
+    with _record('vocab_rank', R * K * 2 + V * K * 2, 2 * R * V * K):
+        L.check(L.lib().b4c_vocab_rank(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(rank), ws.data_ptr(),
+                                       ws.numel(), R, V, K, _st()), 'vocab_rank')
+    return rank
+
+
+def rank_metrics(rank, k):
+    """-> (hit [R], ndcg [R]) fp32: [rank < k], [rank < k] / log2(rank + 2); rows with a negative rank: 0"""
+    R = rank.shape[0]
+    hit = torch.empty(R, dtype=torch.float32, device=rank.device)
+    ndcg = torch.empty(R, dtype=torch.float32, device=rank.device)
+    if R:
+        L.check(L.lib().b4c_rank_metrics(_p(rank), R, k, _p(hit), _p(ndcg), _st()), 'rank_metrics')
+    return hit, ndcg
+
+
+def vocab_topk(h, wt, bias, V, k, labels_i32=None):
+    """-> (idx [R, k] int32, hit, ndcg (when labels are given), overflow int32 [1]): the k best item ids of every row of
+    h wt^T + bias in order, scores never in memory.  overflow[0] rows (ids -1) have too many ties at the selection
+    threshold: rank those on materialised scores."""
+    _cuda(h)
+    R, K = h.shape
+    idx = torch.empty(R, k, dtype=torch.int32, device=h.device)
+    hit = torch.empty(R, dtype=torch.float32, device=h.device) if labels_i32 is not None else None
+    ndcg = torch.empty(R, dtype=torch.float32, device=h.device) if labels_i32 is not None else None
+    overflow = torch.empty(1, dtype=torch.int32, device=h.device)
+    if R == 0:
+        return idx, hit, ndcg, overflow.zero_()
+    ws = _rank_workspace(h, R, V, K)
+    with _record('vocab_topk', 2 * (R * K * 2 + V * K * 2), 4 * R * V * K):
+        L.check(L.lib().b4c_vocab_topk(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), k, _p(idx), _p(labels_i32), _p(hit),
+                                       _p(ndcg), _p(overflow), ws.data_ptr(), ws.numel(), R, V, K, _st()), 'vocab_topk')
+    return idx, hit, ndcg, overflow
+
+
 class VocabSoftmaxFn(torch.autograd.Function):
     """Dense(V, softmax) (head.py:36) on the head's trunk output, probabilities materialised once, logits never:
     apply(h [R, K] bf16, pack, V, kernel, bias) -> probs [R, Np].  Backward: the softmax Jacobian on the saved

@@ -278,6 +278,26 @@ int b4c_vocab_lse(const void *h, int ld_h, const void *wt, int ld_w, const float
 int b4c_gemm_nt_softmax(const void *A, int lda, const void *Bt, int ldb, void *C, int ldc, int M, int N, int K,
                         const float *bias, const float *lse2, void *stream);
 
+/* ---- (ABI version 8) R15 without the (R x V) scores in memory: ranking over the vocabulary for the bf16 scoring path -----
+ * replaces tf.math.top_k + the Recall / NDCG bookkeeping (utils.py:161-190, 225-255) on MATERIALISED probabilities
+ * (b4c_gemm_nt_softmax + b4c_topk_rows: 4.1 GB written and read back at C2) by sweeps that keep the logits tile in MFMA
+ * accumulators.  Softmax is monotone: the logits rank as the probabilities do.  h [R][ld_h] bf16 (trunk output), wt
+ * [>= V][ld_w] bf16 vocabulary-major, bias fp32 [V] or NULL, K in {64, 128}; workspace >= b4c_vocab_rank_workspace_bytes.
+ * Scores are formed as b4c_gemm_nt forms them (sum over k from zero, bias last).
+ *   b4c_vocab_rank: rank[r] = number of items ranked before the label y_r = #{j : x_j > x_y} + #{j < y : x_j == x_y}
+ *     (ties -> lower index first, as tf.math.top_k); negative for rows without a valid label (y < 0 or y >= V).
+ *     HitRate@k = [rank < k], NDCG@k = [rank < k] / log2(rank + 2) for every k: b4c_rank_metrics.
+ *   b4c_vocab_topk: idx [R][k] int32 = the k best item ids in order (k <= B4C_MAX_TOPK), optional hit / ndcg [R] of `labels`.
+ *     Rows with more than 128 candidates at the selection threshold (mass ties) get ids -1 (hit / ndcg NaN) and are counted
+ *     in overflow[0]: the caller ranks those rows on materialised scores (b4c_gemm_nt + b4c_topk_rows). */
+int64_t b4c_vocab_rank_workspace_bytes(int64_t R, int V, int K);
+int b4c_vocab_rank(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels, int32_t *rank,
+                   void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, void *stream);
+int b4c_rank_metrics(const int32_t *rank, int64_t R, int k, float *hit, float *ndcg, void *stream);
+int b4c_vocab_topk(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, int k, int32_t *idx,
+                   const int32_t *labels, float *hit, float *ndcg, int32_t *overflow, void *workspace,
+                   int64_t workspace_bytes, int64_t R, int V, int K, void *stream);
+
 /* ---- (ABI version 4) scalar bookkeeping of the masked mean (losses.py:80-98) and of the head's backward, fused:
  * b4c_label_scale: out[0] = 1 / n_valid (0 if none), out[1] = n_valid, valid = 0 <= label < V (the mask of losses.py:80).
  * b4c_sum_scaled:  out[0] = scale[0] * sum item[0..R) in a fixed order; NaN if poison != NULL and poison[0] < 0.
