@@ -254,18 +254,24 @@ def test_c4_shape_matches_oracle_fp32_and_bf16(gpu):
         if float(gr.abs().max()) < 1e-9:
             continue
         assert float((p.grad.cpu().double() - gr).abs().max()) < 2e-4 * float(gr.abs().max()), n
+    from bert4clickpath_amd import ops
+    from bf16_gates import BF16_GRAD_BOUND, GateRecorder, grad_errors
     m16 = _c4_model(torch.bfloat16, layers=2, Vi=Vi, Va=Va, seed=9)
     m16.load_state_dict(m32.state_dict())
-    l16 = m16.cloze_loss({'asin': items, 'act': act_items}, labels, training=True)
+    with GateRecorder(ops) as rec:
+        l16 = m16.cloze_loss({'asin': items, 'act': act_items}, labels, training=True)
     l16.backward()
     assert abs(float(l16) - float(ref)) < 5e-3 * float(ref)
-    worst = 0.0
-    for n, p in m16.named_parameters():
-        gr = P[n].grad
-        if float(gr.abs().max()) < 1e-9:
-            continue
-        worst = max(worst, float((p.grad.cpu().double() - gr).norm() / gr.norm()))
-    assert worst < 0.2, worst       # bf16 carries 8 significant bits; the q / k projections of a 2-layer toy model are the noisiest
+    # the shared bf16 bound: the fp64 oracle evaluated with the device pass's own ReLU on / off patterns (tests/bf16_gates.py)
+    relu = rec.relu_for(2, 4, torch.from_numpy(b['flat_idx']).long(), B, S)
+    for v in P.values():
+        v.grad = None
+    enc = tr.transformer_forward({'items': ids.cpu(), 'actions': acts.cpu()}, tP, 2, 4, relu=relu)
+    rows, _ = tr.gather_masked_rows(enc, ids.cpu())
+    tr.sparse_ce_tf(torch.softmax(tr.softmax_head_logits(rows, hP, 4, relu=relu), -1), torch.from_numpy(b['labels']).long()).mean().backward()
+    errs = grad_errors(m16.named_parameters(), {n: P[n].grad for n, _ in m16.named_parameters()})
+    name, worst = max(errs.items(), key=lambda kv: kv[1])
+    assert worst < BF16_GRAD_BOUND, (name, worst)
 
 
 def test_c5_shape_slice_runs_on_the_mfma_and_sampled_paths(gpu):

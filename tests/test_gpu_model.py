@@ -163,27 +163,34 @@ def test_gradients_match_oracle_fp32(gpu, dropout):
 
 
 def test_train_step_bf16_tracks_fp32_oracle(gpu):
-    """bf16 storage / fp32 accumulate path against the fp64 oracle (which uses the fp32 master weights):
-    loss within 2e-3 relative, every gradient tensor within 12% in L2 (measured over three seeds, with the last layer
-    evaluated in full and at the [MASK] rows only: worst tensor 5-11%, either form better on some seeds -- scratch/mq_err.py;
-    the fp32 HIP path on the same inputs is at 1e-6, see test_gradients_match_oracle_fp32) -- the documented bf16
-    tolerance: weights, activations and activation gradients are rounded to 8 significant bits."""
+    """bf16 storage / fp32 accumulate path against the fp64 oracle (which uses the fp32 master weights): loss within 2e-3
+    relative; every gradient tensor within bf16_gates.BF16_GRAD_BOUND (3 %) in L2 of the oracle evaluated with the device
+    pass's own ReLU on / off patterns -- exact arithmetic and the arithmetic with the path's bf16 rounding points emulated
+    both (measured 0.2 - 1.2 %).  The plain fp64 comparison (the oracle's own patterns) is reported, not asserted: it reads
+    5 - 11 % because ~0.5 % of the ReLU units sit close enough to zero for bf16 rounding to flip them (tests/bf16_gates.py)."""
+    from bert4clickpath_amd import ops
+    from bf16_gates import BF16_GRAD_BOUND, GateRecorder, grad_errors
     V, d, L, H, B, S = 1000, 64, 2, 2, 16, 50
     model, batch = _random_model_and_batch(11, V, d, L, H, [128, 64], B, S, 0.0, torch.bfloat16)
     ids = torch.from_numpy(batch['ids'])
     items = ids[:, 2:S - 1].contiguous().cuda()
-    loss = model.cloze_loss({'asin': items}, torch.from_numpy(batch['labels_padded']).cuda(), training=True)
+    with GateRecorder(ops) as rec:
+        loss = model.cloze_loss({'asin': items}, torch.from_numpy(batch['labels_padded']).cuda(), training=True)
     loss.backward()
-    Pt = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
-    ref_loss, _ = tr.model_loss(ids, torch.from_numpy(batch['labels']).long(), Pt, L, H, 2)
-    ref_loss.backward()
-    assert abs(float(loss) - float(ref_loss)) < 2e-3 * float(ref_loss)
-    for name, p in model.named_parameters():
-        gr = Pt[name].grad
-        if float(gr.abs().max()) < 1e-9:      # key-bias gradient: identically zero
-            continue
-        err = float((p.grad.cpu().double() - gr).norm() / gr.norm())
-        assert err < 0.12, (name, err)
+    relu = rec.relu_for(L, 2, torch.from_numpy(batch['flat_idx']).long(), B, S)
+    labels = torch.from_numpy(batch['labels']).long()
+    report = {}
+    for what, kw in (('fp64', {}), ('fp64 + device gates', {'relu': relu}), ('bf16-emulating + device gates', {'relu': relu, 'emulate_bf16': True})):
+        Pt = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+        ref_loss, _ = tr.model_loss(ids, labels, Pt, L, H, 2, **kw)
+        ref_loss.backward()
+        assert abs(float(loss) - float(ref_loss)) < 2e-3 * float(ref_loss), what
+        report[what] = grad_errors(model.named_parameters(), {n: Pt[n].grad for n, _ in model.named_parameters()})
+    print('worst gradient tensor, L2 relative: ' + ', '.join('%s %.2f %%' % (k, 100 * max(v.values())) for k, v in report.items()))
+    for what in ('fp64 + device gates', 'bf16-emulating + device gates'):
+        name, err = max(report[what].items(), key=lambda kv: kv[1])
+        assert err < BF16_GRAD_BOUND, (what, name, err)
+    assert max(report['fp64'].values()) < 0.25          # (sanity only: see the docstring)
 
 
 def test_adam_training_reduces_loss_and_matches_oracle_step(gpu):
