@@ -102,9 +102,9 @@ def lib():
             'b4c_softmax_ce_fwd_bwd': (i32, [vp, i32, vp, vp, vp, i64, i32, i32, i32, vp]),
             'b4c_vocab_ce_workspace_bytes': (i64, [i64, i32, i32]),
             'b4c_vocab_ce_fwd': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i64, i64, i32, i32, i32, vp]),
-            'b4c_vocab_ce_dw': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i64, i64, i32, i32, vp]),
-            'b4c_vocab_ce_dw_sweep': (i32, [vp, i32, vp, i32, vp, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, vp]),
-            'b4c_vocab_ce_dw_labels': (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i64, i64, i32, i32, vp]),
+            'b4c_vocab_ce_dw': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i64, i64, i32, i32, i32, vp]),
+            'b4c_vocab_ce_dw_sweep': (i32, [vp, i32, vp, i32, vp, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+            'b4c_vocab_ce_dw_labels': (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i64, i64, i32, i32, i32, vp]),
             'b4c_sort_ids_workspace_bytes': (i64, [i64, i32]),
             'b4c_sort_ids': (i32, [vp, i64, i32, vp, vp, i64, vp]),
             'b4c_gather_i64': (i32, [vp, vp, vp, i64, vp]),

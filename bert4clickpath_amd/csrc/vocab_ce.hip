@@ -818,6 +818,36 @@ __global__ void __launch_bounds__(256) vce_label_add_kernel(float *__restrict__ 
     }
 }
 
+// K5, deterministic form: the rows are sorted by label (stable: b4c_sort_ids), ONE wave sums each run of equal labels in row
+// order and is the only writer of that label's row of the scratch -- no float atomics, the same bits every time.
+__global__ void __launch_bounds__(256) vce_label_keys_kernel(const int32_t *__restrict__ labels, int64_t R, int V, int64_t *__restrict__ keys) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i < R) { const int y = labels[i]; keys[i] = (y >= 0 && y < V) ? y : V; }          // V: ignored rows sort to the end
+}
+template <int KD>
+__global__ void __launch_bounds__(256) vce_label_sorted_kernel(VceDwArgs a, const int64_t *__restrict__ keys, const int32_t *__restrict__ order,
+                                                               float *__restrict__ tmp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.R) return;
+    const int64_t y = keys[order[i]];
+    if (y >= a.V || (i > 0 && keys[order[i - 1]] == y)) return;           // not the first row of a run of a valid label
+    float acc[KD / 64], sb = 0.f;
+#pragma unroll
+    for (int e = 0; e < KD / 64; ++e) acc[e] = 0.f;
+    for (int64_t j = i; j < a.R; ++j) {
+        const int64_t row = order[j];
+        if (keys[row] != y) break;
+        const float yd = a.rowscal[row * 8 + 4];
+#pragma unroll
+        for (int e = 0; e < KD / 64; ++e) acc[e] += -yd * (float)a.h[row * a.ld_h + lane + 64 * e];
+        sb += -yd;
+    }
+#pragma unroll
+    for (int e = 0; e < KD / 64; ++e) tmp[y * KD + lane + 64 * e] = acc[e];
+    if (lane == 0 && a.db) a.db[y] += sb;
+}
+
 // lse2[row] = log2 sum_j 2^(x_j log2 e) from the per-part statistics of vce_token_kernel<KD, 0>
 __global__ void __launch_bounds__(256) vce_lse_kernel(VceArgs a, float *__restrict__ lse2) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -873,7 +903,8 @@ template <int KD> static size_t vce_dw_lds() {
 extern "C" int64_t b4c_vocab_ce_workspace_bytes(int64_t R, int V, int K) {
     if (R <= 0 || V <= 0 || !vce_shape_ok(K)) return 0;
     const int64_t fwd = (int64_t)8 * R * (4 + 2 * (int64_t)K + 4) * 4;   // 8 = the largest vocabulary split
-    const int64_t dw = (int64_t)V * K * 4;                              // vocabulary-major scratch of the label term
+    // vocabulary-major scratch of the label term; deterministic form: + sort keys, order and the sort's own workspace
+    const int64_t dw = (int64_t)V * K * 4 + 64 + R * 12 + b4c_sort_ids_workspace_bytes(R, V + 1);
     return fwd > dw ? fwd : dw;
 }
 
@@ -970,7 +1001,7 @@ extern "C" int b4c_vocab_lse(const void *h, int ld_h, const void *wt, int ld_w, 
 }
 
 template <int KD>
-static void vce_dw_sweep_launch(VceDwArgs a, int vt0, int nvt, int background_wgs, hipStream_t st) {
+static void vce_dw_sweep_launch(VceDwArgs a, int vt0, int nvt, int background_wgs, bool deterministic, hipStream_t st) {
     const int64_t ntt = ceil_div64(a.R, 128);
     const size_t lds = vce_dw_lds<KD>();
     static thread_local bool done = false;
@@ -987,19 +1018,32 @@ static void vce_dw_sweep_launch(VceDwArgs a, int vt0, int nvt, int background_wg
             const double fill = (double)units / (double)(rounds * background_wgs) - (rounds < 2 ? 0.5 : 0.0);
             if (fill > best + 0.02) { best = fill; ts = t; }
         }
+        if (deterministic) ts = 1;          // one workgroup per vocabulary tile walks every token: plain adds, a fixed order
         a.tsplit = ts;
         const int64_t units = (int64_t)nvt * ts, rounds = ceil_div64(units, background_wgs);
         vce_dw_kernel<KD, 1><<<(unsigned)ceil_div64(units, rounds), 256, lds, st>>>(a);
     } else {
-        a.tsplit = vce_pick_split(nvt, ntt, 0.025);
+        a.tsplit = deterministic ? 1 : vce_pick_split(nvt, ntt, 0.025);
         vce_dw_kernel<KD, 2><<<(unsigned)(nvt * a.tsplit), 512, lds, st>>>(a);
     }
 }
 template <int KD>
-static void vce_dw_label_launch(VceDwArgs a, const int32_t *labels, float *tmp, hipStream_t st) {
+static int vce_dw_label_launch(VceDwArgs a, const int32_t *labels, float *tmp, int64_t tmp_bytes, bool deterministic, hipStream_t st) {
     (void)hipMemsetAsync(tmp, 0, (size_t)a.V * KD * 4, st);
-    vce_label_kernel<KD><<<(unsigned)ceil_div64(a.R, VCE_LABEL_ROWS), 256, 0, st>>>(a, labels, tmp);
+    if (deterministic) {
+        char *p = (char *)tmp + (((size_t)a.V * KD * 4 + 63) & ~(size_t)63);
+        int64_t *keys = (int64_t *)p;          p += (size_t)a.R * 8;
+        int32_t *order = (int32_t *)p;         p += (size_t)a.R * 4;
+        const int64_t sort_bytes = b4c_sort_ids_workspace_bytes(a.R, a.V + 1);
+        B4C_REQUIRE(p + sort_bytes <= (char *)tmp + tmp_bytes, "vocab_ce_dw_labels: workspace too small for the deterministic form");
+        vce_label_keys_kernel<<<(unsigned)ceil_div64(a.R, 256), 256, 0, st>>>(labels, a.R, a.V, keys);
+        if (int rc = b4c_sort_ids(keys, a.R, a.V + 1, order, p, sort_bytes, st)) return rc;
+        vce_label_sorted_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a, keys, order, tmp);
+    } else {
+        vce_label_kernel<KD><<<(unsigned)ceil_div64(a.R, VCE_LABEL_ROWS), 256, 0, st>>>(a, labels, tmp);
+    }
     vce_label_add_kernel<KD><<<dim3((unsigned)((a.V + 31) / 32), KD / 32), 256, 0, st>>>(a.dW, a.ldw, tmp, a.V);
+    return B4C_OK;
 }
 
 static int vce_dw_check(const void *h, int ld_h, const void *wt, int ld_w, const float *rowscal, float *dW, int ldw, int64_t R, int V,
@@ -1021,42 +1065,47 @@ static VceDwArgs vce_dw_args(const void *h, int ld_h, const void *wt, int ld_w, 
 
 extern "C" int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
                                const float *rowscal, float *dW, int ldw, float *db, void *workspace, int64_t workspace_bytes,
-                               int64_t R, int V, int K, void *stream) {
+                               int64_t R, int V, int K, int deterministic, void *stream) {
     if (int rc = vce_dw_check(h, ld_h, wt, ld_w, rowscal, dW, ldw, R, V, K, "vocab_ce_dw")) return rc;
     B4C_REQUIRE(labels && workspace, "vocab_ce_dw: null pointer");
     B4C_REQUIRE(workspace_bytes >= (int64_t)V * K * 4, "vocab_ce_dw: workspace too small");
     if (R == 0) return B4C_OK;
     const VceDwArgs a = vce_dw_args(h, ld_h, wt, ld_w, bias, rowscal, dW, ldw, db, R, V);
     const int nvt = (V + 127) / 128;
-    if (K == 128) { vce_dw_sweep_launch<128>(a, 0, nvt, 0, (hipStream_t)stream); vce_dw_label_launch<128>(a, labels, (float *)workspace, (hipStream_t)stream); }
-    else { vce_dw_sweep_launch<64>(a, 0, nvt, 0, (hipStream_t)stream); vce_dw_label_launch<64>(a, labels, (float *)workspace, (hipStream_t)stream); }
+    const bool det = deterministic != 0;
+    int rc;
+    if (K == 128) { vce_dw_sweep_launch<128>(a, 0, nvt, 0, det, (hipStream_t)stream); rc = vce_dw_label_launch<128>(a, labels, (float *)workspace, workspace_bytes, det, (hipStream_t)stream); }
+    else { vce_dw_sweep_launch<64>(a, 0, nvt, 0, det, (hipStream_t)stream); rc = vce_dw_label_launch<64>(a, labels, (float *)workspace, workspace_bytes, det, (hipStream_t)stream); }
+    if (rc) return rc;
     return b4c_check_launch("vocab_ce_dw");
 }
 
 extern "C" int b4c_vocab_ce_dw_sweep(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const float *rowscal,
                                      float *dW, int ldw, float *db, int64_t R, int V, int K, int tile_begin, int tile_end,
-                                     int background_workgroups, void *stream) {
+                                     int background_workgroups, int deterministic, void *stream) {
     if (int rc = vce_dw_check(h, ld_h, wt, ld_w, rowscal, dW, ldw, R, V, K, "vocab_ce_dw_sweep")) return rc;
     const int nvt = (V + 127) / 128;
     B4C_REQUIRE(tile_begin >= 0 && tile_begin <= tile_end && tile_end <= nvt, "vocab_ce_dw_sweep: tiles [%d, %d) of %d", tile_begin, tile_end, nvt);
     B4C_REQUIRE(background_workgroups >= 0, "vocab_ce_dw_sweep: background_workgroups %d", background_workgroups);
     if (R == 0 || tile_begin == tile_end) return B4C_OK;
     const VceDwArgs a = vce_dw_args(h, ld_h, wt, ld_w, bias, rowscal, dW, ldw, db, R, V);
-    if (K == 128) vce_dw_sweep_launch<128>(a, tile_begin, tile_end - tile_begin, background_workgroups, (hipStream_t)stream);
-    else vce_dw_sweep_launch<64>(a, tile_begin, tile_end - tile_begin, background_workgroups, (hipStream_t)stream);
+    if (K == 128) vce_dw_sweep_launch<128>(a, tile_begin, tile_end - tile_begin, background_workgroups, deterministic != 0, (hipStream_t)stream);
+    else vce_dw_sweep_launch<64>(a, tile_begin, tile_end - tile_begin, background_workgroups, deterministic != 0, (hipStream_t)stream);
     return b4c_check_launch("vocab_ce_dw_sweep");
 }
 
 extern "C" int b4c_vocab_ce_dw_labels(const void *h, int ld_h, const int32_t *labels, const float *rowscal, float *dW, int ldw,
-                                      float *db, void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, void *stream) {
+                                      float *db, void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, int deterministic,
+                                      void *stream) {
     B4C_REQUIRE(h && labels && rowscal && dW && workspace, "vocab_ce_dw_labels: null pointer");
     B4C_REQUIRE(vce_shape_ok(K), "vocab_ce_dw_labels: K=%d unsupported (64 or 128)", K);
     B4C_REQUIRE(R >= 0 && V > 0 && ld_h >= K && ldw >= V, "vocab_ce_dw_labels: shape");
     B4C_REQUIRE(workspace_bytes >= (int64_t)V * K * 4, "vocab_ce_dw_labels: workspace too small");
     if (R == 0) return B4C_OK;
     const VceDwArgs a = vce_dw_args(h, ld_h, nullptr, 0, nullptr, rowscal, dW, ldw, db, R, V);
-    if (K == 128) vce_dw_label_launch<128>(a, labels, (float *)workspace, (hipStream_t)stream);
-    else vce_dw_label_launch<64>(a, labels, (float *)workspace, (hipStream_t)stream);
+    const int rc = K == 128 ? vce_dw_label_launch<128>(a, labels, (float *)workspace, workspace_bytes, deterministic != 0, (hipStream_t)stream)
+                            : vce_dw_label_launch<64>(a, labels, (float *)workspace, workspace_bytes, deterministic != 0, (hipStream_t)stream);
+    if (rc) return rc;
     return b4c_check_launch("vocab_ce_dw_labels");
 }
 

@@ -833,7 +833,8 @@ def vocab_ce_dw(h, wt, bias, labels_i32, rowscal, V, dW, db):
     ws = _vce_workspace(h, R, V, K)
     with _record('vocab_ce_dw', R * K * 2 + V * K * 2 + V * K * 4, 4 * R * V * K):
         L.check(L.lib().b4c_vocab_ce_dw(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(rowscal),
-                                        _p(dW), dW.stride(0), _p(db), ws.data_ptr(), ws.numel(), R, V, K, _st()), 'vocab_ce_dw')
+                                        _p(dW), dW.stride(0), _p(db), ws.data_ptr(), ws.numel(), R, V, K, int(deterministic_vocab_dw), _st()),
+                'vocab_ce_dw')
 
 
 def vocab_ce_dw_sweep(h, wt, bias, rowscal, V, dW, db, tile_begin, tile_end, background_workgroups=0):
@@ -846,7 +847,8 @@ def vocab_ce_dw_sweep(h, wt, bias, rowscal, V, dW, db, tile_begin, tile_end, bac
     with _record('vocab_ce_dw_bg' if background_workgroups > 0 else 'vocab_ce_dw',
                  int(frac * (R * K * 2 + V * K * 2 + V * K * 4)), int(frac * 4 * R * V * K)):
         L.check(L.lib().b4c_vocab_ce_dw_sweep(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(rowscal), _p(dW), dW.stride(0),
-                                              _p(db), R, V, K, tile_begin, tile_end, background_workgroups, _st()), 'vocab_ce_dw_sweep')
+                                              _p(db), R, V, K, tile_begin, tile_end, background_workgroups, int(deterministic_vocab_dw), _st()),
+                'vocab_ce_dw_sweep')
 
 
 def vocab_ce_dw_labels(h, labels_i32, rowscal, V, dW, db):
@@ -856,7 +858,7 @@ def vocab_ce_dw_labels(h, labels_i32, rowscal, V, dW, db):
         return
     ws = _vce_workspace(h, R, V, K)
     L.check(L.lib().b4c_vocab_ce_dw_labels(_p(h), h.stride(0), _p(labels_i32), _p(rowscal), _p(dW), dW.stride(0), _p(db),
-                                           ws.data_ptr(), ws.numel(), R, V, K, _st()), 'vocab_ce_dw_labels')
+                                           ws.data_ptr(), ws.numel(), R, V, K, int(deterministic_vocab_dw), _st()), 'vocab_ce_dw_labels')
 
 
 fused_softmax_proj = True      # Dense(V, softmax) of the bf16 path in one pass over (R x V): lse sweep + softmax epilogue

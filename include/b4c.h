@@ -254,7 +254,11 @@ int b4c_vocab_ce_fwd(const void *h, int ld_h, const void *wt, int ld_w, const fl
                      void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, int variant, void *stream);
 int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const int32_t *labels,
                     const float *rowscal, float *dW, int ldw, float *db, void *workspace, int64_t workspace_bytes,
-                    int64_t R, int V, int K, void *stream);
+                    int64_t R, int V, int K, int deterministic, void *stream);
+/* (ABI version 8) `deterministic` != 0 (b4c_vocab_ce_dw and its pieces): dW / db are summed in a fixed order -- one workgroup
+ * per vocabulary tile walks every token (plain adds instead of float atomics over token splits), and the label term goes
+ * through a stable sort of the rows by label with one wave summing each run: the same bits on every run of the same inputs.
+ * Costs the sweep its token split (fewer workgroups than CUs' worth of rounds); workspace as b4c_vocab_ce_workspace_bytes. */
 /* (ABI version 5) b4c_vocab_ce_dw in pieces, so that the sweep can run BESIDE the HBM-bound encoder backward:
  * b4c_vocab_ce_dw_sweep adds the dlogit part of dW / db for the 128-id vocabulary tiles [tile_begin, tile_end) only
  * (tiles own disjoint columns of dW: any partition of [0, ceil(V / 128)) over any number of calls gives the full sweep);
@@ -264,9 +268,10 @@ int b4c_vocab_ce_dw(const void *h, int ld_h, const void *wt, int ld_w, const flo
  * (dW[:, y] -= yd h_row, db[y] -= yd) once; workspace >= V * K * 4 bytes.  Sweep + labels == b4c_vocab_ce_dw. */
 int b4c_vocab_ce_dw_sweep(const void *h, int ld_h, const void *wt, int ld_w, const float *bias, const float *rowscal,
                           float *dW, int ldw, float *db, int64_t R, int V, int K, int tile_begin, int tile_end,
-                          int background_workgroups, void *stream);
+                          int background_workgroups, int deterministic, void *stream);
 int b4c_vocab_ce_dw_labels(const void *h, int ld_h, const int32_t *labels, const float *rowscal, float *dW, int ldw,
-                           float *db, void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, void *stream);
+                           float *db, void *workspace, int64_t workspace_bytes, int64_t R, int V, int K, int deterministic,
+                           void *stream);
 /* ---- (ABI version 4) R12 for scoring: Dense(V, softmax) (head.py:36) with ONE pass over the (R x V) tensor ------------------
  * replaces the materialised projection + softmax (b4c_gemm_nt + b4c_softmax_rows: write, read, write) of the
  * bf16 path: b4c_vocab_lse recomputes the logits in MFMA accumulators (nothing reaches HBM) and leaves

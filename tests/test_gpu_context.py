@@ -42,7 +42,7 @@ class _PlainAdam:
         assert all(getattr(p, '_b4c_ctx', None) is None for p in self.model.parameters())
         self.opt.step()
         ops.bump_weights_epoch()            # (torch's optimizer writes the masters behind the packed copies' back)
-        return float(loss)
+        return float(loss.detach())
 
 
 class _ArenaAdam:
@@ -56,7 +56,7 @@ class _ArenaAdam:
         loss = self.model.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, n_real_tokens=n_real)
         loss.backward()
         self.opt.step()
-        return float(loss)
+        return float(loss.detach())
 
 
 def _weights(model):
@@ -133,3 +133,31 @@ def test_wrong_n_real_tokens_poisons_the_scoring_paths():
     assert bool(torch.isfinite(good.float()).all()) and int(top_good.min()) >= 0
     assert bool(torch.isnan(bad.float()).all())
     assert bool(torch.isnan(hit_bad).all()) and bool((top_bad == -1).all())
+
+
+def test_deterministic_projection_gradient_over_a_whole_step():
+    """ops.deterministic_vocab_dw with the background sweep on: the vocabulary projection's gradient (kernel and bias slices of
+    the arena) comes out bit-identical from two fresh runs of the same step.  (Its inputs -- the forward pass, the head's dh and
+    row scalars -- are order-fixed; the LayerNorm dgamma / dbeta and the embedding rows still meet through float atomics and are
+    compared to rounding.)"""
+    from bert4clickpath_amd import ops
+    prev = (ops.background_workgroups, ops.deterministic_vocab_dw)
+    ops.background_workgroups, ops.deterministic_vocab_dw = 8, True
+    try:
+        items, labels, n_real = _batch(51)
+        grads = []
+        for _ in range(2):
+            t = _ArenaAdam(_model(0, 3))
+            t.opt.zero_grad()
+            loss = t.model.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, n_real_tokens=n_real)
+            loss.backward()
+            ops.join_side_work(t.opt.arena.ctx)
+            torch.cuda.synchronize()
+            grads.append({n: p.grad.detach().clone() for n, p in t.model.named_parameters()})
+        for n in ('head.output_layer.kernel', 'head.output_layer.bias'):
+            assert torch.equal(grads[0][n], grads[1][n]), n
+            assert float(grads[0][n].abs().max()) > 0
+        for n, g in grads[0].items():
+            assert float((g - grads[1][n]).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-9, n
+    finally:
+        ops.background_workgroups, ops.deterministic_vocab_dw = prev

@@ -165,3 +165,47 @@ def test_vocab_ce_dw_in_pieces_equals_the_whole(ops, R, V, K, scale, bg):
         assert float((db - db0).abs().max()) <= 1e-5 * scale_b + 1e-9, background
     with pytest.raises(L.B4CError):
         ops.vocab_ce_dw_sweep(hd, wt, bd, rowscal, V, dW, db, 0, nt + 1, 0)
+
+
+@pytest.mark.parametrize('R,V,K,bg', [(5000, 2100, 128, 0), (5000, 2100, 128, 16), (700, 333, 64, 3)])
+def test_vocab_ce_dw_deterministic_option(ops, R, V, K, bg):
+    """ops.deterministic_vocab_dw: the projection's dW / db summed in a fixed order (one workgroup per vocabulary tile walks
+    every token; the label term through a stable sort of the rows by label) -- bit-identical from run to run, with hot labels
+    (hundreds of rows per label), foreground and background form, and equal to the atomic form up to the order of the sums."""
+    from bert4clickpath_amd import _lib as L
+    h, W, b, y = _case(R, V, K, 0.9, seed=R + V, n_ignored=7)
+    y[: R // 3] = 3                                   # a hot label: one run of a third of the rows
+    dev = 'cuda'
+    hd = torch.tensor(h, device=dev).bfloat16()
+    Vp = (V + 7) // 8 * 8
+    wt = torch.zeros(Vp, K, device=dev, dtype=torch.bfloat16)
+    wt[:V] = torch.tensor(W, device=dev).bfloat16()
+    bd = torch.zeros(Vp, device=dev)
+    bd[:V] = torch.tensor(b, device=dev)
+    yd = torch.tensor(y, device=dev)
+    gs = torch.tensor([1.0 / R], device=dev)
+    _, _, rowscal = ops.vocab_ce_fwd(hd, wt, bd, yd, gs, V, L.CE_TF)
+    nt = (V + 127) // 128
+
+    def run():
+        dW, db = torch.zeros(K, V, device=dev), torch.zeros(V, device=dev)
+        if bg:
+            cut = nt // 2
+            ops.vocab_ce_dw_sweep(hd, wt, bd, rowscal, V, dW, db, 0, cut, bg)
+            ops.vocab_ce_dw_sweep(hd, wt, bd, rowscal, V, dW, db, cut, nt, bg)
+            ops.vocab_ce_dw_labels(hd, yd, rowscal, V, dW, db)
+        else:
+            ops.vocab_ce_dw(hd, wt, bd, yd, rowscal, V, dW, db)
+        return dW, db
+    prev = ops.deterministic_vocab_dw
+    try:
+        ops.deterministic_vocab_dw = False
+        dW0, db0 = run()
+        ops.deterministic_vocab_dw = True
+        runs = [run() for _ in range(3)]
+    finally:
+        ops.deterministic_vocab_dw = prev
+    for dW, db in runs[1:]:
+        assert torch.equal(dW, runs[0][0]) and torch.equal(db, runs[0][1])
+    assert float((runs[0][0] - dW0).abs().max()) <= 1e-5 * float(dW0.abs().max()) + 1e-9
+    assert float((runs[0][1] - db0).abs().max()) <= 1e-5 * float(db0.abs().max()) + 1e-9
