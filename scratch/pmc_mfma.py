@@ -11,7 +11,7 @@ import json
 import sys
 
 FAM = [('gemm_nt_ln', ('gemm_nt_ln',)), ('vocab_proj', ('gemm_nt_wide',)), ('gemm_nt', ('gemm_nt_kernel',)), ('gemm_tn', ('gemm_tn_', 'tn_reduce')),
-       ('attn_mq_bwd', ('attn_mq_bwd',)), ('attn_mq_fwd', ('attn_mq_fwd',)), ('attn_bwd', ('attn_bwd',)), ('attn_fwd', ('attn_fwd',)), ('vocab_lse', ('vce_token_kernel<128, 0', 'vce_lse_kernel')), ('vocab_ce_fwd', ('vce_token_kernel', 'vce_combine')),
+       ('attn_mq_bwd', ('attn_mq_bwd',)), ('attn_mq_fwd', ('attn_mq_fwd',)), ('attn_bwd', ('attn_bwd',)), ('attn_fwd', ('attn_fwd',)), ('vocab_rank', ('vce_scan_kernel<128, 0,', 'vce_label_logit')), ('vocab_topk', ('vce_scan_kernel', 'vce_tau_kernel', 'vce_select_kernel')), ('vocab_lse', ('vce_token_kernel<128, 0', 'vce_lse_kernel')), ('vocab_ce_fwd', ('vce_token_kernel', 'vce_combine')),
        ('vocab_ce_dw_bg', ('vce_dw_kernel<128, 1>', 'vce_dw_kernel<64, 1>')), ('vocab_ce_dw', ('vce_dw_kernel', 'vce_label')), ('add_ln_bwd', ('add_ln_bwd',)), ('add_ln_fwd', ('add_ln_fwd',)),
        ('embed_fwd', ('embed_fwd',)), ('embed_bwd', ('embed_bwd',)), ('adam', ('adam_kernel',)), ('softmax_rows', ('softmax_rows',)),
        ('topk_rows', ('topk_rows',))]

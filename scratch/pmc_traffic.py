@@ -8,6 +8,8 @@ FAM = [('attn_mq_fwd', ('attn_mq_fwd',), None), ('attn_mq_bwd', ('attn_mq_bwd',)
        ('attn_bwd', ('attn_bwd',), None), ('attn_fwd', ('attn_fwd',), None), ('softmax_ce', ('softmax_ce',), None),
        ('add_ln_fwd', ('add_ln_fwd',), None), ('add_ln_bwd', ('add_ln_bwd',), None), ('embed_bwd', ('embed_bwd',), None),
        ('embed_fwd', ('embed_fwd',), None), ('adam', ('adam_kernel',), None),
+       ('vocab_rank', ('vce_scan_kernel<128, 0,', 'vce_scan_kernel<64, 0,', 'vce_label_logit'), 'vce_label_logit'),
+       ('vocab_topk', ('vce_scan_kernel', 'vce_tau_kernel', 'vce_select_kernel'), 'vce_select_kernel'),
        ('vocab_lse', ('vce_token_kernel<128, 0,', 'vce_token_kernel<64, 0,', 'vce_token_kernelILi128ELi0E', 'vce_lse_kernel'), 'vce_lse_kernel'),
        ('vocab_ce_fwd', ('vce_token_kernel', 'vce_combine_kernel'), 'vce_combine_kernel'),
        # (the background form goes out in pieces: the label kernel marks one launch of the family per step)

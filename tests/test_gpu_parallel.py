@@ -204,7 +204,9 @@ def test_bench_step_at_two_ranks(tmp_path, dropout):
                 lo, hi = tr.opt.arena.slice_of(p)
                 diff[lo:hi] = 0
         # the two shards' gradients meet in another order (all-reduce of two arenas / two passes into one arena; float atomics
-        # in the background sweep): last-bit differences, which three Adam steps carry into the weights
-        assert float(diff.max()) < 2e-4 and float(np.linalg.norm(ref - w0)) < 1e-4 * float(np.linalg.norm(ref)), float(diff.max())
+        # in the background sweep): last-bit differences.  Adam (epsilon 1e-9) turns the sign of a noise-sized gradient into
+        # a full +-lr step, so single elements may differ by up to steps x lr = 3e-3; the bulk may not
+        assert float(diff.max()) < 3.5e-3, float(diff.max())
+        assert float(np.linalg.norm(diff)) < 3e-4 * float(np.linalg.norm(ref)), float(np.linalg.norm(diff)) / float(np.linalg.norm(ref))
     finally:
         ops.background_workgroups = prev
