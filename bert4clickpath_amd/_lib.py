@@ -74,8 +74,6 @@ def lib():
             'b4c_pack_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, vp]),
             'b4c_gemm_nt': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
             'b4c_gemm_nt_add_ln': (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, vp]),
-            'b4c_gemm_nt_ln_bwd_workspace_bytes': (i64, [i32]),
-            'b4c_gemm_nt_ln_bwd': (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, u64, i32, vp]),
             'b4c_gemm_tn_group_workspace_bytes': (i64, [vp, i32, i32]),
             'b4c_gemm_tn_group': (i32, [vp, i32, i32, i32, vp, i64, vp]),
             'b4c_gemm_tn_workspace_bytes': (i64, [i32, i32, i32, i32]),

@@ -280,15 +280,6 @@ class Encoder(nn.Module):
         if training and self.dropout_rate > 0 and not _input_dropout_done:
             x = ops.DropoutFn.apply(x, float(self.dropout_rate), dropout_seeds.next())
         B, S, d = x.shape
-        layers = [{'mha': l.mha, 'ffn': l.ffn, 'ln1': l.layernorm1, 'ln2': l.layernorm2} for l in self.enc_layers]
-        if rows is None and packed is None and mask is not None and mask.dtype == torch.uint8 and mask.dim() == 2 and \
-                ops.encoder_stack_supported(x, layers, bool(training), self.dropout_rate):
-            # one autograd node for the whole stack: LayerNorm backward runs in GEMM epilogues (ops.EncoderStackFn)
-            for lay in layers:
-                lay['s1'], lay['s2'] = dropout_seeds.next(), dropout_seeds.next()
-            out = ops.EncoderStackFn.apply(x.reshape(B * S, d), mask, layers, B, S, self.enc_layers[0].num_heads,
-                                           float(self.dropout_rate))
-            return out.view(B, S, d)
         last = len(self.enc_layers) - 1
         for i, layer in enumerate(self.enc_layers):
             x = layer(x, training, mask, packed, rows if i == last else None)

@@ -624,205 +624,6 @@ extern "C" int b4c_gemm_nt_add_ln(const void *A, int lda, const void *Bt, int ld
     return b4c_check_launch("gemm_nt_add_ln");
 }
 
-// ------------------------------------------------------------------------------------------
-// NT + residual + LayerNorm BACKWARD (bf16, N <= 128): the GEMM that produces the gradient of an encoder block's
-// input (dh W1^T + dz2, dqkv Wqkv^T + dz1: 128 columns = whole rows) also runs the backward of the LayerNorm that
-// sits in front of that input (transformer.py:204-213, previous block): its result `dout` never goes to HBM (2 of
-// the 6 [T][d] passes of the pair).
-//   dout = bf16(A Bt^T + r)                                  (what gemm_nt + residual would have stored)
-//   g = dout gamma;  xh = (z - mean) rstd;  dz = rstd (g - mean(g) - xh mean(g xh));  dy = dropout-mask(dz) / keep
-//   dgamma += sum_rows dout xh,  dbeta += sum_rows dout      (per-workgroup partial sums -> lnbwd_reduce_kernel)
-// Lane layout and summation order of add_ln_bwd_kernel<bf16, 16>: dz and dy are bit-identical to the two kernels.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gemm_nt_lnbwd_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ Bt, int ldb,
-                                                            const bf16_t *__restrict__ res, int ldr, const bf16_t *__restrict__ z,
-                                                            const float *__restrict__ stats, const float *__restrict__ gamma,
-                                                            bf16_t *__restrict__ dz, bf16_t *__restrict__ dy, float *__restrict__ partial,
-                                                            int M, int N, int K, float rate, uint64_t seed) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * TILE;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
-    const int nk = (K + MM<bf16_t>::BKE - 1) / MM<bf16_t>::BKE;
-    u32x4 xa[4], xb[4];
-    nt_load<bf16_t>(A, lda, m0, M, 0, K, tid, xa);
-    nt_load<bf16_t>(Bt, ldb, 0, N, 0, K, tid, xb);
-    const int part = tid & 15, col = part * 8;
-    float gm[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) gm[k] = 0.f;
-    if (col < N) Vec8<float>::load(gamma + col, gm);
-    // mean / rstd of the lane's eight rows: requested now, used in the epilogue (loaded inside the epilogue loop under
-    // `if (on)` they were waited for on the spot: eight exposed round trips per workgroup)
-    float sma[4], sra[4], smb[4], srb[4];   // rows (tid >> 4) + 16 q: q = 0..3 and 4..7 (rotated like xa / xb)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {            // unconditional, on clamped rows
-        const int64_t ra = m0 + (tid >> 4) + 16 * q, rb = ra + 64;
-        const float *pa = stats + (ra < M ? ra : M - 1) * 2, *pb = stats + (rb < M ? rb : M - 1) * 2;
-        sma[q] = pa[0]; sra[q] = pa[1];
-        smb[q] = pb[0]; srb[q] = pb[1];
-    }
-    nt_store(smem, tid, xa);
-    nt_store(smem + TILE_BYTES, tid, xb);
-    __syncthreads();
-    const __amdgpu_buffer_rsrc_t rrs = tile_rsrc(res + (int64_t)m0 * ldr, (int64_t)M - m0, TILE, (int64_t)ldr * 2);
-    const __amdgpu_buffer_rsrc_t zrs = tile_rsrc(z + (int64_t)m0 * N, (int64_t)M - m0, TILE, (int64_t)N * 2);
-    u32x4 za[4], zb[4];
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) {
-            nt_load<bf16_t>(A, lda, m0, M, (kt + 1) * MM<bf16_t>::BKE, K, tid, xa);
-            nt_load<bf16_t>(Bt, ldb, 0, N, (kt + 1) * MM<bf16_t>::BKE, K, tid, xb);
-        } else {
-            // residual and z chunks 0..3 ride under the last tile's MFMAs
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = (tid >> 4) + 16 * i;
-                xa[i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ((row * ldr + col) * 2) | oob_if(col >= N), 0, 0);
-                za[i] = __builtin_amdgcn_raw_buffer_load_b128(zrs, ((row * N + col) * 2) | oob_if(col >= N), 0, 0);
-            }
-        }
-        mma_stage<bf16_t>(smem + TILE_BYTES, smem, wn, wm, r, h, acc);
-        __syncthreads();
-        if (more) {
-            nt_store(smem, tid, xa);
-            nt_store(smem + TILE_BYTES, tid, xb);
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int tq = 0; tq < 4; ++tq) {
-                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-                bf16x4_t w;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) w[k] = (bf16_t)acc[j][i][4 * tq + k];
-                *reinterpret_cast<bf16x4_t *>(smem + (wm * 64 + i * 32 + r) * LN_OUT_STRIDE + (wn * 64 + j * 32 + 8 * tq + 4 * h) * 2) = w;
-            }
-    float *red = reinterpret_cast<float *>(smem + TILE * LN_OUT_STRIDE);     // [2][128] behind the staged tile
-    red[tid] = 0.f;
-    __syncthreads();
-    const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
-    const float inv_d = 1.0f / (float)N;
-    const uint32_t thr = b4c_keep_threshold(rate);
-    float pg[8], pb[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) pg[k] = pb[k] = 0.f;
-#pragma unroll 1
-    for (int hq = 0; hq < 2; ++hq) {
-      if (hq == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (tid >> 4) + 16 * (4 + i);
-            xb[i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ((row * ldr + col) * 2) | oob_if(col >= N), 0, 0);
-            zb[i] = __builtin_amdgcn_raw_buffer_load_b128(zrs, ((row * N + col) * 2) | oob_if(col >= N), 0, 0);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = hq * 4 + i;
-        const int row = (tid >> 4) + 16 * q;
-        const int64_t grow = m0 + row;
-        const bool on = grow < M && col < N;     // rows are uniform over their 16 lanes
-        float gv[8], xh[8];
-        float s1 = 0.f, s2 = 0.f, mean = 0.f, rstd = 0.f;
-        if (on) {
-            mean = sma[i];
-            rstd = sra[i];
-            const u32x2 lo = *reinterpret_cast<const u32x2 *>(smem + row * LN_OUT_STRIDE + part * 16);
-            const u32x2 hi = *reinterpret_cast<const u32x2 *>(smem + row * LN_OUT_STRIDE + part * 16 + 8);
-            const u32x4 w4 = {lo[0], lo[1], hi[0], hi[1]};
-            const bf16x8 cv = __builtin_bit_cast(bf16x8, w4);
-            const bf16x8 rv = __builtin_bit_cast(bf16x8, xa[i]);
-            const bf16x8 zv = __builtin_bit_cast(bf16x8, za[i]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float go = (float)(bf16_t)((float)cv[k] + (float)rv[k]);     // the bf16 dout gemm_nt would have stored
-                xh[k] = ((float)zv[k] - mean) * rstd;
-                gv[k] = go * gm[k];
-                s1 += gv[k];
-                s2 += gv[k] * xh[k];
-                pg[k] += go * xh[k];
-                pb[k] += go;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) gv[k] = xh[k] = 0.f;
-        }
-        s1 = group_sum<16>(s1) * inv_d;
-        s2 = group_sum<16>(s2) * inv_d;
-        if (on) {
-            float o[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = rstd * (gv[k] - s1 - xh[k] * s2);
-            Vec8<bf16_t>::store(dz + grow * N + col, o);
-            if (rate > 0.f && dy) {
-                const uint32_t km = b4c_keep8(seed, (uint64_t)(grow * N + col), thr);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = ((km >> k) & 1u) ? o[k] * inv_keep : 0.f;
-                Vec8<bf16_t>::store(dy + grow * N + col, o);
-            }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { xa[i] = xb[i]; za[i] = zb[i]; sma[i] = smb[i]; sra[i] = srb[i]; }
-    }
-    // column sums of the workgroup's rows: 16 row groups -> LDS -> one 1-KB partial row (no global atomics: 6,400
-    // workgroups adding to the same 256 addresses would serialise at ~100 ns per add)
-    if (col < N) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            atomicAdd(&red[col + k], pg[k]);
-            atomicAdd(&red[128 + col + k], pb[k]);
-        }
-    }
-    __syncthreads();
-    partial[(int64_t)blockIdx.x * 256 + tid] = red[tid];
-}
-
-// dgamma[c] += sum_w partial[w][c], dbeta[c] += sum_w partial[w][128 + c]
-__global__ void __launch_bounds__(256) lnbwd_reduce_kernel(const float *__restrict__ partial, int n_wg, float *__restrict__ dgamma,
-                                                           float *__restrict__ dbeta, int N) {
-    const int tid = threadIdx.x;
-    float s = 0.f;
-#pragma unroll 8
-    for (int w = blockIdx.x; w < n_wg; w += gridDim.x) s += partial[(int64_t)w * 256 + tid];
-    const int c = tid & 127;
-    if (c < N) atomicAdd((tid < 128 ? dgamma : dbeta) + c, s);
-}
-
-extern "C" int64_t b4c_gemm_nt_ln_bwd_workspace_bytes(int M) { return M > 0 ? ceil_div64(M, TILE) * 256 * 4 : 0; }
-
-extern "C" int b4c_gemm_nt_ln_bwd(const void *A, int lda, const void *Bt, int ldb, const void *residual, int ldr, const void *z,
-                                  const float *stats, const float *gamma, void *dz, void *dy, float *dgamma, float *dbeta,
-                                  void *workspace, int64_t workspace_bytes, int M, int N, int K, float dropout_rate, uint64_t seed,
-                                  int dtype, void *stream) {
-    B4C_REQUIRE(A && Bt && residual && z && stats && gamma && dz && dgamma && dbeta && workspace, "gemm_nt_ln_bwd: null pointer");
-    B4C_REQUIRE(dtype == B4C_BF16, "gemm_nt_ln_bwd: bf16 only (dtype %d)", dtype);
-    B4C_REQUIRE(M > 0 && N > 0 && N <= TILE && N % 8 == 0 && K > 0 && K % 8 == 0, "gemm_nt_ln_bwd: M=%d N=%d K=%d (N <= 128, N, K %% 8 == 0)", M, N, K);
-    B4C_REQUIRE(lda >= K && ldb >= K && ldr >= N && lda % 8 == 0 && ldb % 8 == 0 && ldr % 8 == 0, "gemm_nt_ln_bwd: pitches");
-    B4C_REQUIRE(((((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)residual | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dy | (uintptr_t)gamma) & 15) == 0),
-                "gemm_nt_ln_bwd: operands must be 16-byte aligned");
-    B4C_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f && (dropout_rate == 0.f || dy), "gemm_nt_ln_bwd: dropout_rate %f needs dy", (double)dropout_rate);
-    B4C_REQUIRE(workspace_bytes >= b4c_gemm_nt_ln_bwd_workspace_bytes(M), "gemm_nt_ln_bwd: workspace too small");
-    const int grid = (M + TILE - 1) / TILE;
-    hipStream_t st = (hipStream_t)stream;
-    gemm_nt_lnbwd_kernel<<<grid, 256, STAGE_BYTES, st>>>((const bf16_t *)A, lda, (const bf16_t *)Bt, ldb, (const bf16_t *)residual, ldr,
-                                                         (const bf16_t *)z, stats, gamma, (bf16_t *)dz, (bf16_t *)dy,
-                                                         (float *)workspace, M, N, K, dropout_rate, seed);
-    lnbwd_reduce_kernel<<<grid < 64 ? grid : 64, 256, 0, st>>>((const float *)workspace, grid, dgamma, dbeta, N);
-    return b4c_check_launch("gemm_nt_ln_bwd");
-}
 
 // Wide-N, small-K form (the vocabulary projection: [R][128] x [V][128]^T -> [R][V]).  The generic kernel
 // above spends most of its time outside stores and MFMAs there (with both removed it still runs at half its

@@ -634,29 +634,6 @@ def gemm_nt_add_ln(a, bt, bias, x, gamma, beta, rate, seed, save=True):
     return z, out, stats
 
 
-_lnbwd_ws = {}
-
-
-def gemm_nt_ln_bwd(a, bt, residual, z, stats, gamma, rate, seed, dgamma, dbeta):
-    """(dz, dy) = LayerNorm-backward(a @ bt^T + residual) with dgamma / dbeta accumulated in place:
-    == gemm_nt(residual=) + add_dropout_layernorm_bwd (dz, dy bit for bit), without the intermediate in HBM."""
-    M, K = a.shape
-    n = z.shape[1]
-    dz = torch.empty_like(z)
-    dy = torch.empty_like(z) if rate > 0 else None
-    need = L.lib().b4c_gemm_nt_ln_bwd_workspace_bytes(M)
-    ws = _lnbwd_ws.get(a.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=a.device)
-        _lnbwd_ws[a.device] = ws
-    es = a.element_size()
-    with _record('gemm_nt_ln_bwd', M * K * es + n * K * es + M * n * es * (4 if rate > 0 else 3), 2 * M * n * K):
-        L.check(L.lib().b4c_gemm_nt_ln_bwd(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(residual), residual.stride(0), _p(z),
-                                           _p(stats), _p(gamma), _p(dz), _p(dy), _p(dgamma), _p(dbeta), ws.data_ptr(),
-                                           ws.numel(), M, n, K, rate, seed, dt_code(a.dtype), _st()), 'gemm_nt_ln_bwd')
-    return dz, dy
-
-
 def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed, into=None):
     rows, d = z.shape
     dz = torch.empty_like(z)
@@ -1398,112 +1375,6 @@ class FFNBlockFn(torch.autograd.Function):
             _ready(gam, bet)
             return (dx,) + (None,) * 11
         return (dx, dW1, db1, dW2, db2, dgamma, dbeta) + (None,) * 5
-
-
-# One autograd node for the whole encoder stack with LayerNorm backward in GEMM epilogues.  Correct (bit-identical
-# dz / dy, tests/test_gpu_model.py) but measured SLOWER at C2 (401 us per fused launch against 304 us for the two
-# kernels: 220 registers, two workgroups per CU, and the epilogue's loads sit on the critical path), so it is off.
-fused_ln_bwd = False
-
-
-class EncoderStackFn(torch.autograd.Function):
-    """All encoder layers as ONE autograd node (bf16, d_model <= 128, gradients accumulated in place in the
-    optimizer's arena).  Forward = the kernels of AttnBlockFn + FFNBlockFn, layer after layer.  Backward fuses every
-    LayerNorm backward whose incoming gradient is produced by a GEMM into that GEMM (b4c_gemm_nt_ln_bwd):
-        LN1 of layer l      <-  dh . W1^T + dz2          (FFN1 dX of the same layer)
-        LN2 of layer l - 1  <-  dqkv . Wqkv^T + dz1      (QKV dX of layer l)
-    Only LN2 of the last layer (its gradient comes from the head) runs as a kernel of its own.
-    apply(x, key_pad, layers, B, S, H, rate): layers = [{'mha', 'ffn', 'ln1', 'ln2', 's1', 's2'}, ...] (modules, seeds)."""
-
-    @staticmethod
-    def forward(ctx, x, key_pad, layers, B, S, H, rate):
-        T_tok, d = x.shape
-        dh = d // H
-        saved = []
-        for lay in layers:
-            m, f, ln1, ln2 = lay['mha'], lay['ffn'], lay['ln1'], lay['ln2']
-            wt_qkv, _, b_qkv = m._pk_qkv.get(x.dtype, d, True)
-            wt_o, _, b_o = m._pk_o.get(x.dtype, d, True)
-            qkv = gemm_nt(x, wt_qkv, 3 * d, b_qkv)
-            o, lse = attn_fwd(qkv, key_pad, B, S, H, dh)
-            z1, out1, st1 = gemm_nt_add_ln(o, wt_o, b_o, x, ln1.gamma.detach(), ln1.beta.detach(), rate, lay['s1'])
-            wt1, _, bb1 = f._pk1.get(x.dtype, d, True)
-            Fp = f._pk1.Np
-            wt2, _, bb2 = f._pk2.get(x.dtype, Fp, True)
-            h = gemm_nt(out1, wt1, Fp, bb1, act=L.ACT_RELU)
-            z2, out2, st2 = gemm_nt_add_ln(h, wt2, bb2, out1, ln2.gamma.detach(), ln2.beta.detach(), rate, lay['s2'])
-            saved += [x, qkv, o, lse, z1, st1, out1, h, z2, st2]
-            x = out2
-        ctx.save_for_backward(key_pad, *saved)
-        ctx.layers, ctx.dims = layers, (B, S, H, dh, rate)
-        return x
-
-    @staticmethod
-    def backward(ctx, dout):
-        key_pad, *saved = ctx.saved_tensors
-        layers = ctx.layers
-        B, S, H, dh, rate = ctx.dims
-        d = H * dh
-        dz2 = dy2 = None
-        dx = None
-        for l in range(len(layers) - 1, -1, -1):
-            lay = layers[l]
-            m, f, ln1, ln2 = lay['mha'], lay['ffn'], lay['ln1'], lay['ln2']
-            x, qkv, o, lse, z1, st1, out1, h, z2, st2 = saved[10 * l:10 * l + 10]
-            dt = x.dtype
-            if dz2 is None:        # the last layer: dout comes from the head through autograd
-                dz2, dy2, _, _ = add_dropout_layernorm_bwd(dout.contiguous(), z2, st2, ln2.gamma.detach(), rate, lay['s2'],
-                                                           into=(ln2.gamma.grad, ln2.beta.grad))
-                _ready(ln2.gamma, ln2.beta)
-            Fp = h.shape[1]
-            _, wc1, _ = f._pk1.get(dt, d, True)
-            _, wc2, _ = f._pk2.get(dt, Fp, True)
-            w1, b1, w2, b2 = f[0].kernel, f[0].bias, f[1].kernel, f[1].bias
-            gemm_tn(h, dy2, f._pk2.K, d, into=([w2.grad], [b2.grad]))
-            dhid = gemm_nt(dy2, wc2, Fp, gate=h)
-            gemm_tn(out1, dhid, d, f._pk1.N, into=([w1.grad], [b1.grad]))
-            _ready(w1, b1, w2, b2)
-            # FFN1 dX + dz2, fused with the backward of LN1
-            dz1, dy1 = gemm_nt_ln_bwd(dhid, wc1, dz2, z1, st1, ln1.gamma.detach(), rate, lay['s1'], ln1.gamma.grad, ln1.beta.grad)
-            if dy1 is None:
-                dy1 = dz1
-            _ready(ln1.gamma, ln1.beta)
-            _, wc_o, _ = m._pk_o.get(dt, d, True)
-            _, wc_qkv, _ = m._pk_qkv.get(dt, d, True)
-            wo, bo = m.dense.kernel, m.dense.bias
-            gemm_tn(o, dy1, d, d, into=([wo.grad], [bo.grad]))
-            d_o = gemm_nt(dy1, wc_o, d)
-            dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh)
-            gemm_tn(x, dqkv, d, 3 * d, into=([m.wq.kernel.grad, m.wk.kernel.grad, m.wv.kernel.grad],
-                                             [m.wq.bias.grad, m.wk.bias.grad, m.wv.bias.grad]))
-            _ready(wo, bo, m.wq.kernel, m.wq.bias, m.wk.kernel, m.wk.bias, m.wv.kernel, m.wv.bias)
-            if l > 0:              # QKV dX + dz1, fused with the backward of the previous layer's LN2
-                prev = layers[l - 1]
-                z2p, st2p = saved[10 * (l - 1) + 8], saved[10 * (l - 1) + 9]
-                g2, b2p = prev['ln2'].gamma, prev['ln2'].beta
-                dz2, dy2 = gemm_nt_ln_bwd(dqkv, wc_qkv, dz1, z2p, st2p, g2.detach(), rate, prev['s2'], g2.grad, b2p.grad)
-                if dy2 is None:
-                    dy2 = dz2
-                _ready(g2, b2p)
-            else:
-                dx = gemm_nt(dqkv, wc_qkv, d, residual=dz1)
-        return dx, None, None, None, None, None, None
-
-
-def encoder_stack_supported(x, layers, training, rate):
-    """EncoderStackFn's preconditions: bf16 training with in-place (arena) gradients, d_model <= 128."""
-    if not (fused_ln_bwd and fused_ln and training and torch.is_grad_enabled() and x.dtype == torch.bfloat16):
-        return False
-    d = x.shape[-1]
-    if d > 128 or d % 8:
-        return False
-    for lay in layers:
-        m, f = lay['mha'], lay['ffn']
-        ps = [m.wq.kernel, m.wq.bias, m.wk.kernel, m.wk.bias, m.wv.kernel, m.wv.bias, m.dense.kernel, m.dense.bias,
-              f[0].kernel, f[0].bias, f[1].kernel, f[1].bias, lay['ln1'].gamma, lay['ln1'].beta, lay['ln2'].gamma, lay['ln2'].beta]
-        if not _inplace_ok(*ps):
-            return False
-    return True
 
 
 class MLPFn(torch.autograd.Function):

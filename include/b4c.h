@@ -121,18 +121,6 @@ int b4c_gemm_nt_add_ln(const void *A, int lda, const void *Bt, int ldb, const fl
                        const float *gamma, const float *beta, void *z, void *out, float *stats, int M, int N, int K,
                        float eps, float dropout_rate, uint64_t seed, int dtype, void *stream);
 
-/* backward counterpart (bf16, N <= 128): the GEMM whose result is the gradient of an encoder block's input also
- * runs the backward of the LayerNorm in front of that input:
- *   dout = A . Bt^T + residual;   (dz, dy, dgamma +=, dbeta +=) = add_dropout_layernorm_bwd(dout, z, stats, gamma)
- * == b4c_gemm_nt(residual) followed by b4c_add_dropout_layernorm_bwd (dz / dy bit for bit), without dout in HBM.
- * dy may be NULL when dropout_rate == 0.  workspace >= b4c_gemm_nt_ln_bwd_workspace_bytes(M) (per-workgroup
- * column sums, reduced by a second small kernel instead of contended atomics). */
-int64_t b4c_gemm_nt_ln_bwd_workspace_bytes(int M);
-int b4c_gemm_nt_ln_bwd(const void *A, int lda, const void *Bt, int ldb, const void *residual, int ldr, const void *z,
-                       const float *stats, const float *gamma, void *dz, void *dy, float *dgamma, float *dbeta,
-                       void *workspace, int64_t workspace_bytes, int M, int N, int K, float dropout_rate, uint64_t seed,
-                       int dtype, void *stream);
-
 /* dW[K][N] += A[M][K]^T . G[M][N]   and  db[N] += colsum(G)   (fp32 outputs ADDED to what is there: the
  * caller zeroes or accumulates; db may be NULL).  The reduction over the M (token) axis is split over
  * workgroups when the output has few 128x128 tiles; the partial tiles are then summed

@@ -25,7 +25,7 @@ s = buf.reshape(2048, 8, 6).astype(np.float64)
 s = s[s.sum((1, 2)) > 0]
 names = ['issue next tile DMA', 'logits chain (16 MFMA)', 'max / min / raise', 'exp + cvt + 16 P.W MFMA + l', 'bias store, vmcnt(0), barrier', 'stamp / loop overhead']
 tot = s.sum(2).mean()
-ntile = 391 / 4.0
+ntile = 391 / float(os.environ.get("PARTS", "3"))
 print('MODE %d: workgroups %d; cycles per wave %.0f = %.0f per tile' % (mode, len(s), tot, tot / ntile))
 for k, n in enumerate(names):
     print('  %-32s %8.0f per tile  %5.1f %%' % (n, s[:, :, k].mean() / ntile, 100 * s[:, :, k].mean() / tot))

@@ -249,50 +249,3 @@ def test_segment_to_head_and_empty_masks(gpu):
     assert out2.shape == (2, 0, V)
     loss = model2.cloze_loss({'asin': items}, torch.full((2, 0), -1.0), training=False)
     assert float(loss) == 0.0
-
-
-def test_encoder_stack_node_matches_per_block_nodes():
-    """ops.EncoderStackFn (one autograd node, LayerNorm backward inside GEMM epilogues) against the per-block nodes:
-    same kernels forward, bit-identical dz / dy backward -> same loss, gradients equal up to fp32 summation order."""
-    from bert4clickpath_amd import ops, optim, input_pipeline
-    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
-    from bert4clickpath_amd.clickstream_transformer import transformer as tr
-    dev = 'cuda'
-    V, B, S = 300, 24, 40
-    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=7)
-    ids = torch.from_numpy(b['ids'])[:, 2:S - 1].contiguous().to(dev)
-    lab, fi = torch.from_numpy(b['labels']).to(dev), torch.from_numpy(b['flat_idx']).to(dev)
-
-    def run(stack):
-        torch.manual_seed(5)
-        head = SoftMaxHead([64], V, input_dim=64)
-        m = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': 64}, head,
-                                   value_to_head='[MASK]', num_encoder_layers=3, num_attention_heads=2, dropout_rate=0.1,
-                                   compute_dtype=torch.bfloat16).to(dev)
-        opt = optim.Adam(m.parameters())
-        tr.set_dropout_seed(31)
-        ops.fused_ln_bwd = stack
-        try:
-            opt.zero_grad()
-            loss = m.cloze_loss({'asin': ids}, lab, training=True, flat_idx=fi)
-            loss.backward()
-        finally:
-            ops.fused_ln_bwd = False
-        names = [n for n, _ in m.named_parameters()]
-        return float(loss.detach()), {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()}, names
-
-    calls = []
-    orig = ops.gemm_nt_ln_bwd
-    ops.gemm_nt_ln_bwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-    try:
-        l1, g1, names = run(True)
-        assert len(calls) == 2 * 3 - 1          # every LayerNorm backward but the last layer's LN2
-        l0, g0, _ = run(False)
-        assert len(calls) == 5
-    finally:
-        ops.gemm_nt_ln_bwd = orig
-    assert l1 == l0
-    for n in names:
-        ref = g0[n]
-        scale = max(float(ref.abs().max()), 1e-12)
-        assert float((g1[n] - ref).abs().max()) <= 2e-4 * scale + 1e-9, n
