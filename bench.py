@@ -72,6 +72,8 @@ def parse():
                     '(8,192 shared log-uniform negatives; no reference counterpart)')
     ap.add_argument('--action_dim', type=int, default=0, help='second feature (actions) embedding dim, part of d_model; 0 = single feature')
     ap.add_argument('--action_vocab', type=int, default=1000)
+    ap.add_argument('--feature_sum', action='store_true', help='config 4 as BASELINE.json words it ("dual embedding gather + sum"): items and '
+                    'actions are both d_model wide and their rows are ADDED (feature_combine=\'sum\', an extension: the reference concatenates)')
     ap.add_argument('--traffic_json', default=None, help='optional JSON with PMC-derived HBM bytes per launch')
     a = ap.parse_args()
     if a.config == 'c4':
@@ -93,9 +95,11 @@ def build_model(a, device):
     chains, vocabs, dims = {'items': ['asin']}, {'items': vocab}, {'items': a.d_model - a.action_dim}
     if a.action_dim > 0:      # second feature, concatenated on the last axis (reference transformer.py:384-388)
         chains['actions'], vocabs['actions'], dims['actions'] = ['act'], ['a%d' % i for i in range(a.action_vocab)], a.action_dim
+    if a.feature_sum:         # ... or added to the first one: both d_model wide
+        dims = {f: a.d_model for f in dims}
     model = ClickstreamTransformer(chains, vocabs, dims, head,
                                    value_to_head='[MASK]', num_encoder_layers=a.layers, num_attention_heads=a.heads,
-                                   dropout_rate=a.dropout,
+                                   dropout_rate=a.dropout, feature_combine='sum' if a.feature_sum else 'concat',
                                    compute_dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
     return model.to(device)
 
@@ -452,7 +456,9 @@ def main():
                                       ' (sampled softmax, %d shared log-uniform negatives)' % a.sampled if a.sampled else '',
                                       a.batch, world, a.dropout, len(batches),
                                       'precomputed on the host' if a.host_flat_idx else 'generated on the device inside the step',
-                                      '; two concatenated features items(%d)+actions(%d, vocab %d)' % (a.d_model - a.action_dim, a.action_dim, a.action_vocab)
+                                      ('; two SUMMED features items(%d)+actions(%d, vocab %d) (feature_combine=sum: an extension, the reference concatenates)'
+                                       % (a.d_model, a.d_model, a.action_vocab) if a.feature_sum else
+                                       '; two concatenated features items(%d)+actions(%d, vocab %d)' % (a.d_model - a.action_dim, a.action_dim, a.action_vocab))
                                       if a.action_dim > 0 else '',
                                       'the padded (B, S) layout' if a.dense else
                                       'the padding-free layout (%.0f %% of the B x S positions are real tokens)%s'

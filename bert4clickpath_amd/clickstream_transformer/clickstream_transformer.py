@@ -89,8 +89,9 @@ class TransformerInputPrep:
 class ClickstreamTransformer(nn.Module):
     def __init__(self, sequential_input_config, feature_vocabs, embedding_dims, head_unit, segment_to_head=None,
                  value_to_head=None, num_encoder_layers=1, num_attention_heads=1, dropout_rate=0.1,
-                 compute_dtype=torch.float32, **kwargs):
+                 compute_dtype=torch.float32, feature_combine='concat', **kwargs):
         super().__init__()
+        self.feature_combine = feature_combine      # 'sum': the features' embedding rows are added (extension, transformer.Transformer)
         self.sequential_input_config = sequential_input_config
         self.feature_vocabs = feature_vocabs
         self.embedding_dims = embedding_dims
@@ -109,7 +110,7 @@ class ClickstreamTransformer(nn.Module):
             embedding_sizes={f: self.embedding_sizes[f] for f in self.embedding_dims.keys()},
             embedding_dims=self.embedding_dims, num_layers=num_encoder_layers,
             num_attention_heads=num_attention_heads, encoder_ff_dim=100,   # hard-coded in the reference (:225)
-            dropout_rate=dropout_rate, compute_dtype=compute_dtype)
+            dropout_rate=dropout_rate, compute_dtype=compute_dtype, feature_combine=feature_combine)
         if hasattr(self.head, 'tie') and getattr(self.head, '_table', None) is None:
             # tied-weight head: project back onto the FIRST embedded feature's table (the items)
             first = list(self.embedding_dims.keys())[0]
@@ -129,7 +130,8 @@ class ClickstreamTransformer(nn.Module):
         return {'sequential_input_config': self.sequential_input_config, 'feature_vocabs': self.feature_vocabs,
                 'embedding_dims': self.embedding_dims, 'head_unit': self.head, 'segment_to_head': self.segment_to_head,
                 'value_to_head': self.value_to_head, 'num_encoder_layers': self.num_encoder_layers,
-                'num_attention_heads': self.num_attention_heads, 'dropout_rate': self.dropout_rate}
+                'num_attention_heads': self.num_attention_heads, 'dropout_rate': self.dropout_rate,
+                **({'feature_combine': 'sum'} if self.feature_combine == 'sum' else {})}
 
     @staticmethod
     def _create_lookup_tables(vocabularies, tokens_to_prepend=None):

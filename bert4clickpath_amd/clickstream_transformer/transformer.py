@@ -318,10 +318,11 @@ class _FeatureModules(nn.Module):
 
 class Transformer(nn.Module):
     """Encoder-only Transformer over one or more categorical sequence features (reference :271-402):
-    per-feature embedding -> concat on the last axis -> * sqrt(d_model) -> + sinusoidal PE -> Encoder."""
+    per-feature embedding -> concat on the last axis (or, feature_combine='sum', added) -> * sqrt(d_model) -> + sinusoidal
+    PE -> Encoder."""
 
     def __init__(self, num_layers, num_attention_heads, embedding_sizes, embedding_dims, encoder_ff_dim, dropout_rate,
-                 item_embedding_weights=None, compute_dtype=torch.float32, **kwargs):
+                 item_embedding_weights=None, compute_dtype=torch.float32, feature_combine='concat', **kwargs):
         super().__init__()
         assert set(embedding_sizes.keys()) == set(embedding_dims.keys()), \
             "embedding_sizes and embedding_dims must have the same set of keys."
@@ -330,7 +331,18 @@ class Transformer(nn.Module):
         self.encoder_ff_dim, self.dropout_rate = encoder_ff_dim, dropout_rate
         self.item_embedding_weights = item_embedding_weights
         self.maximum_position_encoding = 10000
-        self.d_model = sum(embedding_dims.values())
+        # feature_combine='sum' (no reference counterpart; the reference concatenates, :384-388): two or more features of ONE
+        # width whose embedding rows are added -- d_model is that width
+        if feature_combine not in ('concat', 'sum'):
+            raise ValueError("feature_combine must be 'concat' or 'sum', got %r" % (feature_combine,))
+        self.feature_combine = feature_combine
+        if feature_combine == 'sum':
+            widths = set(int(v) for v in embedding_dims.values())
+            if len(embedding_dims) < 2 or len(widths) != 1:
+                raise ValueError("feature_combine='sum' needs two or more features with one embedding dim, got %r" % (dict(embedding_dims),))
+            self.d_model = widths.pop()
+        else:
+            self.d_model = sum(embedding_dims.values())
         for f, dim in embedding_dims.items():
             if dim % 8 != 0:
                 raise B4CError('MI355X build: embedding dim of feature %r is %d; must be a multiple of 8' % (f, dim))
@@ -346,7 +358,8 @@ class Transformer(nn.Module):
         return {'num_layers': self.num_layers, 'num_attention_heads': self.num_attention_heads,
                 'embedding_sizes': self.embedding_sizes, 'embedding_dims': self.embedding_dims,
                 'encoder_ff_dim': self.encoder_ff_dim, 'dropout_rate': self.dropout_rate,
-                'item_embedding_weights': self.item_embedding_weights}
+                'item_embedding_weights': self.item_embedding_weights,
+                **({'feature_combine': 'sum'} if self.feature_combine == 'sum' else {})}
 
     def packed_supported(self, S):
         """The padding-free layout runs on the bf16 MFMA attention kernels only (head depth 32 / 64, S <= 512)."""
@@ -371,6 +384,7 @@ class Transformer(nn.Module):
         if packed is not None and not self.packed_supported(S):
             raise B4CError('packed layout needs bf16, head depth 32 / 64 and S <= 512')
         x, key_pad = ops.EmbedFn.apply(self.pos_encoding, self.scale, rate, seed, self.compute_dtype,
-                                       len(ids) if packed is None else (len(ids), packed), *ids, *tables)
+                                       (len(ids), packed, 'sum') if self.feature_combine == 'sum' else
+                                       (len(ids) if packed is None else (len(ids), packed)), *ids, *tables)
         out = self.encoder(x, training, key_pad, _input_dropout_done=True, packed=packed, rows=rows)
         return (out, key_pad) if return_key_pad else out

@@ -34,8 +34,10 @@ struct EmbedArgs {
     const int64_t *ids[B4C_MAX_FEATURES];
     float *table[B4C_MAX_FEATURES];   // const for fwd; gradient tables for bwd
     int64_t rows[B4C_MAX_FEATURES];
-    int col0[B4C_MAX_FEATURES + 1];   // column offset of each feature in the d_model-wide row
+    int col0[B4C_MAX_FEATURES + 1];   // column offset of each feature in the d_model-wide row (all 0 when the features are summed)
+    int fd[B4C_MAX_FEATURES];         // width of each feature's table
     int n;
+    int sum;                          // 1: every feature is d_model wide and the rows are ADDED (config 4 of the north star)
 };
 
 // one thread = 8 consecutive output columns of one token (a 16-B bf16 / 32-B fp32 store)
@@ -53,20 +55,29 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(EmbedArgs a, const float
         // packed layout: output row t is the dense position token_src[t] = b * S + s (its ids and its positional row)
         const int64_t ts = token_src ? (int64_t)token_src[t] : t;
         const int s = (int)(ts % S);
-        int f = 0;
-#pragma unroll
-        for (int k = 1; k < B4C_MAX_FEATURES; ++k)
-            if (k < a.n && c >= a.col0[k]) f = k;
-        int64_t id = a.ids[f][ts];
         if (c == 0 && key_pad) key_pad[t] = (a.ids[0][ts] == 0) ? 1 : 0;
-        id = id < 0 ? 0 : (id >= a.rows[f] ? a.rows[f] - 1 : id);
-        const int fd = a.col0[f + 1] - a.col0[f];
-        const int cf = c - a.col0[f];
         float v[8], p[8];
-        const float *src = a.table[f] + id * fd + cf;
-        // a feature's width need not be a multiple of 8: chunks may straddle features only if the
-        // host let them; the host guarantees every feature dim % 8 == 0.
-        Vec8<float>::load(src, v);
+        if (a.sum) {        // rows of all features added in feature order (fp32), then scaled
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+            for (int f = 0; f < a.n; ++f) {
+                int64_t id = a.ids[f][ts];
+                id = id < 0 ? 0 : (id >= a.rows[f] ? a.rows[f] - 1 : id);
+                float w[8];
+                Vec8<float>::load(a.table[f] + id * d + c, w);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += w[k];
+            }
+        } else {
+            int f = 0;
+#pragma unroll
+            for (int k = 1; k < B4C_MAX_FEATURES; ++k)
+                if (k < a.n && c >= a.col0[k]) f = k;
+            int64_t id = a.ids[f][ts];
+            id = id < 0 ? 0 : (id >= a.rows[f] ? a.rows[f] - 1 : id);
+            // every feature dim is a multiple of 8 (the host checks): a chunk never straddles two features
+            Vec8<float>::load(a.table[f] + id * a.fd[f] + (c - a.col0[f]), v);
+        }
         Vec8<float>::load(pe + (int64_t)s * d + c, p);
         const uint32_t km = rate > 0.f ? b4c_keep8(seed, (uint64_t)(t * d + c), b4c_keep_threshold(rate)) : 0xFFu;
 #pragma unroll
@@ -100,14 +111,18 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(EmbedArgs a, float scale
         float g = (float)dout[t * ld + c];
         if (g == 0.f) continue;
         if (rate > 0.f && !b4c_keep_elem(seed, (uint64_t)i, rate)) continue;
-        int f = 0;
+        int f0 = 0;
 #pragma unroll
         for (int k = 1; k < B4C_MAX_FEATURES; ++k)
-            if (k < a.n && c >= a.col0[k]) f = k;
-        int64_t id = a.ids[f][t];
-        id = id < 0 ? 0 : (id >= a.rows[f] ? a.rows[f] - 1 : id);
-        if (id < EMB_HOT) atomicAdd(&hot[id * d + c], g * mul);
-        else atomicAdd(a.table[f] + id * (a.col0[f + 1] - a.col0[f]) + (c - a.col0[f]), g * mul);
+            if (k < a.n && c >= a.col0[k]) f0 = k;
+        const int f1 = a.sum ? a.n : f0 + 1;      // summed features all receive the gradient of the one d_model-wide row
+        for (int f = a.sum ? 0 : f0; f < f1; ++f) {
+            int64_t id = a.ids[f][t];
+            id = id < 0 ? 0 : (id >= a.rows[f] ? a.rows[f] - 1 : id);
+            // the LDS copy of the hot rows is per column of the d_model-wide row: with summed features it serves the last one
+            if (id < EMB_HOT && f == f0) atomicAdd(&hot[id * d + c], g * mul);
+            else atomicAdd(a.table[f] + id * a.fd[f] + (c - a.col0[f]), g * mul);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < EMB_HOT * d; i += 256) {
@@ -118,7 +133,7 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(EmbedArgs a, float scale
 #pragma unroll
         for (int k = 1; k < B4C_MAX_FEATURES; ++k)
             if (k < a.n && c >= a.col0[k]) f = k;
-        if (id < a.rows[f]) atomicAdd(a.table[f] + (int64_t)id * (a.col0[f + 1] - a.col0[f]) + (c - a.col0[f]), v);
+        if (id < a.rows[f]) atomicAdd(a.table[f] + (int64_t)id * a.fd[f] + (c - a.col0[f]), v);
     }
 }
 
@@ -127,6 +142,9 @@ static int fill_embed_args(EmbedArgs &a, int n_feat, const int64_t *const *h_ids
     B4C_REQUIRE(n_feat >= 1 && n_feat <= B4C_MAX_FEATURES, "embed: n_feat %d out of range", n_feat);
     memset(&a, 0, sizeof(a));
     a.n = n_feat;
+    // two or more features that are each d_model wide: their rows are added, not concatenated
+    a.sum = n_feat >= 2;
+    for (int f = 0; f < n_feat; ++f) a.sum = a.sum && h_dims[f] == d_model;
     int off = 0;
     for (int f = 0; f < n_feat; ++f) {
         B4C_REQUIRE(h_dims[f] > 0 && h_dims[f] % 8 == 0, "embed: feature dim %d must be a positive multiple of 8", h_dims[f]);
@@ -134,11 +152,12 @@ static int fill_embed_args(EmbedArgs &a, int n_feat, const int64_t *const *h_ids
         a.ids[f] = h_ids[f];
         a.table[f] = h_tables[f];
         a.rows[f] = h_rows[f];
-        a.col0[f] = off;
+        a.fd[f] = h_dims[f];
+        a.col0[f] = a.sum ? 0 : off;
         off += h_dims[f];
     }
-    for (int f = n_feat; f <= B4C_MAX_FEATURES; ++f) a.col0[f] = off;
-    B4C_REQUIRE(off == d_model, "embed: sum of feature dims %d != d_model %d", off, d_model);
+    for (int f = n_feat; f <= B4C_MAX_FEATURES; ++f) a.col0[f] = a.sum ? d_model : off;
+    B4C_REQUIRE(a.sum || off == d_model, "embed: sum of feature dims %d != d_model %d (and not every feature is d_model wide)", off, d_model);
     return B4C_OK;
 }
 
@@ -224,7 +243,7 @@ __global__ void __launch_bounds__(256) embed_bwd_sorted_kernel(EmbedArgs a, Embe
     const int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     if (p0 >= T_tok) return;
     const int np = (int)((T_tok - p0 < 64) ? T_tok - p0 : 64);
-    const int c0 = a.col0[f], fd = a.col0[f + 1] - c0;
+    const int c0 = a.col0[f], fd = a.fd[f];
     const int32_t *order = ord.order[f];
     const int64_t *ids = a.ids[f];
     const int64_t nrows = a.rows[f];

@@ -186,10 +186,19 @@ def remap_index(idx, mapping):
     return out
 
 
-def embed_concat_pe_fwd(ids_list, tables, pe, scale, rate, seed, dtype, packed=None):
+def embed_concat_pe_fwd(ids_list, tables, pe, scale, rate, seed, dtype, packed=None, combine='concat'):
+    """combine='sum' (two or more features of one width): the gathered rows are added instead of concatenated -- the
+    library takes that form when every table is d_model wide."""
     _cuda(pe, *ids_list, *tables)
     B, S = ids_list[0].shape
-    d = sum(int(t.shape[1]) for t in tables)
+    if combine == 'sum':
+        d = int(tables[0].shape[1])
+        if len(tables) < 2 or any(int(t.shape[1]) != d for t in tables):
+            raise B4CError("combine='sum' needs two or more embedding tables of one width")
+    elif combine == 'concat':
+        d = sum(int(t.shape[1]) for t in tables)
+    else:
+        raise B4CError("combine must be 'concat' or 'sum', got %r" % (combine,))
     for i in ids_list:
         if i.dtype != torch.int64 or not i.is_contiguous() or tuple(i.shape) != (B, S):
             raise B4CError('embedding ids must be contiguous int64 (B,S) tensors of one shape')
@@ -1140,15 +1149,18 @@ def _as2d(x):
 # --------------------------------------------------------------------------------------
 class EmbedFn(torch.autograd.Function):
     """R6: gather + concat + *sqrt(d) + PE (+ input dropout).  apply(pe, scale, rate, seed, dtype, n, *ids, *tables);
-    n may be (n, Packed): the packed layout, output (1, T, d)."""
+    n may be (n, Packed): the packed layout, output (1, T, d); or (n, Packed | None, 'sum'): the features' rows are added."""
 
     @staticmethod
     def forward(ctx, pe, scale, rate, seed, dtype, n, *args):
-        packed = None
+        packed, combine = None, 'concat'
         if isinstance(n, tuple):
-            n, packed = n
+            if len(n) == 3:
+                n, packed, combine = n
+            else:
+                n, packed = n
         ids, tables = list(args[:n]), list(args[n:])
-        out, key_pad = embed_concat_pe_fwd(ids, [t.detach() for t in tables], pe, scale, rate, seed, dtype, packed)
+        out, key_pad = embed_concat_pe_fwd(ids, [t.detach() for t in tables], pe, scale, rate, seed, dtype, packed, combine)
         if packed is not None:
             # backward works on the packed ids (one gather per feature): B = 1, S = T rows
             pk_ids = []

@@ -55,6 +55,10 @@ const char *b4c_last_error(void);
  *   key_pad[t] = (ids_0[t] == 0)
  * h_ids / h_tables / h_dims / h_rows: HOST arrays of n_feat entries (device pointers inside).
  * ids are int64 (B*S); ids outside [0, rows) are clamped.  pe: fp32 [>=S][d_model].
+ * The features are concatenated when their dims add up to d_model (the reference, :384-388).  SUMMED FEATURES (no reference
+ * counterpart; BASELINE.json configs[3] words the two-feature input as "gather + sum"): n_feat >= 2 and EVERY h_dims[f] ==
+ * d_model -- out[t, j] = drop( (sum_f table_f[ids_f[t], j]) * scale + pe[s, j] ), rows added in feature order in fp32, and
+ * the backward entry points give every table the gradient of the one d_model-wide row.
  * dropout: keep(e) from the counter hash b4c_keep(seed, e), e = t*d_model + col; rate 0 = off. */
 int b4c_embed_concat_pe_fwd(int n_feat, const int64_t *const *h_ids, const float *const *h_tables,
                             const int *h_dims, const int64_t *h_rows, const float *pe, float scale,

@@ -195,11 +195,18 @@ def dense(x, kernel, bias, act=None):
     return y
 
 
-def embed_concat_pe(ids_by_feature, tables, d_model, dtype=np.float32):
+def embed_concat_pe(ids_by_feature, tables, d_model, dtype=np.float32, combine='concat'):
     """transformer.py:384-398: per-feature gather, concat on last axis, * sqrt(float32(d)),
-    + PE[:, :S, :].  `ids_by_feature` and `tables` are dicts in the same key order."""
+    + PE[:, :S, :].  `ids_by_feature` and `tables` are dicts in the same key order.
+    combine='sum' (NO REFERENCE COUNTERPART -- the reference only concatenates; BASELINE.json configs[3] words the two-feature
+    input as "gather + sum"): the gathered rows, all d_model wide, are added in feature order before the scale."""
     parts = [np.asarray(tables[f], dtype=dtype)[np.asarray(ids_by_feature[f])] for f in ids_by_feature]
-    x = np.concatenate(parts, axis=-1)
+    if combine == 'sum':
+        x = parts[0]
+        for part in parts[1:]:
+            x = x + part
+    else:
+        x = np.concatenate(parts, axis=-1)
     S = x.shape[1]
     x = x * dtype(np.sqrt(np.float32(d_model)))
     pe = positional_encoding(MAX_POSITION if S <= MAX_POSITION else S, d_model)[:, :S, :]
@@ -249,15 +256,15 @@ def encoder_layer(x, p, num_heads, mask):
     return layer_norm(out1 + f, p['layernorm2.gamma'], p['layernorm2.beta'])
 
 
-def transformer_forward(ids_by_feature, params, num_layers, num_heads, dtype=np.float32, return_all=False):
+def transformer_forward(ids_by_feature, params, num_layers, num_heads, dtype=np.float32, return_all=False, combine='concat'):
     """transformer.py:376-402 + Encoder.call :255-268 (no final LayerNorm).
-    params: flat dict  'embedding_layers.<f>.weight', 'encoder.enc_layers.<i>.<...>'."""
+    params: flat dict  'embedding_layers.<f>.weight', 'encoder.enc_layers.<i>.<...>'.  combine: see embed_concat_pe."""
     params = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
     feats = list(ids_by_feature.keys())
     tables = {f: params['embedding_layers.%s.weight' % f] for f in feats}
-    d_model = sum(tables[f].shape[1] for f in feats)
+    d_model = tables[feats[0]].shape[1] if combine == 'sum' else sum(tables[f].shape[1] for f in feats)
     mask = create_padding_mask(ids_by_feature[feats[0]], dtype)
-    x = embed_concat_pe(ids_by_feature, tables, d_model, dtype)
+    x = embed_concat_pe(ids_by_feature, tables, d_model, dtype, combine)
     outs = [x]
     for i in range(num_layers):
         pre = 'encoder.enc_layers.%d.' % i

@@ -87,7 +87,7 @@ def _relu(name, z):
 
 
 def transformer_forward(ids_by_feature, P, num_layers, num_heads, dropout_rate=0.0, keep_masks=None, emulate_bf16=False,
-                        relu=_relu):
+                        relu=_relu, combine='concat'):
     """P: dict name -> tensor, names as numpy_ref.init_params without the 'transformer.' prefix.
     emulate_bf16: round to bf16 where the HIP throughput path stores bf16 (see _RoundBoth above).
     relu(name, z): the activation of the FFN ('ffn.<layer>'; the head's trunk calls 'head.<i>'); tests of the bf16 path pass one
@@ -98,7 +98,9 @@ def transformer_forward(ids_by_feature, P, num_layers, num_heads, dropout_rate=0
     feats = list(ids_by_feature.keys())
     first = ids_by_feature[feats[0]]
     B, S = first.shape
-    x = torch.cat([P['embedding_layers.%s.weight' % f][ids_by_feature[f]] for f in feats], dim=-1)
+    parts = [P['embedding_layers.%s.weight' % f][ids_by_feature[f]] for f in feats]
+    # combine='sum': no reference counterpart (numpy_ref.embed_concat_pe); rows added in feature order
+    x = sum(parts[1:], parts[0]) if combine == 'sum' else torch.cat(parts, dim=-1)
     d = x.shape[-1]
     dt = x.dtype
     x = x * float(np.sqrt(np.float32(d)))            # sqrt taken in float32 (transformer.py:390)
@@ -158,16 +160,17 @@ def sparse_ce_tf(probs, labels):
 
 
 def model_loss(ids, labels_compact, P, num_layers, num_heads, n_hidden, feature='items',
-               dropout_rate=0.0, keep_masks=None, variant='tf', emulate_bf16=False, extra_features=None, relu=_relu):
+               dropout_rate=0.0, keep_masks=None, variant='tf', emulate_bf16=False, extra_features=None, relu=_relu,
+               combine='concat'):
     """Full reference dataflow: encoder -> masked rows -> MLP -> V-way softmax
     (materialised) -> masked sparse CE mean.  labels_compact: (R,) int64 label-space ids.
     emulate_bf16: the same dataflow with the HIP throughput path's bf16 rounding points (the tight reference of the bf16
-    end-to-end tests).  extra_features: {name: ids} of further concatenated features (config 4)."""
+    end-to-end tests).  extra_features: {name: ids} of further concatenated (combine='sum': added) features (config 4)."""
     tP = {k[len('transformer.'):]: v for k, v in P.items() if k.startswith('transformer.')}
     hP = {k[len('head.'):]: v for k, v in P.items() if k.startswith('head.')}
     feats = {feature: ids}
     feats.update(extra_features or {})
-    enc = transformer_forward(feats, tP, num_layers, num_heads, dropout_rate, keep_masks, emulate_bf16, relu)
+    enc = transformer_forward(feats, tP, num_layers, num_heads, dropout_rate, keep_masks, emulate_bf16, relu, combine)
     rows, _ = gather_masked_rows(enc, ids)
     logits = softmax_head_logits(rows, hP, n_hidden, emulate_bf16, relu)
     probs = torch.softmax(logits, dim=-1)

@@ -191,3 +191,34 @@ def test_background_plan_partitions_the_vocabulary_tiles():
             assert sum(sizes) == n_tiles
             if n_tiles >= 100 and kicks:
                 assert sizes[0] == max(sizes) and min(sizes) > 0
+
+
+def test_feature_sum_restatement_and_config():
+    """feature_combine='sum' (an extension: the reference only concatenates, transformer.py:384-388): the restatement adds
+    the gathered rows in feature order before the sqrt(d) scale; the host class takes d_model from the one shared width."""
+    from oracle import torch_ref as tr
+    from bert4clickpath_amd.clickstream_transformer.transformer import Transformer
+    rng = np.random.default_rng(2)
+    d, S = 16, 7
+    ids = {'a': rng.integers(0, 9, (2, S)), 'b': rng.integers(0, 5, (2, S))}
+    tabs = {'a': rng.standard_normal((9, d)), 'b': rng.standard_normal((5, d))}
+    got = nr.embed_concat_pe(ids, tabs, d, np.float64, combine='sum')
+    want = (tabs['a'][ids['a']] + tabs['b'][ids['b']]) * np.float64(np.sqrt(np.float32(d))) + nr.positional_encoding(nr.MAX_POSITION, d)[:, :S]
+    assert np.array_equal(got, want)
+    cat = nr.embed_concat_pe(ids, tabs, 2 * d, np.float64)
+    assert cat.shape == (2, S, 2 * d)
+    # numpy and torch restatements agree through a whole encoder
+    t = Transformer(1, 2, {'a': 9, 'b': 5}, {'a': d, 'b': d}, 100, 0.0, feature_combine='sum')
+    assert t.d_model == d and t.get_config()['feature_combine'] == 'sum'
+    tP = {k: v.detach().double() for k, v in t.state_dict().items() if 'pos_encoding' not in k}
+    e_t = tr.transformer_forward({k: torch.from_numpy(v) for k, v in ids.items()}, tP, 1, 2, combine='sum')
+    e_n = nr.transformer_forward(ids, {k: v.numpy() for k, v in tP.items()}, 1, 2, np.float64, combine='sum')
+    assert float(np.abs(e_t.numpy() - e_n).max()) < 1e-12
+    assert 'feature_combine' not in Transformer(1, 2, {'a': 9}, {'a': d}, 100, 0.0).get_config()      # the reference's config keys
+    import pytest
+    with pytest.raises(ValueError):
+        Transformer(1, 2, {'a': 9, 'b': 5}, {'a': d, 'b': 8}, 100, 0.0, feature_combine='sum')
+    with pytest.raises(ValueError):
+        Transformer(1, 2, {'a': 9}, {'a': d}, 100, 0.0, feature_combine='sum')
+    with pytest.raises(ValueError):
+        Transformer(1, 2, {'a': 9}, {'a': d}, 100, 0.0, feature_combine='mean')
