@@ -112,7 +112,7 @@ def test_more_masks_than_the_cap_poisons_the_loss(packed):
                         n_real_tokens=n_real if packed else None, packed=None if packed else False)
     loss.backward()
     torch.cuda.synchronize()
-    assert np.isnan(float(loss))
+    assert np.isnan(float(loss.detach()))
     counts, offsets, flat, mx = ops.mask_positions(torch.cat([items, items], 1).contiguous(), 1, cap=B * 2)
     assert int(offsets.max()) == B * 2 and int(mx) < 0
     # within the cap nothing changes
@@ -161,3 +161,46 @@ def test_deterministic_projection_gradient_over_a_whole_step():
             assert float((g - grads[1][n]).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-9, n
     finally:
         ops.background_workgroups, ops.deterministic_vocab_dw = prev
+
+
+def test_a_failed_backward_leaves_nothing_for_the_next_step(monkeypatch):
+    """A backward pass that raises after the vocabulary head queued its background dW sweep (the pieces hold that step's
+    tensors): the next zero_grad() drops them (ArenaContext.reset), and the training continues exactly where a run
+    without the failure is."""
+    from bert4clickpath_amd import ops
+    prev = ops.background_workgroups
+    ops.background_workgroups = 8
+    try:
+        batches = [_batch(51), _batch(52)]
+        ref = _ArenaAdam(_model(5, 3))
+        want = [ref.step_on(*batches[0]), ref.step_on(*batches[1])]
+        torch.cuda.synchronize()
+        t = _ArenaAdam(_model(5, 3))
+        got = [t.step_on(*batches[0])]
+        real, calls = ops.attn_bwd, {'n': 0}
+
+        def failing(*a, **k):
+            calls['n'] += 1
+            raise RuntimeError('injected: attention backward fails')
+        monkeypatch.setattr(ops, 'attn_bwd', failing)
+        t.opt.zero_grad()
+        loss = t.model.cloze_loss({'asin': batches[1][0]}, batches[1][1], training=True, max_masked_per_row=10, n_real_tokens=batches[1][2])
+        with pytest.raises(RuntimeError, match='injected'):
+            loss.backward()
+        assert calls['n'] == 1
+        ctx = t.opt.arena.ctx
+        left = len(ctx.queue) + len(ctx.pending)
+        monkeypatch.setattr(ops, 'attn_bwd', real)
+        got.append(t.step_on(*batches[1]))               # zero_grad() -> ctx.reset(): the stale pieces never run
+        torch.cuda.synchronize()
+        assert not ctx.queue and not ctx.pending and ops._active_ctx is None
+        assert left > 0, 'the injected failure came before any side-stream work was queued: the test checks nothing'
+        assert np.allclose(got, want, rtol=1e-4, atol=0), (got, want)
+        w0 = _weights(ref.model)
+        for n, w in _weights(t.model).items():
+            if n.endswith('mha.wk.bias'):
+                continue
+            assert float((w - w0[n]).abs().max()) <= 2.5e-3, n
+            assert float((w - w0[n]).norm()) <= 2e-2 * float(w0[n].norm()) + 1e-6, n
+    finally:
+        ops.background_workgroups = prev

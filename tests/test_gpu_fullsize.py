@@ -310,3 +310,68 @@ def test_c5_shape_slice_runs_on_the_mfma_and_sampled_paths(gpu):
         assert bool(torch.isfinite(opt.arena.flat).all())
     finally:
         pass          # (an arena no longer changes process state: nothing to restore)
+
+
+def test_c5_one_gpu_share_full_size_properties(gpu):
+    """Config 5 at the size one GPU of the 8 carries (bench.py --config c5): vocab 2,000,000, S = 512, d_model 256, 4 heads,
+    4 layers, batch 1024, head [1024, 512, 256, 128] -> 8,192 shared sampled negatives.  No oracle runs at this size (and
+    the sampled head has no reference counterpart); size-independent properties instead: the padding-free layout and the
+    padded one give the same loss and the same gradients at real positions' parameters, the S = 512 key-block attention is
+    the path taken, both 2M-row tables' gradients are row-sparse exactly where the batch and the sampler touched them, an Adam
+    step keeps every one of the 770 M arena entries finite, and a second identical step from the same state is reproducible
+    to float-atomic noise."""
+    from bert4clickpath_amd import input_pipeline, ops, optim
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SampledSoftmaxHead
+    V, S, B, L, H = 2000000, 512, 1024, 4, 4
+    torch.manual_seed(78)
+    head = SampledSoftmaxHead([1024, 512, 256, 128], V, num_sampled=8192)
+    model = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': 256}, head,
+                                   value_to_head='[MASK]', num_encoder_layers=L, num_attention_heads=H, dropout_rate=0.0,
+                                   compute_dtype=torch.bfloat16).cuda()
+    assert ops.L.lib().b4c_attn_bwd_workspace_bytes(B, S, H, 64, ops.L.BF16) == B * S * 256 * 4
+    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=10)
+    ids = torch.from_numpy(b['ids']).cuda()
+    items = ids[:, 2:S - 1].contiguous()
+    labels = torch.from_numpy(b['labels_padded']).cuda()
+    n_real = int((b['ids'] != 0).sum())
+    assert 0.45 < n_real / (B * S) < 0.6                      # lengths U{20..509}
+    opt = optim.Adam(model.parameters())
+    from bert4clickpath_amd.clickstream_transformer.transformer import set_dropout_seed
+    names = ['transformer.encoder.enc_layers.0.mha.wq.kernel', 'transformer.encoder.enc_layers.3.ffn.1.kernel',
+             'head.intermediate_layers.0.kernel', 'transformer.encoder.enc_layers.1.layernorm2.gamma']
+    params = dict(model.named_parameters())
+
+    def one_pass(**kw):
+        opt.zero_grad()
+        set_dropout_seed(1234)                                # the negatives are drawn from this stream: same draw every pass
+        loss = model.cloze_loss({'asin': items}, labels, training=True, max_masked_per_row=10, **kw)
+        loss.backward()
+        ops.join_side_work(opt.arena.ctx)
+        torch.cuda.synchronize()
+        return float(loss.detach()), {n: params[n].grad.detach().float().clone() for n in names}
+
+    lp, gp = one_pass(n_real_tokens=n_real)                   # padding-free layout
+    assert np.isfinite(lp) and 11.0 < lp < 18.0               # ~ log V = 14.5 at initialisation
+    table = model.transformer.embedding_layers['items'].weight
+    touched = torch.zeros(V + 11, dtype=torch.bool, device='cuda')
+    touched[ids.reshape(-1)] = True
+    assert float(table.grad[~touched].abs().max()) == 0.0 and float(table.grad[touched].abs().sum()) > 0
+    t2 = torch.zeros(V, dtype=torch.bool, device='cuda')
+    t2[head.touched_rows()] = True
+    assert int(t2.sum()) <= 8192 + B * 10
+    assert float(head.output_embedding.grad[~t2].abs().max()) == 0.0 and float(head.output_embedding.grad[t2].abs().sum()) > 0
+    lp2, gp2 = one_pass(n_real_tokens=n_real)                 # same state, same batch (the sampler draws again)
+    ld, gd = one_pass(packed=False)                           # padded layout: every position of every layer
+    same_sampler = abs(lp2 - lp) < 1e-6 * abs(lp)
+    tol_loss = 2e-3 if same_sampler else 3e-2                 # fresh negatives move the sampled estimate of the loss a little
+    assert abs(ld - lp2) < tol_loss * abs(lp2) and abs(lp2 - lp) < tol_loss * abs(lp), (lp, lp2, ld)
+    for n in names:
+        a, c = gp2[n], gd[n]
+        assert bool(torch.isfinite(a).all()) and float(a.norm()) > 0, n
+        if same_sampler:
+            assert float((a - c).norm() / c.norm()) < 3e-2, (n, float((a - c).norm() / c.norm()))      # bf16 sums in another order
+    opt.step()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(opt.arena.flat).all())
+    del opt, model
+    torch.cuda.empty_cache()
