@@ -222,3 +222,33 @@ def test_feature_sum_restatement_and_config():
         Transformer(1, 2, {'a': 9}, {'a': d}, 100, 0.0, feature_combine='sum')
     with pytest.raises(ValueError):
         Transformer(1, 2, {'a': 9}, {'a': d}, 100, 0.0, feature_combine='mean')
+
+
+def test_only_the_checkers_touch_the_oracle():
+    """oracle/ is test infrastructure: the package, the examples and bench.py's timed path never import it -- only tests/,
+    __graft_entry__.smoke() and bench.py's cpu_baseline leg do -- and the package has no CPU fallback to route through."""
+    import ast
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+
+    def oracle_imports(path):
+        tree = ast.parse(path.read_text())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and (node.module or '').split('.')[0] == 'oracle':
+                hits.append(node.lineno)
+            if isinstance(node, ast.Import) and any(a.name.split('.')[0] == 'oracle' for a in node.names):
+                hits.append(node.lineno)
+        return hits
+    for path in list((root / 'bert4clickpath_amd').rglob('*.py')) + list((root / 'clickstream_transformer').rglob('*.py')) + \
+            list((root / 'examples').rglob('*.py')):
+        assert not oracle_imports(path), '%s imports the oracle' % path
+    # bench.py: inside cpu_baseline() only;  __graft_entry__.py: inside smoke() only
+    for name, fn in (('bench.py', 'cpu_baseline'), ('__graft_entry__.py', 'smoke')):
+        tree = ast.parse((root / name).read_text())
+        allowed = set()
+        for node in ast.walk(tree):
+            if isinstance(node, ast.FunctionDef) and node.name == fn:
+                allowed = set(range(node.lineno, node.end_lineno + 1))
+        lines = oracle_imports(root / name)
+        assert lines and all(l in allowed for l in lines), (name, lines)
