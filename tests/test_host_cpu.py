@@ -252,3 +252,22 @@ def test_only_the_checkers_touch_the_oracle():
                 allowed = set(range(node.lineno, node.end_lineno + 1))
         lines = oracle_imports(root / name)
         assert lines and all(l in allowed for l in lines), (name, lines)
+
+
+def test_a_missing_library_is_an_error_not_a_fallback():
+    """the product path without libb4c_hip.so: a B4CError that says how to build it -- nothing is computed another way"""
+    import subprocess
+    import sys
+    code = ("import torch\n"
+            "from bert4clickpath_amd import ops\n"
+            "from bert4clickpath_amd._lib import B4CError\n"
+            "try:\n"
+            "    ops.keep_mask(1, 8, 0.5) if False else ops.L.lib()\n"
+            "except B4CError as e:\n"
+            "    print('B4CError:', e)\n"
+            "else:\n"
+            "    print('loaded')\n")
+    env = dict(os.environ, B4C_LIB_PATH='/nonexistent/libb4c_hip.so', PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert 'B4CError' in out.stdout and 'no CPU fallback' in out.stdout and 'loaded' not in out.stdout
