@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(256) mask_count_kernel(const int64_t *__restri
 }
 
 // clamp >= 0: offsets are clamped to it (a caller-given row count -- the packed layout's token count, the sync-free Cloze
-// path's B x max_masked_per_row -- must never index past the tensors that were sized by it) and maxcount[0] is NEGATED
+// path's B x max_masked_per_row -- must never index past the tensors that were sized by it) and maxcount[0] is written as -(max) - 1
 // when the true total differs from it (EXACT) or exceeds it (!EXACT): a poison flag the host folds into the loss without a
 // read-back; `poison` (optional) is set to -1 in the same case
 template <bool EXACT>

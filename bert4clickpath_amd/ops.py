@@ -664,7 +664,7 @@ def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed, into=None):
 
 def mask_positions(ids, value, cap=None, poison=None):
     """-> counts[B], offsets[B+1], flat_idx[cap], maxcount[1] (all int32, device).  More matches than `cap`: offsets stay
-    within cap, maxcount comes back negated and the int32 flag `poison` (optional) is set to -1 (include/b4c.h)."""
+    within cap, maxcount comes back as -(longest row) - 1 and the int32 flag `poison` (optional) is set to -1 (include/b4c.h)."""
     _cuda(ids)
     B, S = ids.shape
     cap = B * S if cap is None else cap

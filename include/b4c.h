@@ -200,7 +200,8 @@ int b4c_add_dropout_layernorm_bwd(const void *dout, const void *z, const float *
  * order (entries >= R untouched), maxcount[1].  All int32 except ids (int64).
  * More matches than `cap` (a caller-limited row count, e.g. B x max_masked_per_row of the sync-free Cloze path): the
  * offsets are clamped to cap -- consumers that size their row tensors by cap never index past them -- maxcount[0] comes
- * back NEGATED and `poison` (optional int32 flag) is set to -1, for the caller to fold into the loss as NaN. */
+ * back as -(longest row) - 1 (negative even when that is 0) and `poison` (optional int32 flag) is set to -1, for the caller to
+ * fold into the loss as NaN. */
 int b4c_mask_positions(const int64_t *ids, int B, int S, int64_t value, int32_t *counts, int32_t *offsets,
                        int32_t *flat_idx, int32_t cap, int32_t *maxcount, int32_t *poison, void *stream);
 /* padded_idx[B*M] = flat index of the m-th match of row b, or -1 (pad slot). */

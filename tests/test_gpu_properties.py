@@ -1,0 +1,222 @@
+"""Integer / index work of the hot path on randomly drawn shapes (hypothesis), bit for bit against numpy restatements of the
+reference lines: [MASK]-position generation and its caps (clickstream_transformer.py:260-297), the padding-free layout's
+bookkeeping (transformer.py:38-41 with input_pipeline.py:198-214), the stable sort behind the embedding backward, label
+compaction (utils.py:104-113), row gather / scatter.  Degenerate shapes are part of the draw: one row, one column, no match at
+all, every position a match, all-pad sequences, caps below and at the true count."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+pytestmark = pytest.mark.gpu
+
+from oracle import numpy_ref as nr  # noqa: E402
+
+SET = dict(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture,
+                                                                   HealthCheck.data_too_large])
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('needs the MI355X')
+    from bert4clickpath_amd import ops as o
+    return o
+
+
+def _ids(draw_seed, B, S, p_match, p_pad_tail):
+    rng = np.random.default_rng(draw_seed)
+    ids = rng.integers(2, 40, (B, S)).astype(np.int64)
+    ids[rng.random((B, S)) < p_match] = 1
+    lens = rng.integers(0, S + 1, B) if p_pad_tail else np.full(B, S)
+    ids[np.arange(S)[None, :] >= lens[:, None]] = 0
+    return ids
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 70), S=st.integers(1, 260), p=st.sampled_from([0.0, 0.02, 0.3, 1.0]),
+       cap_mode=st.sampled_from(['none', 'exact', 'short']))
+def test_mask_positions_any_shape(ops, seed, B, S, p, cap_mode):
+    ids = _ids(seed, B, S, p, False)
+    idx_ref, counts_ref = nr.mask_positions(ids, 1)
+    R = len(idx_ref)
+    flat_ref = (idx_ref[:, 0] * S + idx_ref[:, 1]).astype(np.int32) if R else np.zeros(0, np.int32)
+    cap = {'none': None, 'exact': max(R, 1), 'short': max(R // 2, 1)}[cap_mode]
+    poison = torch.zeros(1, dtype=torch.int32, device='cuda')
+    counts, offsets, flat, mx = ops.mask_positions(torch.from_numpy(ids).cuda(), 1, cap=cap, poison=poison)
+    off_ref = np.concatenate([[0], np.cumsum(counts_ref)]).astype(np.int64)
+    assert np.array_equal(counts.cpu().numpy(), counts_ref.astype(np.int32))
+    longest = int(counts_ref.max()) if B else 0
+    if cap is None or R <= cap:
+        assert np.array_equal(offsets.cpu().numpy(), off_ref.astype(np.int32))
+        assert np.array_equal(flat[:R].cpu().numpy(), flat_ref)
+        assert int(mx) == longest and int(poison) == 0
+    else:       # more matches than rows the caller allocated: offsets clamped, the first `cap` indices intact, the flags raised
+        assert np.array_equal(offsets.cpu().numpy(), np.minimum(off_ref, cap).astype(np.int32))
+        assert np.array_equal(flat[:cap].cpu().numpy(), flat_ref[:cap])
+        assert int(mx) == -longest - 1 and int(poison) == -1
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 60), S=st.integers(1, 230), wrong_cap=st.sampled_from([0, -3, 5]))
+def test_nonpad_positions_any_shape(ops, seed, B, S, wrong_cap):
+    ids = _ids(seed, B, S, 0.05, True)
+    real = ids != 0
+    counts_ref = real.sum(1).astype(np.int32)
+    T = int(counts_ref.sum())
+    src_ref = np.flatnonzero(real.reshape(-1)).astype(np.int32)
+    cap = max(T + wrong_cap, 0)
+    counts, cu, tok_src, packed_of, mx = ops.nonpad_positions(torch.from_numpy(ids).cuda(), cap)
+    assert np.array_equal(counts.cpu().numpy(), counts_ref)
+    cu_ref = np.concatenate([[0], np.cumsum(counts_ref)])
+    longest = int(counts_ref.max())
+    if cap == T:
+        assert np.array_equal(cu.cpu().numpy(), cu_ref.astype(np.int32))
+        assert np.array_equal(tok_src[:T].cpu().numpy(), src_ref)
+        inv = np.full(B * S, -1, np.int32)
+        inv[src_ref] = np.arange(T, dtype=np.int32)
+        assert np.array_equal(packed_of.cpu().numpy(), inv)
+        assert int(mx) == longest
+    else:       # a wrong token count from the caller: never an index past `cap`, and the poison flag
+        assert int(cu.max()) <= cap and int(mx) == -longest - 1
+        n = min(cap, T)
+        assert np.array_equal(tok_src[:n].cpu().numpy(), src_ref[:n])
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(1, 9000), n_rows=st.sampled_from([1, 2, 37, 255, 256, 257, 65536, 65537, 2000011]),
+       skew=st.booleans())
+def test_library_sort_is_numpy_stable_argsort(ops, seed, n, n_rows, skew):
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(-3, n_rows + 3, n)                       # out-of-range ids are clamped as the embedding kernels clamp them
+    if skew:
+        ids[rng.random(n) < 0.7] = min(3, n_rows - 1)           # one hot id: long runs of equal keys
+    order = ops._sort_order(torch.from_numpy(ids.astype(np.int64)).cuda(), n_rows)
+    want = np.argsort(np.clip(ids, 0, n_rows - 1), kind='stable').astype(np.int32)
+    assert np.array_equal(order.cpu().numpy(), want)
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 50), S=st.integers(3, 120), M=st.integers(1, 12))
+def test_compact_labels_and_padded_index(ops, seed, B, S, M):
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(2, 40, (B, S)).astype(np.int64)
+    n = rng.integers(0, min(M, S) + 1, B)
+    labels = np.full((B, M), -1.0, np.float32)
+    for b in range(B):
+        pos = np.sort(rng.choice(S, n[b], replace=False))
+        ids[b, pos] = 1
+        labels[b, :n[b]] = rng.integers(0, 1000, n[b])
+    counts, offsets, flat, mx = ops.mask_positions(torch.from_numpy(ids).cuda(), 1, cap=B * M)
+    R = int(n.sum())
+    lab = ops.compact_labels(torch.from_numpy(labels).cuda(), counts, offsets, B * M, flat)
+    want = labels[labels != -1].astype(np.int32)               # cloze_output_adaptor's boolean_mask order = row-major
+    assert np.array_equal(lab[:R].cpu().numpy(), want) and bool((lab[R:] == -1).all()) and bool((flat[R:] == -1).all())
+    Mx = max(int(mx), 1)
+    pidx = ops.padded_index(counts, offsets, flat, B, Mx).cpu().numpy().reshape(B, Mx)
+    idx_ref, _ = nr.mask_positions(ids, 1)
+    for b in range(B):
+        mine = idx_ref[idx_ref[:, 0] == b]
+        assert np.array_equal(pidx[b, :n[b]], (mine[:, 0] * S + mine[:, 1]).astype(np.int32)) and bool((pidx[b, n[b]:] == -1).all())
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), rows=st.integers(1, 400), d=st.sampled_from([8, 24, 64, 128, 264]), n=st.integers(0, 300),
+       dtype=st.sampled_from(['f32', 'bf16']))
+def test_gather_then_scatter_rows(ops, seed, rows, d, n, dtype):
+    rng = np.random.default_rng(seed)
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    src = torch.from_numpy(rng.standard_normal((rows, d)).astype(np.float32)).cuda().to(dt)
+    n = min(n, rows)
+    idx_h = np.sort(rng.choice(rows, n, replace=False)).astype(np.int32)
+    pad = rng.random(n + 5) < 0.2                                # -1 entries gather zero rows (to_tensor(0) in the reference)
+    idx_pad = np.concatenate([idx_h, np.full(5, -1, np.int32)])
+    idx_pad = np.where(pad, -1, idx_pad).astype(np.int32)
+    got = ops.gather_rows(src, torch.from_numpy(idx_pad).cuda(), n + 5)
+    want = torch.zeros(n + 5, d, dtype=dt)
+    keep = idx_pad >= 0
+    want[torch.from_numpy(keep)] = src.cpu()[torch.from_numpy(idx_pad[keep]).long()]
+    assert torch.equal(got.cpu(), want)
+    if n:
+        idx = torch.from_numpy(idx_h).cuda()
+        back = ops.scatter_rows(ops.gather_rows(src, idx, n), idx, rows)
+        ref = torch.zeros(rows, d, dtype=dt)
+        ref[torch.from_numpy(idx_h).long()] = src.cpu()[torch.from_numpy(idx_h).long()]
+        assert torch.equal(back.cpu(), ref)
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), R=st.integers(1, 40), V=st.integers(1, 3000), k=st.integers(1, 16), levels=st.sampled_from([0, 2, 5, 64]),
+       dtype=st.sampled_from(['f32', 'bf16']))
+def test_topk_ids_with_ties_any_shape(ops, seed, R, V, k, levels, dtype):
+    """tf.math.top_k's contract (utils.py:161-190): values descending, equal values by ascending index -- on score rows with
+    `levels` distinct values (0 = continuous), i.e. from no ties to almost nothing but ties, bit for bit."""
+    k = min(k, V)
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((R, V)).astype(np.float32) if levels == 0 else rng.integers(0, levels, (R, V)).astype(np.float32) / 4
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    ld = (V + 7) // 8 * 8
+    s = torch.zeros(R, ld)
+    s[:, :V] = torch.from_numpy(x)
+    sd = s.cuda().to(dt)
+    xs = sd.float().cpu().numpy()[:, :V]
+    labels = rng.integers(0, V, R).astype(np.int32)
+    _, want = nr.top_k(xs, k)
+    idx, hit, ndcg = ops.topk_rows(sd, V, k, torch.from_numpy(labels).cuda())
+    assert np.array_equal(idx.cpu().numpy(), want)
+    pos = (want == labels[:, None])
+    assert np.array_equal(hit.cpu().numpy(), pos.any(1).astype(np.float32))
+    disc = 1.0 / (np.log(np.arange(2, k + 2, dtype=np.float32)) / np.log(np.float32(2.0)))
+    assert np.allclose(ndcg.cpu().numpy(), (pos * disc[None]).sum(1), atol=1e-6)
+
+
+@settings(**dict(SET, max_examples=25))
+@given(seed=st.integers(0, 2 ** 31 - 1), R=st.integers(1, 300), V=st.integers(9, 2500), K=st.sampled_from([64, 128]), integer=st.booleans(),
+       k=st.integers(1, 12))
+def test_logits_free_rank_and_topk_any_shape(ops, seed, R, V, K, integer, k):
+    """b4c_vocab_rank / b4c_vocab_topk (scores recomputed in the matrix cores, never stored) against the scores formed in fp64
+    from the same bf16 operands: integer operands make every product and sum exact, so ranks and ids -- ties included -- must
+    match bit for bit; continuous operands are compared where the fp64 gap to the neighbouring item exceeds the fp32 rounding."""
+    k = min(k, V)
+    g = torch.Generator().manual_seed(seed)
+    if integer:
+        h = torch.randint(0, 3, (R, K), generator=g).float()
+        W = torch.randint(-1, 2, (V, K), generator=g).float()
+        b = torch.randint(0, 2, (V,), generator=g).float()
+    else:
+        h = (torch.randn(R, K, generator=g) * 0.5).bfloat16().float()
+        W = (torch.randn(V, K, generator=g) * 0.3).bfloat16().float()
+        b = torch.randn(V, generator=g) * 0.5
+    y = torch.randint(0, V, (R,), generator=g).int()
+    y[torch.rand(R, generator=g) < 0.1] = -1
+    Vp = (V + 7) // 8 * 8
+    hd = h.cuda().bfloat16()
+    wt = torch.zeros(Vp, K, device='cuda', dtype=torch.bfloat16)
+    wt[:V] = W.cuda().bfloat16()
+    bd = torch.zeros(Vp, device='cuda')
+    bd[:V] = b.cuda()
+    x = (h.double() @ W.double().t() + b.double()).numpy()
+    yn = y.numpy()
+    xy = x[np.arange(R), np.maximum(yn, 0)][:, None]
+    j = np.arange(V)[None, :]
+    want_rank = np.where(yn >= 0, ((x > xy) | ((x == xy) & (j < yn[:, None]))).sum(1), -1)
+    rank = ops.vocab_rank(hd, wt, bd, y.cuda(), V).cpu().numpy()
+    idx, hit, ndcg, overflow = ops.vocab_topk(hd, wt, bd, V, k, y.cuda())
+    idx = idx.cpu().numpy()
+    _, want_idx = nr.top_k(x.astype(np.float64), k)
+    if integer:
+        assert np.array_equal(np.where(yn >= 0, rank, -1), want_rank)
+        ok = idx[:, 0] >= 0                                   # rows flagged as overflowing (too many ties at the threshold) carry -1
+        assert int((~ok).sum()) == int(overflow)
+        assert np.array_equal(idx[ok], want_idx[ok])
+    else:
+        # a rank may differ only where some item's fp64 score is within fp32 rounding of the label's
+        gap = np.abs(x - xy)
+        gap[np.arange(R), np.maximum(yn, 0)] = np.inf
+        clear = (gap.min(1) > 1e-4) & (yn >= 0)
+        assert np.array_equal(rank[clear], want_rank[clear])
+        assert int(overflow) == 0
+        srt = -np.sort(-x, axis=1)
+        m = min(k, V - 1)                                     # the k-th item has a neighbour below it unless k == V
+        clear_k = (srt[:, :m] - srt[:, 1:m + 1] > 1e-4).all(1)
+        assert np.array_equal(idx[clear_k], want_idx[clear_k])
