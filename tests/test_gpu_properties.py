@@ -220,3 +220,80 @@ def test_logits_free_rank_and_topk_any_shape(ops, seed, R, V, K, integer, k):
         m = min(k, V - 1)                                     # the k-th item has a neighbour below it unless k == V
         clear_k = (srt[:, :m] - srt[:, 1:m + 1] > 1e-4).all(1)
         assert np.array_equal(idx[clear_k], want_idx[clear_k])
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), M=st.integers(1, 700), N8=st.integers(1, 66), K8=st.integers(1, 33), dtype=st.sampled_from(['f32', 'bf16']),
+       bias=st.booleans(), relu=st.booleans(), residual=st.booleans())
+def test_gemm_nt_epilogues_exact_on_integers(ops, seed, M, N8, K8, dtype, bias, relu, residual):
+    """Dense call sites (transformer.py:112-116, 165-166; head.py:35-36): small integers are exact in bf16 and their dot
+    products in fp32, so y = act(a bt^T + bias) + residual must come out bit for bit at ANY M, N, K (tile edges, K tails)."""
+    from bert4clickpath_amd import _lib as L
+    N, K = 8 * N8, 8 * K8
+    g = torch.Generator().manual_seed(seed)
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    bt = torch.randint(-3, 4, (N, K), generator=g).float()
+    b = torch.randint(-5, 6, (N,), generator=g).float() if bias else None
+    r = torch.randint(-4, 5, (M, N), generator=g).float() if residual else None
+    want = a.double() @ bt.double().T
+    if bias:
+        want = want + b.double()
+    if relu:
+        want = want.clamp(min=0)
+    if residual:
+        want = want + r.double()
+    got = ops.gemm_nt(a.cuda().to(dt), bt.cuda().to(dt), N, b.cuda() if bias else None, L.ACT_RELU if relu else L.ACT_NONE,
+                      residual=r.cuda().to(dt) if residual else None, out_dtype=torch.float32)
+    assert torch.equal(got.cpu().double(), want)
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), M=st.integers(1, 5000), K8=st.integers(1, 33), N8=st.integers(1, 49), dtype=st.sampled_from(['f32', 'bf16']))
+def test_gemm_tn_exact_on_integers(ops, seed, M, K8, N8, dtype):
+    """dW = a^T g and db = colsum(g) (the weight gradients of every Dense): exact on small integers for any token count,
+    whatever the token split the launch picks."""
+    K, N = 8 * K8, 8 * N8
+    g = torch.Generator().manual_seed(seed)
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    a = torch.randint(-2, 3, (M, K), generator=g).float()
+    gr = torch.randint(-2, 3, (M, N), generator=g).float()
+    dW, db = ops.gemm_tn(a.cuda().to(dt), gr.cuda().to(dt), K, N)
+    assert torch.equal(dW.cpu().double(), a.double().T @ gr.double())
+    assert torch.equal(db.cpu().double(), gr.double().sum(0))
+
+
+@settings(**dict(SET, max_examples=20))
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 7), smax=st.integers(1, 300), H=st.sampled_from([1, 2, 4]), dh=st.sampled_from([32, 64]),
+       with_empty=st.booleans())
+def test_varlen_attention_random_ragged_batches(ops, seed, B, smax, H, dh, with_empty):
+    """scaled_dot_product_attention (transformer.py:64-97) per sequence of a padding-free batch, forward and backward against
+    fp64 (bf16 operands: 1.2e-2 / 2.5e-2 relative, the bounds of tests/test_gpu_packed.py); sequences of length 0 allowed."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0 if with_empty else 1, smax + 1, B)
+    if lens.sum() == 0:
+        lens[0] = 1
+    T, d = int(lens.sum()), H * dh
+    g = torch.Generator().manual_seed(seed)
+    qkv = (torch.randn(T, 3 * d, generator=g) * 0.8).bfloat16()
+    do = torch.randn(T, d, generator=g).bfloat16()
+    cu_h = np.concatenate([[0], np.cumsum(lens)])
+    cu = torch.tensor(cu_h, dtype=torch.int32, device='cuda')
+    key_pad = torch.zeros(T, dtype=torch.uint8, device='cuda')
+    S_max = int(max(lens.max(), 1))
+    o, lse = ops.attn_fwd(qkv.cuda(), key_pad, B, S_max, H, dh, cu)
+    q64 = qkv.double().requires_grad_(True)
+    outs = []
+    for b in range(B):
+        rows = q64[cu_h[b]:cu_h[b + 1]]
+        Lb = rows.shape[0]
+        q, k, v = [rows[:, i * d:(i + 1) * d].reshape(Lb, H, dh).permute(1, 0, 2) for i in range(3)]
+        w = torch.softmax(q @ k.transpose(-1, -2) / float(np.sqrt(np.float32(dh))), -1)
+        outs.append((w @ v).permute(1, 0, 2).reshape(Lb, d))
+    o_ref = torch.cat(outs)
+    err = lambda a, r: float((a.double().cpu() - r).norm() / r.norm())      # noqa: E731
+    assert err(o, o_ref.detach()) < 1.2e-2
+    o_ref.backward(do.double())
+    dqkv = ops.attn_bwd(qkv.cuda(), key_pad, o, do.cuda(), lse, B, S_max, H, dh, cu)
+    assert err(dqkv, q64.grad) < 2.5e-2
+    assert torch.equal(ops.attn_bwd(qkv.cuda(), key_pad, o, do.cuda(), lse, B, S_max, H, dh, cu), dqkv)     # run-to-run identical
