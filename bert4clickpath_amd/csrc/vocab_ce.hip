@@ -129,8 +129,8 @@ struct VceArgs {
     float *st1;           // [parts][R][4]: m2 (log2-domain reference), l = sum 2^(x log2e - m2), min x, max x
     float *u;             // [parts][R][KD]: sum 2^(x log2e - m2) W   (un-normalised P W)
     float *ud;            // [parts][R][KD]: Ud = sum over the p outside the clip range of p W (normalised)
-    float *sp;            // [parts][R][4]: nu (entries inside the clip range), Pc (sum of the p outside it), nhi (entries above it), -
-    float *rowscal;       // [R][8]: lse2, c = a - b, nb = -b, lo (clip range, -inf / +inf on rows that stay inside), yd, hi, -, -
+    float *sp;            // [parts][R][4]: nu (entries inside the clip range, the row's dominant one apart), Pc (sum of the p below it), ntop (entries above 1/2: 0 or 1), -
+    float *rowscal;       // [R][8]: lse2, c = a - b, nb = -b, lo (lower clip bound, -inf on rows that stay inside), gs yd, 1 = every probability outside the range (c = nb = 0), -, -
     float *item_loss;     // [R]
     bf16_t *dh;           // [R][ld_dh]
     int ld_h, ld_w, ld_dh;
@@ -212,13 +212,15 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
     const int vt0 = (int)((int64_t)nvt * part / a.parts), vt1 = (int)((int64_t)nvt * (part + 1) / a.parts);
 
     float lse2 = INFINITY;   // MODE 2: log2-domain lse of the lane's token
-    bool anyhi = false;      // MODE 2: some token of this tile has a probability above 1 - 1e-7
+    bool anyhi = false;      // MODE 2: some token of this tile has a DOMINANT entry (p > 1/2), the only kind that can pass 1 - 1e-7
     if (MODE == 2) {
         bool clipped = false;
         float pmax = 0.f;
         if (tok < a.R) vce_row_stats(a, tok, lse2, clipped, pmax);
         if (!__syncthreads_or(clipped)) return;          // no clipped row in these 128 tokens (block-uniform)
-        anyhi = __syncthreads_or(pmax > 1.0f - VCE_EPS);
+        // (pmax is 2^(x_max log2e - lse2): good to a few 1e-6 at logits of +-50 -- enough to see a dominant entry, useless to
+        // tell 1 - 1e-7 from 1: that decision is taken from the OTHER entries' mass, vce_combine_kernel)
+        anyhi = __syncthreads_or(pmax > 0.4f);
     }
     bf16x8 hfr[NKS];
     vce_load_hfrag<KD>(a.h, a.ld_h, tok, a.R, hf, hfr);
@@ -341,9 +343,15 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
             // the two lanes of a token share the reference (their P mix in U): lanes l and l + 32 exchange through
             // v_permlane32_swap (one VALU instruction; __shfl_xor is a ds_bpermute: an LDS round trip on the critical path
             // of every tile)
+            // The instruction is written out: through __builtin_amdgcn_permlane32_swap the compiler (ROCm 7.2) keeps the first
+            // result only and drops the max below -- also with an opaque copy as the second operand (round 3 shipped that for a
+            // while: both lanes then carried the LOWER lane's maximum; lse stayed right, but the row maximum, the clip flags
+            // derived from it and, at logit spreads beyond 88, the running sum itself did not; tests/test_gpu_properties.py
+            // found it).
             {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tm), __builtin_bit_cast(unsigned, tm), false, false);
-                tm = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+                float lo_half = tm, hi_half = tm;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo_half), "+v"(hi_half));
+                tm = fmaxf(lo_half, hi_half);      // lanes l < 32: (own, lane l + 32's); lanes l >= 32: (lane l - 32's, own)
             }
             mx = fmaxf(mx, tm);
             const float tm2 = tm * VCE_LOG2E;
@@ -368,15 +376,18 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
         for (int rt = 0; rt < 2; ++rt) {
             __builtin_amdgcn_sched_barrier(0);       // keep one 32-row tile's temporaries live at a time
             float p[16];
-            if (MODE == 2 && anyhi) {                // (block-uniform, rare) a probability above 1 - 1e-7 is clipped as well
+            if (MODE == 2 && anyhi) {
+                // (block-uniform) some row here has a dominant entry, the one probability that may exceed 1 - 1e-7.  Whether it
+                // does is NOT read off its own value (1 - p is below fp32 resolution exactly when it matters): the entry is
+                // counted apart, kept out of Pc / Ud, and the combine kernel decides from the mass of all the others.
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[rt][t], VCE_LOG2E, -e2));
-                    const bool un = __builtin_amdgcn_fmed3f(pv, VCE_EPS, 1.0f - VCE_EPS) == pv;
-                    p[t] = un ? 0.f : pv;
+                    const bool low = pv < VCE_EPS, top = pv > 0.5f;
+                    p[t] = low ? pv : 0.f;
                     Pc += p[t];
-                    nu += un ? 1u : 0u;
-                    nhi += pv > 1.0f - VCE_EPS ? 1u : 0u;      // counted HERE, on the value the test above saw
+                    nu += (low || top) ? 0u : 1u;
+                    nhi += top ? 1u : 0u;
                 }
             } else {
 #pragma unroll
@@ -501,7 +512,7 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
             // the NaN goes out as an integer pattern (it survives any floating-point option the file is compiled with)
             reinterpret_cast<uint32_t *>(a.item_loss)[row] = (y >= a.V) ? 0x7fc00000u : 0u;
             *reinterpret_cast<f32x4 *>(rs) = (f32x4){INFINITY, 0.f, 0.f, -INFINITY};     // lse2 = +inf: p = 0
-            *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){0.f, INFINITY, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         return;
     }
@@ -531,28 +542,39 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
     const float py = __expf(xy - lse);
     const float gs = a.grad_scale[0];
     float loss, invS = 1.f, G = 0.f, yd = 1.f;
+    bool all_out = false;
     if (clipped) {
-        float nu = 0.f, Pc = 0.f, nhi = 0.f;
+        float nu = 0.f, Pc = 0.f, ntop = 0.f;
         for (int p = 0; p < a.parts; ++p) {
             const f32x4 q = *reinterpret_cast<const f32x4 *>(a.sp + ((int64_t)p * a.R + row) * 4);
-            nu += q[0]; Pc += q[1]; nhi += q[2];
+            nu += q[0]; Pc += q[1]; ntop += q[2];
         }
-        const float Pu = 1.0f - Pc;          // the probabilities are normalised by the row's own lse: they sum to 1
-        // S = sum_j clip(p_j): the nu entries inside the range as they are, those above it (at most one) at 1 - 1e-7,
-        // every other entry at 1e-7
-        const float S = Pu + VCE_EPS * ((float)a.V - nu - nhi) + (1.0f - VCE_EPS) * nhi;
-        const float pyc = __builtin_amdgcn_fmed3f(py, VCE_EPS, 1.0f - VCE_EPS);
-        const float uy = (pyc == py) ? 1.f : 0.f;
-        invS = 1.0f / S;
-        yd = uy * py / pyc;
-        G = Pu * invS - yd;
-        loss = logf(S) - logf(pyc);
+        // Does the dominant entry (p > 1/2, if the row has one) exceed 1 - 1e-7?  Exactly when all the OTHER entries together
+        // stay below 1e-7: none of them inside the clip range (each of those alone is >= 1e-7) and the mass Pc of the ones
+        // below it -- a sum of tiny numbers, exact to fp32 rounding -- under 1e-7.  (1 - p itself is not representable
+        // there, and 2^(x log2e - lse2) is off by 1e-6 at logits of +-50: a decision read off p flipped between the kernels.)
+        all_out = ntop > 0.5f && nu < 0.5f && Pc < VCE_EPS;
+        if (all_out) {
+            // every probability is outside the clip range: the loss is a constant of the row, its gradient exactly zero
+            const float S = (1.0f - VCE_EPS) + VCE_EPS * ((float)a.V - 1.0f);
+            loss = logf(S) - logf(py > 0.5f ? 1.0f - VCE_EPS : VCE_EPS);
+            invS = 0.f; yd = 0.f; G = 0.f;
+        } else {
+            const float Pu = 1.0f - Pc;          // the probabilities are normalised by the row's own lse: they sum to 1
+            // S = sum_j clip(p_j): the entries inside the range (the dominant one among them) as they are, every other at 1e-7
+            const float S = Pu + VCE_EPS * ((float)a.V - nu - ntop);
+            const float pyc = fmaxf(py, VCE_EPS);
+            invS = 1.0f / S;
+            yd = (py >= VCE_EPS) ? 1.f : 0.f;    // u_y p_y / clip(p_y)
+            G = Pu * invS - yd;
+            loss = logf(S) - logf(pyc);
+        }
     } else {
         loss = lse - xy;          // -log p_y
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const float v = (U[e] - Ud[e]) * invS - G * U[e] - yd * wy[e];
+        const float v = all_out ? 0.f : (U[e] - Ud[e]) * invS - G * U[e] - yd * wy[e];
         dh[lane * E + e] = (bf16_t)(v * gs);
     }
     if (lane == 0) {
@@ -560,7 +582,7 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
         // dlogit_j = p_j (u_j a - b): inside the clip range [lo, hi] that is p_j c, outside it p_j nb
         const float ra = gs * invS, rb = gs * G;
         *reinterpret_cast<f32x4 *>(rs) = (f32x4){lse2, ra - rb, -rb, clipped ? VCE_EPS : -INFINITY};
-        *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){gs * yd, clipped ? 1.0f - VCE_EPS : INFINITY, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(rs + 4) = (f32x4){gs * yd, all_out ? 1.f : 0.f, 0.f, 0.f};
     }
 }
 
@@ -653,8 +675,8 @@ __global__ void __launch_bounds__(256 * TH, 2) vce_dw_kernel(VceDwArgs a) {
         const f32x4 *rs = sRow + buf * 128;
         const char *rsl = reinterpret_cast<const char *>(rs) + roff;
         fetch(tt + 1, buf ^ 1);        // the other buffer was last read one tile ago (behind the previous barrier)
-        // row scalars {lse2, c = a - b, nb = -b, lo}: lo > 0 marks a row whose probabilities leave the clip range
-        // [lo, 1 - lo] (the upper bound follows from the lower one: rows that stay inside carry lo = -inf)
+        // row scalars {lse2, c = a - b, nb = -b, lo}: lo > 0 marks a row whose probabilities leave the clip range (rows that
+        // stay inside carry lo = -inf)
         const bool any_clip = TH == 2 ? __any(rs[th * 64 + lane][3] > 0.f)      // the wave's token rows
                                       : __any(rs[lane][3] > 0.f || rs[64 + lane][3] > 0.f);
 #pragma unroll
@@ -681,7 +703,9 @@ __global__ void __launch_bounds__(256 * TH, 2) vce_dw_kernel(VceDwArgs a) {
                 for (int t = 0; t < 16; ++t) {
                     const f32x4 s = *reinterpret_cast<const f32x4 *>(rsl + (rt * 32 + (t & 3) + 8 * (t >> 2)) * 16);
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t], VCE_LOG2E, -s[0]));
-                    const bool un = __builtin_amdgcn_fmed3f(p, s[3], 1.0f - s[3]) == p;    // lo = -inf: always inside
+                    // below lo = outside the clip range (lo = -inf: never); the one entry that can be ABOVE the range is the row's
+                    // dominant one, and a row where it is has c = nb = 0 (vce_combine_kernel): nothing to tell apart here
+                    const bool un = p >= s[3];
                     gv[t] = p * (un ? s[1] : s[2]);
                     dbv += gv[t];
                 }

@@ -297,3 +297,51 @@ def test_varlen_attention_random_ragged_batches(ops, seed, B, smax, H, dh, with_
     dqkv = ops.attn_bwd(qkv.cuda(), key_pad, o, do.cuda(), lse, B, S_max, H, dh, cu)
     assert err(dqkv, q64.grad) < 2.5e-2
     assert torch.equal(ops.attn_bwd(qkv.cuda(), key_pad, o, do.cuda(), lse, B, S_max, H, dh, cu), dqkv)     # run-to-run identical
+
+
+@settings(**dict(SET, max_examples=30))
+@given(seed=st.integers(0, 2 ** 31 - 1), R=st.integers(1, 400), V=st.integers(8, 2500), K=st.sampled_from([64, 128]),
+       scale=st.sampled_from([0.2, 0.8, 1.6, 2.5]), p_ign=st.sampled_from([0.0, 0.1, 1.0]), variant=st.sampled_from(['tf', 'tf', 'plain']),
+       confident=st.booleans())
+def test_logits_free_softmax_ce_any_shape_and_clip_regime(ops, seed, R, V, K, scale, p_ign, variant, confident):
+    """R12 - R14 without the logits in memory (csrc/vocab_ce.hip) against the fp64 restatement of softmax -> TF's clipped sparse
+    CE (losses.py:31-98): random R / V / K, operand scales from "nothing clipped" to "almost everything below 1e-7", rows that
+    are confidently right or wrong (a probability above 1 - 1e-7), ignored rows up to all of them.  Bounds of
+    tests/test_gpu_vocab_ce.py: loss items 2e-4, gradients 1 % L2 (bf16 P in front of the matrix cores)."""
+    from bert4clickpath_amd import _lib as L
+    from test_gpu_vocab_ce import _case, _oracle
+    h, W, b, y = _case(R, V, K, scale, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    if confident:                                   # a few rows point hard at one vocabulary row: the label or another one
+        for r in rng.choice(R, min(R, 4), replace=False):
+            j = int(rng.integers(0, V))
+            h[r] = torch.from_numpy((W[j] * 6.0 / max(np.linalg.norm(W[j]) ** 2, 1e-3) * 8.0).astype(np.float32)).bfloat16().float().numpy()
+            if rng.random() < 0.5:
+                y[r] = j
+    y[rng.random(R) < p_ign] = -1
+    item_o, loss_o, dh_o, dW_o, db_o = _oracle(h, W, b, y, variant)
+    hd = torch.tensor(h, device='cuda').bfloat16()
+    Vp = (V + 7) // 8 * 8
+    wt = torch.zeros(Vp, K, device='cuda', dtype=torch.bfloat16)
+    wt[:V] = torch.tensor(W, device='cuda').bfloat16()
+    bd = torch.zeros(Vp, device='cuda')
+    bd[:V] = torch.tensor(b, device='cuda')
+    yd = torch.tensor(y, device='cuda')
+    n = max(int((y >= 0).sum()), 1)
+    gs = torch.tensor([1.0 / n], device='cuda')
+    item, dh, rowscal = ops.vocab_ce_fwd(hd, wt, bd, yd, gs, V, L.CE_TF if variant == 'tf' else L.CE_PLAIN)
+    dW = torch.zeros(K, V, device='cuda')
+    db = torch.zeros(V, device='cuda')
+    ops.vocab_ce_dw(hd, wt, bd, yd, rowscal, V, dW, db)
+    item = item.cpu().numpy()
+    np.testing.assert_allclose(item, item_o, rtol=2e-4, atol=2e-4)
+
+    def rel(a, ref, floor):
+        return np.linalg.norm(a - ref) / max(np.linalg.norm(ref), floor)
+    g = 1.0 / n
+    assert rel(dh.float().cpu().numpy(), dh_o, 1e-3 * g * np.sqrt(R) * np.linalg.norm(W, axis=1).mean()) < 1e-2
+    assert rel(dW.cpu().numpy(), dW_o.T, 1e-3 * g * np.linalg.norm(h)) < 1e-2
+    assert rel(db.cpu().numpy(), db_o, 1e-3 * g * np.sqrt(R)) < 1e-2
+    ign = y < 0
+    if ign.any():
+        assert np.all(item[ign] == 0) and np.all(dh.float().cpu().numpy()[ign] == 0)
