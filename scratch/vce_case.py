@@ -27,4 +27,15 @@ ops.vocab_ce_dw(hd, wt, bd, yd, rowscal, V, dW, db)
 print('item', item.cpu().numpy(), 'oracle', item_o)
 print('rowscal', rowscal.cpu().numpy())
 print('db', db.cpu().numpy(), 'oracle', db_o)
+print('p (fp64)', p)
+print('dW err per column', np.abs(dW.cpu().numpy() - dW_o.T).max(0), 'dW oracle column norms', np.abs(dW_o.T).max(0))
 print('|dh|', float(dh.float().norm()), 'oracle', np.linalg.norm(dh_o))
+
+dhk = dh.float().cpu().numpy()
+err = np.linalg.norm(dhk - dh_o, axis=1)
+print('dh: total rel err %.4f' % (np.linalg.norm(dhk - dh_o) / max(np.linalg.norm(dh_o), 1e-30)))
+rs = rowscal.cpu().numpy()
+for r in np.argsort(-err)[:6]:
+    pr = np.sort(p[r])[::-1]
+    print('  row %d err %.3e |dh_o| %.3e |dh| %.3e label %d p_label %.3e top3 %s n_in_range %d all_out %d c %.3e nb %.3e' % (
+        r, err[r], np.linalg.norm(dh_o[r]), np.linalg.norm(dhk[r]), y[r], p[r, y[r]], pr[:3], int(((p[r] >= 1e-7) & (p[r] <= 1 - 1e-7)).sum()), rs[r, 5], rs[r, 1], rs[r, 2]))
