@@ -369,3 +369,143 @@ def test_the_256_token_sweeps_pass_the_same_property_tests():
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert '2 passed' in r.stdout, r.stdout[-500:]
+
+
+@settings(**dict(SET, max_examples=25))
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 12), smax=st.integers(1, 260), mmax=st.integers(1, 40), H=st.sampled_from([1, 2, 4]),
+       dh=st.sampled_from([32, 64]), dtype=st.sampled_from(['f32', 'bf16']), pad=st.booleans())
+def test_masked_query_attention_random_ragged_batches(ops, seed, B, smax, mmax, H, dh, dtype, pad):
+    """The last layer's attention for the [MASK] rows only (transformer.py:64-97 for those rows; clickstream_transformer.py:
+    281-295 keeps nothing else): random sequence lengths and query counts (sequences without a query included), optional
+    padded keys, against fp64 -- the bounds of tests/test_gpu_mq.py."""
+    from test_gpu_mq import _ref
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, smax + 1, (B,), generator=g)
+    nq = torch.randint(0, mmax + 1, (B,), generator=g)
+    if int(nq.sum()) == 0:
+        nq[0] = 1
+    cu = torch.zeros(B + 1, dtype=torch.int32); cu[1:] = torch.cumsum(lens, 0)          # noqa: E702
+    moff = torch.zeros(B + 1, dtype=torch.int32); moff[1:] = torch.cumsum(nq, 0)        # noqa: E702
+    T, R, d = int(cu[-1]), int(moff[-1]), H * dh
+    q = (torch.randn(R, d, generator=g) * 0.8).to(dt)
+    kv = (torch.randn(T, 2 * d, generator=g) * 0.8).to(dt)
+    go = torch.randn(R, d, generator=g).to(dt)
+    key_pad = None
+    if pad:
+        key_pad = (torch.rand(T, generator=g) < 0.15).to(torch.uint8)
+        key_pad[cu[:-1].long()] = 0                      # every sequence keeps a live key
+    ro, rl, rdq, rdkv = _ref(cu, moff, q, kv, go, H, dh, key_pad)
+    kp = key_pad.cuda() if key_pad is not None else None
+    S_max = int(lens.max())
+    o, lse = ops.attn_mq_fwd(q.cuda(), kv.cuda(), cu.cuda(), moff.cuda(), B, S_max, H, dh, kp)
+    tol = 2e-5 if dt == torch.float32 else 1.5e-2
+    assert float((o.double().cpu() - ro).abs().max()) < tol * max(1.0, float(ro.abs().max()))
+    assert float((lse.double().cpu() - rl).abs().max()) < (1e-4 if dt == torch.float32 else 2e-2)
+    dq, dkv = ops.attn_mq_bwd(q.cuda(), kv.cuda(), cu.cuda(), moff.cuda(), o, go.cuda(), lse, B, S_max, H, dh, kp)
+    btol = 1e-4 if dt == torch.float32 else 3e-2
+    assert float((dq.double().cpu() - rdq).abs().max()) < btol * max(1.0, float(rdq.abs().max()))
+    assert float((dkv.double().cpu() - rdkv).abs().max()) < btol * max(1.0, float(rdkv.abs().max()))
+    for b in range(B):
+        if nq[b] == 0:
+            assert float(dkv[int(cu[b]):int(cu[b + 1])].abs().max()) == 0.0
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), rows=st.integers(1, 500), d8=st.integers(1, 128), rate=st.sampled_from([0.0, 0.1, 0.5]),
+       dtype=st.sampled_from(['f32', 'bf16']))
+def test_add_dropout_layernorm_any_width(ops, seed, rows, d8, rate, dtype):
+    """LN(x + dropout(y)) (transformer.py:183-187, 204-206) and its backward for any row count and any width that is a multiple
+    of 8 up to 1024, with the keep mask regenerated on the host (ops.keep_mask); bounds of tests/test_gpu_kernels.py."""
+    d = 8 * d8
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    g = torch.Generator().manual_seed(seed)
+    x, y = torch.randn(rows, d, generator=g), torch.randn(rows, d, generator=g) * 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    dout = torch.randn(rows, d, generator=g)
+    xd, yd, dod = x.cuda().to(dt), y.cuda().to(dt), dout.cuda().to(dt)
+    z, out, stats = ops.add_dropout_layernorm_fwd(xd, yd, gamma.cuda(), beta.cuda(), rate, seed)
+    keep = torch.from_numpy(ops.keep_mask(seed, rows * d, rate).reshape(rows, d)) if rate > 0 else torch.ones(rows, d, dtype=torch.bool)
+    x64, y64 = xd.double().cpu(), yd.double().cpu()
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    z64 = x64 + y64 * keep / (1 - rate)
+
+    def ln(zz):
+        mean = zz.mean(-1, keepdim=True)
+        var = ((zz - mean) ** 2).mean(-1, keepdim=True)
+        return (zz - mean) * torch.rsqrt(var + 1e-6) * g64 + b64
+    err = lambda a, r: float((a.double().cpu() - r).norm() / max(float(r.norm()), 1e-30))      # noqa: E731
+    tol = 1e-5 if dt == torch.float32 else 1.2e-2
+    assert err(z, z64) < tol and err(out, ln(z64).detach()) < tol
+    zs = z.double().cpu().requires_grad_(True)            # the kernel recomputes xhat from the z it saved
+    ln(zs).backward(dod.double().cpu())
+    dz, dy, dgamma, dbeta = ops.add_dropout_layernorm_bwd(dod, z, stats, gamma.cuda(), rate, seed)
+    btol = 2e-4 if dt == torch.float32 else 1.5e-2
+    assert err(dz, zs.grad) < btol and err(dy, zs.grad * keep / (1 - rate)) < btol
+    # sums over the rows: relative to the size of the terms that are added (a column of dgamma may cancel to ~0)
+    scale_g = float((dod.double().cpu().abs() * 3).sum(0).max())
+    assert float((dgamma.double().cpu() - g64.grad).abs().max()) < btol * max(scale_g, 1.0)
+    assert float((dbeta.double().cpu() - b64.grad).abs().max()) < btol * max(scale_g, 1.0)
+
+
+@settings(**dict(SET, max_examples=30))
+@given(seed=st.integers(0, 2 ** 31 - 1), M=st.integers(1, 600), N=st.sampled_from([64, 128, 256]), K8=st.integers(1, 33), rate=st.sampled_from([0.0, 0.2]))
+def test_gemm_with_layernorm_epilogue_is_the_two_kernels(ops, seed, M, N, K8, rate):
+    """b4c_gemm_nt_add_ln (the out-projection / FFN2 GEMM with residual + dropout + LayerNorm in its epilogue) against
+    b4c_gemm_nt followed by b4c_add_dropout_layernorm_fwd: bit for bit, any M, any K."""
+    K = 8 * K8
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda()
+    bt = (torch.randn(N, K, generator=g) * 0.2).bfloat16().cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    x = torch.randn(M, N, generator=g).bfloat16().cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(N, generator=g)).cuda(), (0.1 * torch.randn(N, generator=g)).cuda()
+    if not ops.gemm_ln_supported(a, N):
+        return
+    z1, o1, s1 = ops.gemm_nt_add_ln(a, bt, bias, x, gamma, beta, rate, seed)
+    y = ops.gemm_nt(a, bt, N, bias)
+    z2, o2, s2 = ops.add_dropout_layernorm_fwd(x, y, gamma, beta, rate, seed)
+    assert torch.equal(z1, z2) and torch.equal(o1, o2) and torch.equal(s1, s2)
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 40), S=st.integers(1, 150), n_feat=st.integers(1, 3), d8=st.integers(1, 16),
+       combine=st.sampled_from(['concat', 'sum']), rate=st.sampled_from([0.0, 0.25]), dtype=st.sampled_from(['f32', 'bf16']))
+def test_embedding_stage_any_shape(ops, seed, B, S, n_feat, d8, combine, rate, dtype):
+    """Per-feature gather -> concat (transformer.py:384-388) or sum (extension) -> * sqrt(d) -> + PE -> input dropout (:263),
+    and the scatter-add of its gradient into the tables (both the atomic and the sorted kernel, by token count), against numpy."""
+    from bert4clickpath_amd.clickstream_transformer.transformer import positional_encoding
+    if combine == 'sum' and n_feat < 2:
+        n_feat = 2
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    rng = np.random.default_rng(seed)
+    dims = [8 * d8] * n_feat if combine == 'sum' else [8 * int(rng.integers(1, d8 + 1)) for _ in range(n_feat)]
+    d = dims[0] if combine == 'sum' else sum(dims)
+    rows = [int(rng.integers(2, 300)) for _ in range(n_feat)]
+    ids = [rng.integers(-2, r + 2, (B, S)).astype(np.int64) for r in rows]            # out-of-range ids are clamped
+    ids[0][rng.random((B, S)) < 0.2] = 0                                              # pads (the first feature defines the mask)
+    tables = [rng.standard_normal((r, w)).astype(np.float32) for r, w in zip(rows, dims)]
+    pe = positional_encoding(max(S, 2), d)[0].cuda()
+    scale = float(np.sqrt(np.float32(d)))
+    ids_t = [torch.from_numpy(i).cuda() for i in ids]
+    tab_t = [torch.from_numpy(t).cuda() for t in tables]
+    out, key_pad = ops.embed_concat_pe_fwd(ids_t, tab_t, pe, scale, rate, seed, dt, combine=combine)
+    parts = [t[np.clip(i, 0, t.shape[0] - 1)].astype(np.float64) for t, i in zip(tables, ids)]
+    x = sum(parts[1:], parts[0]) if combine == 'sum' else np.concatenate(parts, -1)
+    want = x * scale + pe[:S].double().cpu().numpy()[None]
+    keep = ops.keep_mask(seed, B * S * d, rate).reshape(B, S, d) if rate > 0 else np.ones((B, S, d), bool)
+    want = np.where(keep, want / (1 - rate), 0.0)
+    tol = 3e-6 if dt == torch.float32 else 8e-3
+    assert float(np.abs(out.double().cpu().numpy() - want).max()) < tol * max(1.0, float(np.abs(want).max()))
+    assert np.array_equal(key_pad.cpu().numpy(), (ids[0] == 0).astype(np.uint8))
+    dout = torch.from_numpy(rng.standard_normal((B, S, d)).astype(np.float32)).cuda().to(dt)
+    got = ops.embed_concat_pe_bwd(ids_t, tab_t, dout, scale, rate, seed)
+    gflat = (dout.double().cpu().numpy() * keep / (1 - rate) * scale).reshape(-1, d)
+    off = 0
+    for f in range(n_feat):
+        w = dims[f]
+        cols = slice(0, d) if combine == 'sum' else slice(off, off + w)
+        ref = np.zeros((rows[f], w))
+        np.add.at(ref, np.clip(ids[f], 0, rows[f] - 1).reshape(-1), gflat[:, cols])
+        assert float(np.abs(got[f].double().cpu().numpy() - ref).max()) < 3e-5 * max(1.0, float(np.abs(ref).max())), f
+        off += w
