@@ -1843,6 +1843,11 @@ def compact_labels(labels_padded, counts, offsets, cap, flat_idx=None):
     B, M = labels_padded.shape
     lab = labels_padded.to(torch.float32).contiguous()
     out = torch.empty(cap, dtype=torch.int32, device=lab.device)
+    if M == 0:          # a batch whose label rows are all empty (padded_batch of zero-length arrays, input_pipeline.py:198-214)
+        out.fill_(-1)
+        if flat_idx is not None:
+            flat_idx.fill_(-1)
+        return out
     L.check(L.lib().b4c_compact_labels(_p(lab), B, M, _p(counts), _p(offsets), _p(out), _p(flat_idx), cap, _st()),
             'compact_labels')
     return out

@@ -509,3 +509,58 @@ def test_embedding_stage_any_shape(ops, seed, B, S, n_feat, d8, combine, rate, d
         np.add.at(ref, np.clip(ids[f], 0, rows[f] - 1).reshape(-1), gflat[:, cols])
         assert float(np.abs(got[f].double().cpu().numpy() - ref).max()) < 3e-5 * max(1.0, float(np.abs(ref).max())), f
         off += w
+
+
+@settings(**dict(SET, max_examples=12))
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 7), S=st.integers(6, 70), L=st.integers(1, 3), H=st.sampled_from([1, 2, 4]),
+       dh=st.sampled_from([16, 32, 64]), V=st.integers(12, 400), trunk=st.sampled_from([(16,), (32, 16), (8, 24, 16)]),
+       two=st.sampled_from(['one', 'concat', 'sum']), packed=st.booleans())
+def test_whole_model_random_configurations_fp32(ops, seed, B, S, L, H, dh, V, trunk, two, packed):
+    """ClickstreamTransformer + SoftMaxHead at randomly drawn sizes (layers, heads, head depth, sequence length, vocabulary, head
+    trunk, one / two concatenated / two summed features), fp32: probabilities (1e-6), Cloze loss (1e-5) and every gradient
+    (2e-4 of the tensor's largest entry) against the fp64 restatement of the reference dataflow.  (Head depths 16 / 32 / 64: the
+    attention kernels take {16, 32, 64, 128} and refuse anything else with an error.)"""
+    from bert4clickpath_amd import input_pipeline
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    from oracle import torch_ref as tr
+    d = H * dh
+    Va = 11
+    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=seed % 100000, min_len=1, n_extra_features=0 if two == 'one' else 1, extra_vocab=Va)
+    torch.manual_seed(seed % 1000)
+    chains, vocabs = {'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}
+    if two == 'one':
+        dims = {'items': d}
+    else:
+        chains['actions'], vocabs['actions'] = ['act'], ['a%d' % i for i in range(Va)]
+        dims = {'items': d, 'actions': d} if two == 'sum' else {'items': d - 8, 'actions': 8}
+    m = ClickstreamTransformer(chains, vocabs, dims, SoftMaxHead(list(trunk), V), value_to_head='[MASK]', num_encoder_layers=L,
+                               num_attention_heads=H, dropout_rate=0.0, feature_combine='sum' if two == 'sum' else 'concat').cuda()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith('bias') or n.endswith('beta'):
+                p.normal_(0, 0.05)
+    ids = torch.from_numpy(b['ids']).cuda()
+    feats = {'asin': ids[:, 2:S - 1].contiguous()}
+    extra = None
+    if two != 'one':
+        acts = torch.from_numpy(b['extra'][0]).cuda()
+        feats['act'] = acts[:, 2:S - 1].contiguous()
+        extra = {'actions': acts.cpu()}
+    labels = torch.from_numpy(b['labels_padded']).cuda()
+    P = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in m.state_dict().items() if 'pos_encoding' not in k}
+    ref, rprobs = tr.model_loss(ids.cpu(), torch.from_numpy(b['labels']).long(), P, L, H, len(trunk), extra_features=extra,
+                                combine='sum' if two == 'sum' else 'concat')
+    ref.backward()
+    probs = m(feats, training=False)
+    if labels.numel():
+        got = probs.reshape(-1, V)[labels.reshape(-1) != -1]
+        assert float((got.detach().cpu().double() - rprobs.detach()).abs().max()) < 1e-6
+    kw = dict(max_masked_per_row=10, n_real_tokens=int((b['ids'] != 0).sum())) if packed else {}
+    loss = m.cloze_loss(feats, labels, training=True, **kw)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    for n, p in m.named_parameters():
+        gr = P[n].grad
+        if gr is None or float(gr.abs().max()) < 1e-9:
+            continue
+        assert float((p.grad.cpu().double() - gr).abs().max()) < 2e-4 * float(gr.abs().max()), n
