@@ -585,3 +585,111 @@ def test_whole_model_random_configurations_fp32(ops, seed, B, S, L, H, dh, V, tr
                 if gr is None or float(gr.norm()) < 0.05 * gmax:
                     continue
                 assert float((p.grad.cpu().double() - gr).norm() / gr.norm()) < 0.3, n
+
+
+@settings(**dict(SET, max_examples=25))
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 6), S=st.integers(1, 300), H=st.sampled_from([1, 2, 3, 4]), dh=st.sampled_from([16, 32, 64, 128]),
+       dtype=st.sampled_from(['f32', 'bf16']), pad_mode=st.sampled_from(['none', 'tails', 'random']))
+def test_padded_layout_attention_any_shape(ops, seed, B, S, H, dh, dtype, pad_mode):
+    """scaled_dot_product_attention with the reference's key-side padding mask (transformer.py:38-41, 90-91: logits += mask * -1e9)
+    on the padded (B, S) layout: forward, lse and backward against fp64; padded keys get exactly zero dK / dV.  Every sequence
+    keeps a live key, as every sequence the model builds does ([CLS] is never a pad, clickstream_transformer.py:38-63); a
+    sequence of pads only is ill-defined in the reference itself (in fp32, x - 1e9 == -1e9 for every |x| < 32: TF attends
+    uniformly there, exact arithmetic would attend as if nothing were masked) and is not part of the contract."""
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    g = torch.Generator().manual_seed(seed)
+    d = H * dh
+    qkv = torch.randn(B * S, 3 * d, generator=g) * 0.8
+    pad = torch.zeros(B, S, dtype=torch.uint8)
+    if pad_mode == 'tails':
+        lens = torch.randint(1, S + 1, (B,), generator=g)
+        pad = (torch.arange(S)[None, :] >= lens[:, None]).to(torch.uint8)
+    elif pad_mode == 'random':
+        pad = (torch.rand(B, S, generator=g) < 0.3).to(torch.uint8)
+        pad[:, 0] = 0
+    qd = qkv.cuda().to(dt)
+    o, lse = ops.attn_fwd(qd, pad.cuda(), B, S, H, dh)
+    q64 = qd.double().cpu().requires_grad_(True)
+    q, k, v = [q64[:, i * d:(i + 1) * d].reshape(B, S, H, dh).permute(0, 2, 1, 3) for i in range(3)]
+    logits = q @ k.transpose(-1, -2) / float(np.sqrt(np.float32(dh))) + pad[:, None, None, :].double() * -1e9
+    o_ref = (torch.softmax(logits, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, d)
+    lse_ref = torch.logsumexp(logits, -1)
+    err = lambda a, r: float((a.double().cpu() - r).norm() / max(float(r.norm()), 1e-30))      # noqa: E731
+    assert err(o, o_ref.detach()) < (2e-5 if dt == torch.float32 else 1.2e-2)
+    live = (pad.sum(1) < S)                                   # (lse of an all-pad sequence sits at -1e9: compared relatively)
+    for b in range(B):
+        tol = (1e-4 if dt == torch.float32 else 3e-2) if bool(live[b]) else 1e-6 * 1e9
+        assert float((lse[b].double().cpu() - lse_ref[b].detach()).abs().max()) < tol
+    do = torch.randn(B * S, d, generator=g).cuda().to(dt)
+    o_ref.backward(do.double().cpu())
+    dqkv = ops.attn_bwd(qd, pad.cuda(), o, do, lse, B, S, H, dh)
+    assert err(dqkv, q64.grad) < (1e-4 if dt == torch.float32 else 2.5e-2)
+    kv_grad = dqkv[:, d:].reshape(B, S, 2 * d).float().cpu()
+    for b in range(B):
+        if bool(live[b]) and int(pad[b].sum()):
+            assert float(kv_grad[b][pad[b].bool()].abs().max()) == 0.0
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(1, 20000), steps=st.integers(1, 4), grad_mul=st.sampled_from([1.0, 0.125]))
+def test_adam_any_length(ops, seed, n, steps, grad_mul):
+    """Keras Adam(1e-3, 0.9, 0.999, 1e-9) (main.py:87; the bias correction folded into lr_t) on a flat arena of any length
+    (vector tail included), several steps, against the fp64 restatement; grad_mul = the 1 / N of a data-parallel mean."""
+    import math
+    rng = np.random.default_rng(seed)
+    p, gr = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    pd, gd = torch.from_numpy(p).cuda(), torch.from_numpy(gr).cuda()
+    md, vd = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    pr, mr, vr = p.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in range(1, steps + 1):
+        lr_t = 1e-3 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.adam_step_(pd, gd, md, vd, lr_t, 0.9, 0.999, 1e-9, grad_mul)
+        pr, mr, vr = nr.adam_step(pr, gr.astype(np.float64) * grad_mul, mr, vr, t)
+    assert float(np.abs(pd.cpu().numpy() - pr).max()) < 2e-6
+    assert float(np.abs(md.cpu().numpy() - mr).max()) < 1e-6 * max(1.0, float(np.abs(mr).max()))
+    assert float(np.abs(vd.cpu().numpy() - vr).max()) < 1e-6 * max(1.0, float(np.abs(vr).max()))
+
+
+@settings(**dict(SET, max_examples=20))
+@given(seed=st.integers(0, 2 ** 31 - 1), R=st.integers(1, 500), V=st.integers(8, 3000), K=st.sampled_from([64, 128]), cut=st.floats(0.0, 1.0))
+def test_projection_gradient_in_pieces_and_in_fixed_order(ops, seed, R, V, K, cut):
+    """The vocabulary head's dW / db: the whole sweep, the sweep in two vocabulary pieces + the label term (what the background
+    form launches) and the fixed-order form give the same gradient (float-atomic noise apart), and the fixed-order form gives
+    the same BITS twice."""
+    from bert4clickpath_amd import _lib as L
+    from test_gpu_vocab_ce import _case
+    h, W, b, y = _case(R, V, K, 0.9, seed=seed, n_ignored=R // 10)
+    hd = torch.tensor(h, device='cuda').bfloat16()
+    Vp = (V + 7) // 8 * 8
+    wt = torch.zeros(Vp, K, device='cuda', dtype=torch.bfloat16)
+    wt[:V] = torch.tensor(W, device='cuda').bfloat16()
+    bd = torch.zeros(Vp, device='cuda')
+    bd[:V] = torch.tensor(b, device='cuda')
+    yd = torch.tensor(y, device='cuda')
+    gs = torch.tensor([1.0 / max(int((y >= 0).sum()), 1)], device='cuda')
+    item, dh, rowscal = ops.vocab_ce_fwd(hd, wt, bd, yd, gs, V, L.CE_TF)
+
+    def grads(det, pieces):
+        prev = ops.deterministic_vocab_dw
+        ops.deterministic_vocab_dw = det
+        try:
+            dW, db = torch.zeros(K, V, device='cuda'), torch.zeros(V, device='cuda')
+            if pieces:
+                nt = (V + 127) // 128
+                c = min(nt, int(round(cut * nt)))
+                ops.vocab_ce_dw_sweep(hd, wt, bd, rowscal, V, dW, db, 0, c)
+                ops.vocab_ce_dw_sweep(hd, wt, bd, rowscal, V, dW, db, c, nt)
+                ops.vocab_ce_dw_labels(hd, yd, rowscal, V, dW, db)
+            else:
+                ops.vocab_ce_dw(hd, wt, bd, yd, rowscal, V, dW, db)
+            return dW, db
+        finally:
+            ops.deterministic_vocab_dw = prev
+    a_w, a_b = grads(False, False)
+    p_w, p_b = grads(False, True)
+    d_w, d_b = grads(True, False)
+    d2_w, d2_b = grads(True, False)
+    scale = float(a_w.abs().max()) + 1e-12
+    assert float((a_w - p_w).abs().max()) < 1e-5 * scale + 1e-9 and float((a_b - p_b).abs().max()) < 1e-5 * (float(a_b.abs().max()) + 1e-12) + 1e-9
+    assert float((a_w - d_w).abs().max()) < 1e-5 * scale + 1e-9 and float((a_b - d_b).abs().max()) < 1e-5 * (float(a_b.abs().max()) + 1e-12) + 1e-9
+    assert torch.equal(d_w, d2_w) and torch.equal(d_b, d2_b)
