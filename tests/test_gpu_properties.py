@@ -12,8 +12,11 @@ pytestmark = pytest.mark.gpu
 
 from oracle import numpy_ref as nr  # noqa: E402
 
-SET = dict(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture,
-                                                                   HealthCheck.data_too_large])
+# derandomize: the examples are a fixed function of each test's source, the same on every box and run (the exploration with
+# other seeds -- `--hypothesis-seed=N`, some 2,000 cases while these tests were written -- is what found the defects noted in
+# DESIGN.md section 8; the committed suite must not turn red on a draw nobody has seen)
+SET = dict(max_examples=40, deadline=None, derandomize=True, database=None,
+           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture, HealthCheck.data_too_large])
 
 
 @pytest.fixture(scope='module')
