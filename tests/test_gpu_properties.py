@@ -15,7 +15,9 @@ from oracle import numpy_ref as nr  # noqa: E402
 # derandomize: the examples are a fixed function of each test's source, the same on every box and run (the exploration with
 # other seeds -- `--hypothesis-seed=N`, some 2,000 cases while these tests were written -- is what found the defects noted in
 # DESIGN.md section 8; the committed suite must not turn red on a draw nobody has seen)
-SET = dict(max_examples=40, deadline=None, derandomize=True, database=None,
+import os as _os
+# B4C_EXPLORE=1: fresh draws (combine with --hypothesis-seed=N) instead of the fixed set
+SET = dict(max_examples=40, deadline=None, derandomize=not _os.environ.get('B4C_EXPLORE'), database=None,
            suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture, HealthCheck.data_too_large])
 
 
