@@ -698,3 +698,56 @@ def test_projection_gradient_in_pieces_and_in_fixed_order(ops, seed, R, V, K, cu
     assert float((a_w - p_w).abs().max()) < 1e-5 * scale + 1e-9 and float((a_b - p_b).abs().max()) < 1e-5 * (float(a_b.abs().max()) + 1e-12) + 1e-9
     assert float((a_w - d_w).abs().max()) < 1e-5 * scale + 1e-9 and float((a_b - d_b).abs().max()) < 1e-5 * (float(a_b.abs().max()) + 1e-12) + 1e-9
     assert torch.equal(d_w, d2_w) and torch.equal(d_b, d2_b)
+
+
+@settings(**dict(SET, max_examples=30))
+@given(seed=st.integers(0, 2 ** 31 - 1), R=st.integers(1, 40), V=st.integers(1, 9000), spread=st.sampled_from([0.5, 3.0, 12.0]),
+       dtype=st.sampled_from(['f32', 'bf16']), variant=st.sampled_from([0, 1]), p_ign=st.sampled_from([0.0, 0.3]))
+def test_materialised_softmax_and_ce_any_width(ops, seed, R, V, spread, dtype, variant, p_ign):
+    """The reference composition on MATERIALISED scores (head.py:36 softmax; losses.py:31-98 TF's clipped sparse CE on probabilities;
+    variant 1 = plain -log p): softmax rows, the item losses from probabilities, and the fused loss + d / d logits, for any row
+    width (V = 1 included), logit spreads that put nothing / much / nearly everything outside the clip range, ignored rows."""
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    g = torch.Generator().manual_seed(seed)
+    ld = (V + 7) // 8 * 8
+    logits = torch.zeros(R, ld)
+    logits[:, :V] = torch.randn(R, V, generator=g) * spread
+    x = logits.cuda().to(dt)
+    probs = ops.softmax_rows(x, V)
+    p64 = torch.softmax(x.double().cpu()[:, :V], -1)
+    assert float((probs[:, :V].double().cpu() - p64).abs().max()) < (1e-6 if dt == torch.float32 else 4e-3)
+    assert float(probs[:, V:].abs().sum()) == 0
+    labels = torch.randint(0, V, (R,), generator=g)
+    ign = torch.rand(R, generator=g) < p_ign
+    labf = labels.float()
+    labf[ign] = -1.0
+    item, nval = ops.sparse_ce_from_probs(probs, labf.cuda(), V, variant)
+    want = nr.sparse_categorical_crossentropy(labels.numpy(), probs[:, :V].double().cpu().numpy(), 'tf' if variant == 0 else 'plain')
+    want[ign.numpy()] = 0.0
+    assert int(nval) == int((~ign).sum())
+    got = item.double().cpu().numpy()
+    fin = np.isfinite(want)                                     # (plain variant: -log 0 = inf where the fp32 probability underflowed)
+    assert np.array_equal(np.isfinite(got), fin)
+    assert float(np.abs(got[fin] - want[fin]).max(initial=0.0)) < (2e-5 if dt == torch.float32 else 2e-2)
+    # fused loss + gradient w.r.t. the logits
+    x64 = x.double().cpu()[:, :V].clone().requires_grad_(True)
+    p = torch.softmax(x64, -1)
+    if variant == 0:
+        lg = torch.log(torch.clamp(p, 1e-7, 1 - 1e-7))
+        item64 = torch.logsumexp(lg, -1) - lg.gather(1, labels[:, None])[:, 0]
+    else:
+        item64 = -torch.log_softmax(x64, -1).gather(1, labels[:, None])[:, 0]
+    valid = ~ign
+    n = max(int(valid.sum()), 1)
+    if int(valid.sum()):
+        (item64[valid].sum() / n).backward()
+    work = x.clone()
+    lab32 = labels.int().clone()
+    lab32[ign] = -1
+    it2 = ops.softmax_ce_fwd_bwd_(work, lab32.cuda(), torch.tensor([1.0 / n], device='cuda'), V, variant)
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    if int(valid.sum()):
+        assert float((it2.double().cpu()[valid] - item64.detach()[valid]).abs().max()) < tol * max(1.0, float(item64.detach()[valid].abs().max()))
+        gref = x64.grad
+        assert float((work[:, :V].double().cpu() - gref).norm()) < (2e-5 if dt == torch.float32 else 1.5e-2) * max(float(gref.norm()), 1e-2 / n) + (5e-7 if dt == torch.float32 else 2.0 ** -9) / n * np.sqrt(R)      # (absolute side: a row whose true gradient is 0 -- everything clipped -- carries the rounding noise of its O(1 / n) terms)
+    assert float(it2[ign.cuda()].abs().sum()) == 0.0 and float(work[ign.cuda()].abs().sum()) == 0.0 and float(work[:, V:].abs().sum()) == 0.0
