@@ -751,3 +751,58 @@ def test_materialised_softmax_and_ce_any_width(ops, seed, R, V, spread, dtype, v
         gref = x64.grad
         assert float((work[:, :V].double().cpu() - gref).norm()) < (2e-5 if dt == torch.float32 else 1.5e-2) * max(float(gref.norm()), 1e-2 / n) + (5e-7 if dt == torch.float32 else 2.0 ** -9) / n * np.sqrt(R)      # (absolute side: a row whose true gradient is 0 -- everything clipped -- carries the rounding noise of its O(1 / n) terms)
     assert float(it2[ign.cuda()].abs().sum()) == 0.0 and float(work[ign.cuda()].abs().sum()) == 0.0 and float(work[:, V:].abs().sum()) == 0.0
+
+
+@settings(**dict(SET, max_examples=20))
+@given(seed=st.integers(0, 2 ** 31 - 1), V=st.integers(20, 6000), K8=st.integers(1, 16), R=st.integers(1, 120), Ns=st.integers(1, 50),
+       p_ign=st.sampled_from([0.0, 0.2]), dtype=st.sampled_from(['f32', 'bf16']))
+def test_sampled_softmax_head_any_shape(ops, seed, V, K8, R, Ns, p_ign, dtype):
+    """SampledSoftmaxHead (north-star extension, NO REFERENCE ORACLE: checked against this repo's fp64 restatement of
+    tf.nn.sampled_softmax_loss with a log-uniform sampler, logQ correction and accidental-hit removal): loss and gradients w.r.t.
+    the input rows and every parameter at random vocabulary / width / row / sample counts; the projection gradient is row-sparse."""
+    from bert4clickpath_amd.clickstream_transformer import SampledSoftmaxHead
+    from oracle import torch_ref as tr
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    Kd, Ns = 8 * K8, 8 * Ns                              # (the head asks for a multiple of 8 negatives)
+    torch.manual_seed(seed % 100003)
+    head = SampledSoftmaxHead([24, Kd], V, num_sampled=Ns, input_dim=16).cuda()
+    with torch.no_grad():
+        head.output_bias.normal_(0, 0.3)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(R, 16, generator=g).cuda().to(dt).requires_grad_(True)
+    labels = torch.randint(0, V, (R,), generator=g, dtype=torch.int32)
+    labels[torch.rand(R, generator=g) < 0.3] = torch.randint(0, min(V, 4), (1,), generator=g, dtype=torch.int32)    # frequent ids: hits among the negatives
+    labels[torch.rand(R, generator=g) < p_ign] = -1
+    keep = labels >= 0
+    if not bool(keep.any()):
+        labels[0], keep[0] = 0, True
+    lab = labels.cuda()
+    samples, logq = ops.log_uniform_sample(seed % 9973, Ns, V, 'cuda')
+    loss = head.cloze_ce(x, lab, 0, samples=(samples, logq))
+    loss.backward()
+    P = {n: p.detach().cpu().double().clone().requires_grad_(True) for n, p in head.named_parameters()}
+    xr = x.detach().cpu().double().requires_grad_(True)
+    h = tr.dense_stack(xr, P, 2)
+    W, b = P['output_embedding'], P['output_bias']
+    yl, s = labels[keep].long(), samples.cpu()
+    zt = (h[keep] * W[yl]).sum(1) + b[yl] - torch.from_numpy(nr.log_uniform_logq(yl.numpy(), V, Ns))
+    zn = h[keep] @ W[s].t() + b[s][None] - torch.from_numpy(nr.log_uniform_logq(s.numpy(), V, Ns))[None]
+    zn = zn.masked_fill(s[None, :] == yl[:, None], float('-inf'))
+    ref = (torch.logsumexp(torch.cat([zt[:, None], zn], 1), 1) - zt).mean()
+    ref.backward()
+    if dt == torch.float32:
+        assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
+        tol = 3e-4
+    else:
+        assert abs(float(loss.detach()) - float(ref.detach())) < 2e-2 * max(1.0, abs(float(ref.detach())))
+        tol = 0.3       # bf16 weights, activations and logits (8 significant bits); with a 24-unit trunk and a few rows one ReLU
+                        # that flips between the two passes is a large share of a gradient: a net for gross mistakes only
+    big = max(float(P[n].grad.norm()) for n in P)
+    assert float((x.grad.cpu().double() - xr.grad).norm()) < tol * max(float(xr.grad.norm()), 1e-3 * big)
+    for n, p in head.named_parameters():
+        gr = P[n].grad
+        assert float((p.grad.cpu().double() - gr).norm()) < tol * max(float(gr.norm()), 0.02 * big), n
+    touched = torch.zeros(V, dtype=torch.bool)
+    touched[head.touched_rows().cpu()] = True
+    if bool((~touched).any()):
+        assert float(head.output_embedding.grad.cpu()[~touched].abs().max()) == 0.0
