@@ -806,3 +806,52 @@ def test_sampled_softmax_head_any_shape(ops, seed, V, K8, R, Ns, p_ign, dtype):
     touched[head.touched_rows().cpu()] = True
     if bool((~touched).any()):
         assert float(head.output_embedding.grad.cpu()[~touched].abs().max()) == 0.0
+
+
+@settings(**dict(SET, max_examples=10))
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 8), S=st.integers(6, 50), L=st.integers(1, 2), H=st.sampled_from([1, 2]),
+       dh=st.sampled_from([16, 32, 64]), V=st.integers(12, 300), hidden=st.sampled_from([(24,), (40, 16)]), arena=st.booleans())
+def test_tied_weight_head_random_configurations_fp32(ops, seed, B, S, L, H, dh, V, hidden, arena):
+    """ClozeMaskedItemPrediction (north-star extension, NO REFERENCE ORACLE: logits = trunk(h) . E[10 : 10 + V]^T + b, the item
+    table is the embedding's) at random sizes, fp32: loss (1e-5) and every gradient (2e-4), the table receiving the embedding's
+    and the head's gradient, against this repo's fp64 restatement; optionally through an arena optimizer (in-place gradients)."""
+    from bert4clickpath_amd import input_pipeline, optim
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, ClozeMaskedItemPrediction
+    from oracle import torch_ref as tr
+    d = H * dh
+    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=seed % 100000, min_len=2)
+    if b['labels'].shape[0] == 0:
+        return
+    torch.manual_seed(seed % 1000)
+    head = ClozeMaskedItemPrediction(list(hidden), V)
+    m = ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': d}, head, value_to_head='[MASK]',
+                               num_encoder_layers=L, num_attention_heads=H, dropout_rate=0.0).cuda()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith('bias') or n.endswith('beta'):
+                p.normal_(0, 0.05)
+    ids = torch.from_numpy(b['ids'])
+    items = ids[:, 2:S - 1].contiguous().cuda()
+    labels = torch.from_numpy(b['labels_padded']).cuda()
+    P = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in m.state_dict().items() if 'pos_encoding' not in k}
+    tP = {k[len('transformer.'):]: v for k, v in P.items() if k.startswith('transformer.')}
+    hP = {k[len('head.'):]: v for k, v in P.items() if k.startswith('head.')}
+    enc = tr.transformer_forward({'items': ids}, tP, L, H)
+    rows, _ = tr.gather_masked_rows(enc, ids)
+    n_layers = sum(1 for k in hP if k.startswith('intermediate_layers.') and k.endswith('.kernel'))      # + the projection onto the
+    logits = tr.tied_head_logits(rows, hP, n_layers, tP['embedding_layers.items.weight'], 10, V)          # table width when it differs
+    ref = tr.sparse_ce_tf(torch.softmax(logits, -1), torch.from_numpy(b['labels']).long()).mean()
+    ref.backward()
+    opt = optim.Adam(m.parameters()) if arena else None
+    if opt:
+        opt.zero_grad()
+    loss = m.cloze_loss({'asin': items}, labels, training=True)
+    loss.backward()
+    if opt:
+        ops.join_side_work(opt.arena.ctx)
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
+    for n, p in m.named_parameters():
+        gr = P[n].grad
+        if gr is None or float(gr.abs().max()) < 1e-9:
+            continue
+        assert float((p.grad.cpu().double() - gr).abs().max()) < 2e-4 * float(gr.abs().max()), n
