@@ -121,3 +121,57 @@ def test_shard_rows_partition():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1
+
+
+def _random_worker(rank, world, port, q):
+    """Randomly drawn arenas (parameter count and shapes, bucket cuts), gradients that exist on some ranks only, hooks on and
+    off, 'sum' and 'mean': after finish() every rank holds the same reduced arena -- the sum (or mean) of what the ranks produced."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import numpy as np
+    from bert4clickpath_amd import optim, parallel
+    parallel.init_distributed(backend='gloo')
+    checked = 0
+    for case in range(12):
+        rng = np.random.default_rng(1000 + case)                  # the same draw on every rank
+        n_par = int(rng.integers(1, 9))
+        shapes = [tuple(int(x) for x in rng.integers(1, 40, int(rng.integers(1, 3)))) for _ in range(n_par)]
+        torch.manual_seed(case)
+        params = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+        arena = optim.FlatArena(params)
+        inner = sorted(set(int(o) for o in rng.choice(arena.offsets[1:], size=min(len(arena.offsets) - 1, int(rng.integers(0, 4))), replace=False))) \
+            if len(arena.offsets) > 1 else []
+        overlap, mode = bool(rng.integers(0, 2)), ('sum', 'mean')[int(rng.integers(0, 2))]
+        red = parallel.GradReducer(arena, bucket_bounds=inner, reduce=mode, overlap=overlap)
+        has = rng.random((world, n_par)) < 0.8                     # which rank produces which gradient
+        coef = rng.standard_normal((world, n_par))
+        arena.zero_grad()
+        red.begin_backward()
+        mine = [(float(coef[rank, i]), p) for i, p in enumerate(params) if has[rank, i]]
+        if mine:
+            sum(c * (p * p).sum() for c, p in mine).backward()
+        red.finish()
+        if mode == 'mean':                                         # 'mean' multiplies the summed arena by 1 / world at the optimizer
+            assert red.grad_mul == 1.0 / world
+        for i, p in enumerate(params):
+            want = sum(float(coef[r, i]) for r in range(world) if has[r, i]) * 2.0 * p.detach()
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (case, i, mode, overlap)
+        checked += 1
+    q.put((rank, checked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_random_arenas_reduce_to_the_sum_on_every_rank(world):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_random_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res[r] == 12 for r in range(world))
