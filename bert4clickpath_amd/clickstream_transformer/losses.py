@@ -64,6 +64,9 @@ class MaskedLoss:
         binary: y_true and y_pred of one shape (labels 0 / 1, -1 = pad).  Returns a 0-d tensor."""
         ops._cuda(y_pred)
         yt = torch.as_tensor(y_true, device=y_pred.device).to(torch.float32).reshape(-1).contiguous()
+        # (a NON-empty batch whose labels are all pads: the reference divides 0 by 0 there, :84-91, and so does the binary kind
+        # here; the sparse kind returns 0 with zero gradients, what the Cloze composition gets through its adaptor -- DESIGN.md
+        # section 1, deviations)
         if yt.numel() == 0:      # empty sub-batch guard of losses.py:89-91
             return torch.zeros((), dtype=torch.float32, device=y_pred.device)
         if self.item_wise_loss_fn.kind == 'binary':

@@ -855,3 +855,38 @@ def test_tied_weight_head_random_configurations_fp32(ops, seed, B, S, L, H, dh, 
         if gr is None or float(gr.abs().max()) < 1e-9:
             continue
         assert float((p.grad.cpu().double() - gr).abs().max()) < 2e-4 * float(gr.abs().max()), n
+
+
+@settings(**dict(SET, max_examples=25))
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 9), Lq=st.integers(1, 20), d8=st.integers(1, 12), trunk=st.sampled_from([(8,), (24, 16)]),
+       pos_weight=st.sampled_from([None, 0.5, 3.0]), p_pad=st.sampled_from([0.0, 0.3, 1.0]))
+def test_binary_head_and_masked_bce_any_shape(ops, seed, B, Lq, d8, trunk, pos_weight, p_pad):
+    """BinaryClassificationHead (head.py:4-26) + MaskedLoss(K.binary_crossentropy, pos_weight) (losses.py:31-98): sigmoid
+    probabilities (1e-6), the masked, weighted loss (1e-6) and the gradients w.r.t. input and parameters (2e-4) against the fp64
+    restatement, at random shapes, with label pads up to a batch without a single label."""
+    from bert4clickpath_amd.clickstream_transformer import BinaryClassificationHead, MaskedLoss, binary_crossentropy
+    from oracle import torch_ref as tr
+    d = 8 * d8
+    torch.manual_seed(seed % 100003)
+    head = BinaryClassificationHead(list(trunk), input_dim=d).cuda()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Lq, d, generator=g).cuda().requires_grad_(True)
+    y = torch.randint(0, 2, (B, Lq), generator=g).float()
+    y[torch.rand(B, Lq, generator=g) < p_pad] = -1.0
+    probs = head(x)
+    loss = MaskedLoss(binary_crossentropy, pos_weight=pos_weight)(y.cuda(), probs)
+    loss.backward()
+    P = {n: p.detach().cpu().double().clone().requires_grad_(True) for n, p in head.named_parameters()}
+    xr = x.detach().cpu().double().requires_grad_(True)
+    pr = tr.binary_head(xr, P, len(trunk))
+    ref = tr.masked_loss(y.double(), pr, tr.binary_ce_tf, pos_weight)
+    assert float((probs.detach().cpu().double() - pr.detach()).abs().max()) < 1e-6
+    if bool((y != -1).any()):
+        assert abs(float(loss.detach()) - float(ref.detach())) < 1e-6 * max(1.0, abs(float(ref.detach())))
+        ref.backward()
+        assert float((x.grad.cpu().double() - xr.grad).abs().max()) < 2e-4 * float(xr.grad.abs().max()) + 1e-12
+        for n, p in head.named_parameters():
+            assert float((p.grad.cpu().double() - P[n].grad).abs().max()) < 2e-4 * float(P[n].grad.abs().max()) + 1e-12, n
+    else:
+        # a non-empty batch of pads only: 0 / 0 in the reference (losses.py:84-91 guards the EMPTY tensor only), and here
+        assert np.isnan(float(ref.detach())) and np.isnan(float(loss.detach()))
