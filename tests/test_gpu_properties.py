@@ -890,3 +890,31 @@ def test_binary_head_and_masked_bce_any_shape(ops, seed, B, Lq, d8, trunk, pos_w
     else:
         # a non-empty batch of pads only: 0 / 0 in the reference (losses.py:84-91 guards the EMPTY tensor only), and here
         assert np.isnan(float(ref.detach())) and np.isnan(float(loss.detach()))
+
+
+@settings(**dict(SET, max_examples=25))
+@given(seed=st.integers(0, 2 ** 31 - 1), R=st.integers(1, 300), V=st.integers(2048, 9000), K=st.sampled_from([64, 128]),
+       scale=st.sampled_from([0.2, 0.7, 1.6, 2.5]))
+def test_one_pass_vocabulary_softmax_any_shape_and_spread(ops, seed, R, V, K, scale):
+    """Dense(V, softmax) (head.py:36) as the scoring path computes it -- an lse sweep, then the projection with the softmax in
+    its epilogue, logits never stored -- against the fp64 softmax of the same bf16 operands: from flat rows to logit spreads of
+    +-150 (scale 2.5), where the running sum of the sweep has to follow its maximum to stay finite."""
+    g = torch.Generator().manual_seed(seed)
+    h = (torch.randn(R, K, generator=g) * scale).bfloat16().cuda()
+    Np = ops.rup8(V)
+    w = torch.zeros(Np, K)
+    w[:V] = torch.randn(V, K, generator=g) * scale
+    w = w.bfloat16().cuda()
+    b = torch.zeros(Np)
+    b[:V] = torch.randn(V, generator=g)
+    b = b.cuda()
+    probs = ops.vocab_softmax(h, w, b, Np, V)
+    ref = torch.softmax(h.double() @ w[:V].double().t() + b[:V].double(), dim=1)
+    got = probs[:, :V].double()
+    assert bool(torch.isfinite(got).all())
+    # bf16 output: 2^-9 relative on every probability that is not denormal-small
+    big = ref > 1e-30
+    assert float(((got - ref).abs() / ref.clamp(min=1e-30))[big].max()) < 8e-3
+    assert float((got.sum(1) - 1).abs().max()) < 6e-3
+    if Np != V:
+        assert float(probs[:, V:].abs().max()) == 0.0
