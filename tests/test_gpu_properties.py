@@ -570,6 +570,22 @@ def test_whole_model_random_configurations_fp32(ops, seed, B, S, L, H, dh, V, tr
         if gr is None or float(gr.abs().max()) < 1e-9:
             continue
         assert float((p.grad.cpu().double() - gr).abs().max()) < 2e-4 * float(gr.abs().max()), n
+    # top-k ids and the metric terms (utils.py:161-190, 225-255): ids equal a stable descending sort of the fp64 probabilities
+    # wherever the neighbours' gap is beyond fp32 rounding; hit / ndcg are exactly what the returned ids and the labels say
+    if labels.numel() and int((labels != -1).sum()) > 0:
+        kk = min(5, V)
+        top, hit, ndcg = m.predict_topk(feats, kk, labels)
+        rp = rprobs.detach().numpy()
+        order = np.argsort(-rp, axis=1, kind='stable')[:, :kk]
+        srt = -np.sort(-rp, axis=1)
+        mcol = min(kk, V - 1)
+        clear = ((srt[:, :mcol] - srt[:, 1:mcol + 1]) > 1e-5 * srt[:, :mcol]).all(1)
+        assert np.array_equal(top.cpu().numpy()[clear], order[clear])
+        lab_c = b['labels']
+        pos = (top.cpu().numpy() == lab_c[:, None])
+        assert np.array_equal(hit.cpu().numpy(), pos.any(1).astype(np.float32))
+        disc = 1.0 / (np.log(np.arange(2, kk + 2, dtype=np.float32)) / np.log(np.float32(2.0)))
+        assert np.allclose(ndcg.cpu().numpy(), (pos * disc[None]).sum(1), atol=1e-6)
     # the bf16 throughput path on the same weights and batch (MFMA attention needs head depth 32 / 64 for the padding-free
     # layout): a coarse net for shape / stride / layout mistakes -- loss within 1 %, every sizeable gradient within 25 % L2
     # (the tight bf16 bound needs the device pass's ReLU patterns: tests/bf16_gates.py)
