@@ -280,7 +280,8 @@ def test_varlen_attention_random_ragged_batches(ops, seed, B, smax, H, dh, with_
         lens[0] = 1
     T, d = int(lens.sum()), H * dh
     g = torch.Generator().manual_seed(seed)
-    qkv = (torch.randn(T, 3 * d, generator=g) * scale).bfloat16()          # scale 3: logits of +-40, near one-hot attention rows
+    # scale 3: logits of +-40, near one-hot attention rows -- through q and k; v stays O(1) (see the masked-query test)
+    qkv = (torch.randn(T, 3 * d, generator=g) * torch.cat([torch.full((2 * d,), float(scale)), torch.full((d,), 0.8)])).bfloat16()
     do = torch.randn(T, d, generator=g).bfloat16()
     cu_h = np.concatenate([[0], np.cumsum(lens)])
     cu = torch.tensor(cu_h, dtype=torch.int32, device='cuda')
@@ -300,7 +301,7 @@ def test_varlen_attention_random_ragged_batches(ops, seed, B, smax, H, dh, with_
     assert err(o, o_ref.detach()) < 1.2e-2
     o_ref.backward(do.double())
     dqkv = ops.attn_bwd(qkv.cuda(), key_pad, o, do.cuda(), lse, B, S_max, H, dh, cu)
-    assert err(dqkv, q64.grad) < (2.5e-2 if scale < 1 else 4e-2)
+    assert err(dqkv, q64.grad) < 2.5e-2
     assert torch.equal(ops.attn_bwd(qkv.cuda(), key_pad, o, do.cuda(), lse, B, S_max, H, dh, cu), dqkv)     # run-to-run identical
 
 
@@ -393,8 +394,10 @@ def test_masked_query_attention_random_ragged_batches(ops, seed, B, smax, mmax, 
     cu = torch.zeros(B + 1, dtype=torch.int32); cu[1:] = torch.cumsum(lens, 0)          # noqa: E702
     moff = torch.zeros(B + 1, dtype=torch.int32); moff[1:] = torch.cumsum(nq, 0)        # noqa: E702
     T, R, d = int(cu[-1]), int(moff[-1]), H * dh
+    # scale 3 sharpens the attention rows (logits of +-40) through q and k only: the values stay O(1), or the bf16 rounding of
+    # O inside delta = rowsum(dO o O) -- 2^-9 |v| per term, as in any flash-style backward -- would be all the test sees
     q = (torch.randn(R, d, generator=g) * scale).to(dt)
-    kv = (torch.randn(T, 2 * d, generator=g) * scale).to(dt)
+    kv = (torch.randn(T, 2 * d, generator=g) * torch.cat([torch.full((d,), float(scale)), torch.full((d,), 0.8)])).to(dt)
     go = torch.randn(R, d, generator=g).to(dt)
     key_pad = None
     if pad:
@@ -408,8 +411,7 @@ def test_masked_query_attention_random_ragged_batches(ops, seed, B, smax, mmax, 
     assert float((o.double().cpu() - ro).abs().max()) < tol * max(1.0, float(ro.abs().max()))
     assert float((lse.double().cpu() - rl).abs().max()) < (1e-4 if dt == torch.float32 else 2e-2)
     dq, dkv = ops.attn_mq_bwd(q.cuda(), kv.cuda(), cu.cuda(), moff.cuda(), o, go.cuda(), lse, B, S_max, H, dh, kp)
-    # (bf16 at scale 3: near one-hot attention rows, P and dS pass through bf16 once each in front of the matrix cores)
-    btol = 1e-4 if dt == torch.float32 else (3e-2 if scale < 1 else 7e-2)
+    btol = 1e-4 if dt == torch.float32 else 3e-2
     assert float((dq.double().cpu() - rdq).abs().max()) < btol * max(1.0, float(rdq.abs().max()))
     assert float((dkv.double().cpu() - rdkv).abs().max()) < btol * max(1.0, float(rdkv.abs().max()))
     for b in range(B):
@@ -621,7 +623,7 @@ def test_padded_layout_attention_any_shape(ops, seed, B, S, H, dh, dtype, pad_mo
     dt = torch.float32 if dtype == 'f32' else torch.bfloat16
     g = torch.Generator().manual_seed(seed)
     d = H * dh
-    qkv = torch.randn(B * S, 3 * d, generator=g) * scale
+    qkv = torch.randn(B * S, 3 * d, generator=g) * torch.cat([torch.full((2 * d,), float(scale)), torch.full((d,), 0.8)])
     pad = torch.zeros(B, S, dtype=torch.uint8)
     if pad_mode == 'tails':
         lens = torch.randint(1, S + 1, (B,), generator=g)
@@ -645,7 +647,7 @@ def test_padded_layout_attention_any_shape(ops, seed, B, S, H, dh, dtype, pad_mo
     do = torch.randn(B * S, d, generator=g).cuda().to(dt)
     o_ref.backward(do.double().cpu())
     dqkv = ops.attn_bwd(qd, pad.cuda(), o, do, lse, B, S, H, dh)
-    assert err(dqkv, q64.grad) < (1e-4 if dt == torch.float32 else (2.5e-2 if scale < 1 else 4e-2))
+    assert err(dqkv, q64.grad) < (1e-4 if dt == torch.float32 else 2.5e-2)
     kv_grad = dqkv[:, d:].reshape(B, S, 2 * d).float().cpu()
     for b in range(B):
         if bool(live[b]) and int(pad[b].sum()):
