@@ -937,3 +937,49 @@ def test_one_pass_vocabulary_softmax_any_shape_and_spread(ops, seed, R, V, K, sc
     assert float((got.sum(1) - 1).abs().max()) < 6e-3
     if Np != V:
         assert float(probs[:, V:].abs().max()) == 0.0
+
+
+@settings(**dict(SET, max_examples=10))
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(2, 24), S=st.integers(8, 90), L=st.integers(1, 3), H=st.sampled_from([1, 2, 4]),
+       dh=st.sampled_from([32, 64]), V=st.integers(200, 3000), K=st.sampled_from([64, 128]), bg=st.sampled_from([0, 8]))
+def test_arena_step_equals_plain_autograd_step_bf16(ops, seed, B, S, L, H, dh, V, K, bg):
+    """What bench.py runs -- bf16, padding-free layout, last layer at the [MASK] rows, logits-free head, gradients written in
+    place into a flat arena, the projection's dW as background pieces on a side stream -- against the same model trained through
+    plain autograd gradients: same loss bits, gradients equal up to the float-atomic order of the two dW forms."""
+    from bert4clickpath_amd import input_pipeline, optim
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    d = H * dh
+    b = input_pipeline.synthetic_cloze_batch(B, S, V, seed=seed % 100000, min_len=3)
+    if b['labels'].shape[0] == 0:
+        return
+
+    def make():
+        torch.manual_seed(seed % 1000)
+        return ClickstreamTransformer({'items': ['asin']}, {'items': ['i%d' % i for i in range(V)]}, {'items': d}, SoftMaxHead([32, K], V),
+                                      value_to_head='[MASK]', num_encoder_layers=L, num_attention_heads=H, dropout_rate=0.0,
+                                      compute_dtype=torch.bfloat16).cuda()
+    items = torch.from_numpy(b['ids'])[:, 2:S - 1].contiguous().cuda()
+    labels = torch.from_numpy(b['labels_padded']).cuda()
+    kw = dict(max_masked_per_row=10, n_real_tokens=int((b['ids'] != 0).sum()))
+    plain = make()
+    lp = plain.cloze_loss({'asin': items}, labels, training=True, **kw)
+    lp.backward()
+    prev = ops.background_workgroups
+    ops.background_workgroups = bg
+    try:
+        ar = make()
+        opt = optim.Adam(ar.parameters())
+        opt.zero_grad()
+        la = ar.cloze_loss({'asin': items}, labels, training=True, **kw)
+        la.backward()
+        ops.join_side_work(opt.arena.ctx)
+        torch.cuda.synchronize()
+    finally:
+        ops.background_workgroups = prev
+    assert float(la.detach()) == float(lp.detach())
+    gp = dict(plain.named_parameters())
+    for n, p in ar.named_parameters():
+        a, c = p.grad.float(), gp[n].grad.float()
+        assert float((a - c).abs().max()) <= 2e-3 * float(c.abs().max()) + 1e-9, n
+    c = opt.arena.ctx
+    assert not c.queue and not c.pending and ops._active_ctx is None
