@@ -36,8 +36,9 @@ class TransformerInputPrep:
 
     @staticmethod
     def _chain_sequences(sequences):
-        first = sequences[0]
-        if _is_string_feature(first):
+        # (a nested list without any element -- a (B, 0) sequence -- has no dtype of its own: the chain is of strings as soon
+        # as ONE of its sequences is, and of int64 ids when none says otherwise)
+        if any(_is_string_feature(x) for x in sequences):
             seqs = [np.asarray(s, dtype=object) for s in sequences]
             B = seqs[0].shape[0]
             cls = np.full((B, 1), CLASSIFICATION_TOKEN, dtype=object)
@@ -46,7 +47,8 @@ class TransformerInputPrep:
             for s in seqs:
                 parts += [s.reshape(B, -1), sep]
             return np.concatenate(parts, axis=1)
-        seqs = [torch.as_tensor(s) for s in sequences]
+        seqs = [s if isinstance(s, torch.Tensor) else torch.as_tensor(np.asarray(s).astype(np.int64) if np.asarray(s).size == 0 else s)
+                for s in sequences]
         B = seqs[0].shape[0]
         if all(s.is_cuda and s.dtype == torch.int64 and s.dim() == 2 for s in seqs) and len(seqs) <= 8:
             return ops.chain_ids(seqs, CLS, SEP)          # one library launch instead of torch.cat
@@ -72,11 +74,17 @@ class TransformerInputPrep:
             features[new_feature] = self._chain_sequences(seqs)
             if lens is None:
                 lens = [int(np.asarray(s).shape[1]) if not isinstance(s, torch.Tensor) else int(s.shape[1]) for s in seqs]
-        # SEP positions are the same in every row (sequences are padded before chaining)
-        ends, pos = [1], 1
-        for n in lens:
-            pos += n + 1
-            ends.append(pos)
+        first = features[list(self.seq_chain_mapping.keys())[0]]
+        if isinstance(first, np.ndarray) and first.dtype == object and first.shape[0] > 0:
+            # the reference's rule, literally (:79-90): every position of ROW 0 that holds '[SEP]' ends a segment -- also an
+            # item that happens to be that token
+            ends = [int(i) for i in np.flatnonzero(first[0] == SEPARATOR_TOKEN)]
+        else:
+            # integer ids (possibly on the GPU: no read-back): the separators sit where the chain put them, the same in every row
+            ends, pos = [1], 1
+            for n in lens:
+                pos += n + 1
+                ends.append(pos)
         starts = [0] + [e + 1 for e in ends[:-1]]
         if not keep_features:
             drop = set()
