@@ -983,3 +983,37 @@ def test_arena_step_equals_plain_autograd_step_bf16(ops, seed, B, S, L, H, dh, V
         assert float((a - c).abs().max()) <= 2e-3 * float(c.abs().max()) + 1e-9, n
     c = opt.arena.ctx
     assert not c.queue and not c.pending and ops._active_ctx is None
+
+
+@settings(**dict(SET, max_examples=12))
+@given(data=st.data(), B=st.integers(1, 6), Lr=st.integers(1, 14), H=st.sampled_from([1, 2]), layers=st.integers(1, 2))
+def test_string_inputs_with_reserved_tokens_anywhere(ops, data, B, Lr, H, layers):
+    """The model called as the reference is -- nested lists of STRINGS -- with reserved tokens ([PAD] in the middle, [MASK]
+    several times or never, [CLS] / [SEP] / [UNK] as items, out-of-vocabulary strings) anywhere in the rows: chaining, lookup,
+    key-padding mask, the ragged gather of the [MASK] positions with its zero padding (clickstream_transformer.py:260-297) and
+    the head, against the numpy restatement, probabilities to 1e-6."""
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    V, d = 23, 32
+    vocab = ['v%d' % i for i in range(V)]
+    toks = st.sampled_from(vocab + ['not-in-vocab', '[PAD]', '[MASK]', '[MASK]', '[CLS]', '[SEP]', '[UNK]'])
+    rows = [[data.draw(toks) for _ in range(Lr)] for _ in range(B)]
+    torch.manual_seed(B * 100 + Lr)
+    model = ClickstreamTransformer({'items': ['asin']}, {'items': vocab}, {'items': d}, SoftMaxHead([16], V), value_to_head='[MASK]',
+                                   num_encoder_layers=layers, num_attention_heads=H, dropout_rate=0.0).cuda()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('bias') or n.endswith('beta'):
+                p.normal_(0, 0.05)
+    probs = model({'asin': rows}, training=False)
+    chained = nr.chain_sequences([rows])
+    table, oov, _ = nr.build_lookup(vocab)
+    ids = np.asarray(nr.lookup(table, oov, chained))
+    P = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    tP = {k[len('transformer.'):]: v for k, v in P.items() if k.startswith('transformer.')}
+    enc = nr.transformer_forward({'items': ids}, tP, layers, H, np.float64)
+    head_in = nr.gather_output_by_raw_value(enc, np.asarray(chained, dtype=object), '[MASK]')
+    hP = {k[len('head.'):]: v.astype(np.float64) for k, v in P.items() if k.startswith('head.')}
+    want = nr.softmax_head(head_in, hP, 1)
+    assert tuple(probs.shape) == tuple(want.shape)
+    if want.size:
+        assert float(np.abs(probs.detach().cpu().numpy() - want).max()) < 1e-6
