@@ -1017,3 +1017,37 @@ def test_string_inputs_with_reserved_tokens_anywhere(ops, data, B, Lr, H, layers
     assert tuple(probs.shape) == tuple(want.shape)
     if want.size:
         assert float(np.abs(probs.detach().cpu().numpy() - want).max()) < 1e-6
+
+
+@settings(**dict(SET, max_examples=12))
+@given(data=st.data(), B=st.integers(1, 5), L1=st.integers(0, 9), L2=st.integers(0, 6), seg=st.integers(0, 2))
+def test_segment_routing_with_two_chained_sequences(ops, data, B, L1, L2, seg):
+    """segment_to_head (clickstream_transformer.py:318-322): the head sees enc[:, starts[k] : ends[k]] of the chain
+    [CLS] [SEP] seq_1 [SEP] seq_2 [SEP], with the bounds the reference derives from the '[SEP]' positions of ROW 0 -- so an item
+    that IS '[SEP]' moves them (for every row).  Probabilities against the numpy restatement, 1e-6."""
+    from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
+    V, d = 19, 32
+    vocab = ['v%d' % i for i in range(V)]
+    toks = st.sampled_from(vocab + ['[PAD]', '[SEP]', 'oov'])
+    a = [[data.draw(toks) for _ in range(L1)] for _ in range(B)]
+    c = [[data.draw(toks) for _ in range(L2)] for _ in range(B)]
+    if L1 + L2 == 0:
+        return                                  # (typeless empty nested lists: see tests/test_host_properties.py)
+    torch.manual_seed(seg + 10 * B)
+    model = ClickstreamTransformer({'items': ['s1', 's2']}, {'items': vocab}, {'items': d}, SoftMaxHead([16], V), segment_to_head=seg,
+                                   num_encoder_layers=1, num_attention_heads=2, dropout_rate=0.0).cuda()
+    chained = nr.chain_sequences([a, c]) if L1 else [['[CLS]', '[SEP]'] + a[b] + ['[SEP]'] + c[b] + ['[SEP]'] for b in range(B)]
+    starts, ends = nr.segment_bounds(chained[0])
+    if seg >= len(ends):
+        return
+    out = model({'s1': a, 's2': c}, training=False)
+    table, oov, _ = nr.build_lookup(vocab)
+    ids = np.asarray(nr.lookup(table, oov, chained))
+    P = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    tP = {k[len('transformer.'):]: v for k, v in P.items() if k.startswith('transformer.')}
+    enc = nr.transformer_forward({'items': ids}, tP, 1, 2, np.float64)
+    hP = {k[len('head.'):]: v.astype(np.float64) for k, v in P.items() if k.startswith('head.')}
+    want = nr.softmax_head(enc[:, starts[seg]:ends[seg], :], hP, 1)
+    assert tuple(out.shape) == tuple(want.shape)
+    if want.size:
+        assert float(np.abs(out.detach().cpu().numpy() - want).max()) < 1e-6
