@@ -1051,3 +1051,35 @@ def test_segment_routing_with_two_chained_sequences(ops, data, B, L1, L2, seg):
     assert tuple(out.shape) == tuple(want.shape)
     if want.size:
         assert float(np.abs(out.detach().cpu().numpy() - want).max()) < 1e-6
+
+
+@settings(**dict(SET, max_examples=30))
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 12), M=st.integers(1, 7), V=st.integers(2, 2500), k=st.integers(1, 12),
+       levels=st.sampled_from([0, 3, 40]), p_pad=st.sampled_from([0.0, 0.4, 1.0]), dtype=st.sampled_from(['f32', 'bf16']), batches=st.integers(1, 3))
+def test_cloze_metrics_accumulate_like_the_reference(ops, seed, B, M, V, k, levels, p_pad, dtype, batches):
+    """ClozeMaskedRecall(k) / ClozeMaskedNDCG(k) (utils.py:137-259): update_state over several (B, M, V) batches with padded
+    labels (pads up to a whole batch), scores with heavy ties (lower index wins), result() = accumulated terms / accumulated
+    examples -- against the restatement's accumulators, exactly in the hits and to 1e-6 in the NDCG terms."""
+    from bert4clickpath_amd.cloze import ClozeMaskedNDCG, ClozeMaskedRecall
+    k = min(k, V)
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    rng = np.random.default_rng(seed)
+    rec, nd = ClozeMaskedRecall(k), ClozeMaskedNDCG(k)
+    tot = {'h': 0.0, 'n': 0.0, 'g': 0.0}
+    for _ in range(batches):
+        x = rng.random((B, M, V)).astype(np.float32) if levels == 0 else rng.integers(0, levels, (B, M, V)).astype(np.float32) / 64
+        yp = torch.from_numpy(x).cuda().to(dt)
+        y = rng.integers(0, V, (B, M)).astype(np.float32)
+        y[rng.random((B, M)) < p_pad] = -1.0
+        rec.update_state(torch.from_numpy(y).cuda(), yp)
+        nd.update_state(torch.from_numpy(y).cuda(), yp)
+        xs = yp.float().cpu().numpy()
+        h, n = nr.recall_at_k(y, xs, k)
+        g, _ = nr.ndcg_at_k(y, xs, k)
+        tot['h'] += h; tot['n'] += n; tot['g'] += g         # noqa: E702
+    if tot['n'] == 0:
+        assert rec.total is None or float(rec.n_examples) == 0.0
+        return
+    assert float(rec.n_examples) == tot['n'] and float(rec.total) == tot['h']
+    assert abs(float(nd.total) - tot['g']) < 1e-5 * max(1.0, tot['g'])
+    assert abs(float(rec.result()) - tot['h'] / tot['n']) < 1e-6 and abs(float(nd.result()) - tot['g'] / tot['n']) < 1e-5
