@@ -412,8 +412,17 @@ def test_masked_query_attention_random_ragged_batches(ops, seed, B, smax, mmax, 
     assert float((lse.double().cpu() - rl).abs().max()) < (1e-4 if dt == torch.float32 else 2e-2)
     dq, dkv = ops.attn_mq_bwd(q.cuda(), kv.cuda(), cu.cuda(), moff.cuda(), o, go.cuda(), lse, B, S_max, H, dh, kp)
     btol = 1e-4 if dt == torch.float32 else 3e-2
-    assert float((dq.double().cpu() - rdq).abs().max()) < btol * max(1.0, float(rdq.abs().max()))
-    assert float((dkv.double().cpu() - rdkv).abs().max()) < btol * max(1.0, float(rdkv.abs().max()))
+    # bf16: delta = rowsum(dO o O) is taken from the STORED (bf16) O, so it is off by up to 2^-9 sum_i |dO_i O_i| per (row, head);
+    # where one key holds the row, dS = P (dP - delta) is a difference of two equal numbers and keeps that error whole: it reaches
+    # dq through |k| / sqrt(dh) and dk through |q| / sqrt(dh) (a drawn case -- one query, six keys, q and k scaled by 3 -- gave
+    # 0.0440 on a dq of 0.61, the figure an fp64 restatement with that one rounding gives to eight digits)
+    fq = fk = 0.0
+    if dt == torch.bfloat16:
+        dmax = float((go.double() * ro).abs().view(R, H, dh).sum(-1).max())
+        fq = 2.0 ** -9 * dmax * float(kv[:, :d].abs().max()) / np.sqrt(dh)
+        fk = 2.0 ** -9 * dmax * float(q.abs().max()) / np.sqrt(dh) * max(1, int(nq.max()))
+    assert float((dq.double().cpu() - rdq).abs().max()) < btol * max(1.0, float(rdq.abs().max())) + fq
+    assert float((dkv.double().cpu() - rdkv).abs().max()) < btol * max(1.0, float(rdkv.abs().max())) + fk
     for b in range(B):
         if nq[b] == 0:
             assert float(dkv[int(cu[b]):int(cu[b + 1])].abs().max()) == 0.0
