@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(64 * MQ_WAVES, 3) attn_mq_fwd_mfma_kernel(cons
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSTR = DH * 2 + 16;
     constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8, VC = 32 * CH / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5, li = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hf = lane >> 5, li = lane & 15, g = lane >> 4;
     char *sV = smem + wave * (2 * 32 * KSTR);                 // this wave's two V tiles
     const int item = blockIdx.x * MQ_WAVES + wave;
     if (item >= n_items) return;                              // (no workgroup barrier anywhere below)
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(64 * MQ_WAVES, 2) attn_mq_bwd_mfma_kernel(cons
     constexpr int KSTR = DH * 2 + 16, TSTR = 32 * 2 + 16;
     constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8, VC = 32 * CH / 64;
     constexpr int WBYTES = 3 * 32 * KSTR + 32 * TSTR + 2 * 32 * 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5, li = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hf = lane >> 5, li = lane & 15, g = lane >> 4;
     char *sQ = smem + wave * WBYTES;
     char *sG = sQ + 32 * KSTR;
     char *sK = sG + 32 * KSTR;
