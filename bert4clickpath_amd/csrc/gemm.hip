@@ -35,7 +35,11 @@ template <typename K> static void allow_lds(K kernel, size_t bytes) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void *base, int64_t rows_left, int tile_rows, int64_t row_bytes) {
     const int64_t rows = rows_left < tile_rows ? (rows_left < 0 ? 0 : rows_left) : tile_rows;
     const int64_t bytes = rows * row_bytes;           // < 1 GiB for every tile this file uses
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (unsigned)(bytes > 0x3FFFFFF0ll ? 0x3FFFFFF0ll : bytes), 0x00020000);
+    // Every caller passes workgroup-uniform operands, but the clamp above comes out of the vector ALU (v_med3 / v_cndmask) and
+    // a descriptor word in a VGPR makes the compiler wrap EVERY buffer load in a readfirstlane "waterfall" loop (gemm_nt_ln:
+    // four in the prologue and four inside the k loop).  Saying it once here keeps the descriptor in SGPRs.
+    const unsigned nb = __builtin_amdgcn_readfirstlane((unsigned)(bytes > 0x3FFFFFF0ll ? 0x3FFFFFF0ll : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, nb, 0x00020000);
 }
 // or-ing this bit into a byte offset pushes it past every tile descriptor (plain integer arithmetic: a select
 // between a real offset and a large constant gets if-converted into two differently-encoded loads)
