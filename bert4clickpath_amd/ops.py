@@ -348,8 +348,8 @@ def gemm_nt(a, bt, n, bias=None, act=L.ACT_NONE, gate=None, residual=None, out_d
     # the materialised vocabulary projection (wide kernel: bf16, K <= 128, N >= 2048, plain epilogue) is its own family
     fam = 'vocab_proj' if (n >= 2048 and K <= 128 and a.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and
                            act == L.ACT_NONE and gate is None and residual is None) else 'gemm_nt'
-    # token-sized launches ([T] rows: HBM-bound at 60 - 130 us each) and row-sized ones ([R] rows of the head trunk and of
-    # the rows-only last layer: a few us each, launch-bound) are two families: one number would describe neither
+    # token-sized launches ([T] rows: HBM-bound at 60 - 130 us each) and row-sized ones ([R] rows of the head trunk -- 10 - 60 us
+    # each, matrix work -- and of the rows-only last layer, a few us each) are two families: one number would describe neither
     if fam == 'gemm_nt' and 2 * M < rec_hints.get('token_rows', 0):
         fam = 'gemm_nt_rows'
     with _record(fam, nbytes, 2 * M * n * K):
