@@ -1464,7 +1464,8 @@ overlap_vocab_dw = os.environ.get('B4C_OVERLAP_DW', '1') == '1'
 background_workgroups = int(os.environ.get('B4C_VCE_DW_BG', '0'))      # 0: one per CU of the device
 # deterministic_vocab_dw: the projection's dW / db are summed in a fixed order (no float atomics: one workgroup per
 # vocabulary tile walks every token, the label term goes through a stable sort of the rows by label) -- two identical steps
-# give bit-identical arenas.  Default off: the split sweep fills the CUs better (B4C_DETERMINISTIC_DW=1 switches it on).
+# give a bit-identical projection gradient (LayerNorm dgamma / dbeta and a few embedding rows still meet through float atomics).
+# Default off: the split sweep fills the CUs better (B4C_DETERMINISTIC_DW=1 switches it on).
 deterministic_vocab_dw = os.environ.get('B4C_DETERMINISTIC_DW', '0') == '1'
 
 
