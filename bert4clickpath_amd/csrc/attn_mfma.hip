@@ -289,15 +289,15 @@ __global__ void __launch_bounds__(512, (QPW == 1 ? 4 : 2)) attn_fwd_mfma_kernel(
 // computed while staging; dQ tile = 8 (16 x 16) MFMA tiles, one per wave.
 // ------------------------------------------------------------------------------------------
 template <int DH>
-__global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
-                                                            const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o,
-                                                            int ld_do, const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
-                                                            int ld_dq, int S_arg, int H, float scale, int key0, float *__restrict__ dq_acc,
-                                                            int acc_mode, const int32_t *__restrict__ cu) {
-    // Sequences longer than 256 run this kernel once per block of 256 keys (key0 = 0, 256, ...): a launch owns the dK / dV
-    // rows of its keys and the part of dQ that sums over them.  acc_mode 0: dQ is complete, written as bf16; 1: first
-    // block, the partial dQ goes to dq_acc (fp32 [B*S][H*DH]); 2: middle block, dq_acc += partial; 3: last block,
-    // dQ = bf16(dq_acc + partial).  Every launch streams all the query tiles.
+__device__ __forceinline__ void attn_bwd_key_block(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
+                                                   const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o,
+                                                   int ld_do, const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
+                                                   int ld_dq, int S_arg, int H, float scale, int key0, float *__restrict__ dq_acc,
+                                                   int acc_mode, const int32_t *__restrict__ cu) {
+    // One block of up to 256 keys of one (sequence, head): the workgroup owns the dK / dV rows of those keys and the part of
+    // dQ that sums over them.  acc_mode 0: dQ is complete, written as bf16; 1: first block of several, the partial dQ goes
+    // to dq_acc (fp32 [B*S][H*DH]); 2: middle block, dq_acc += partial; 3: last block, dQ = bf16(dq_acc + partial).  Every
+    // block streams all the query tiles.  (A dQ element is written and read back by the SAME thread in every block.)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSTR = DH * 2 + 16;
     constexpr int NKS = DH / 16, NDT = DH / 32, CH = DH / 8;
@@ -485,6 +485,21 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__rest
                 *reinterpret_cast<bf16x4 *>(krow + dt * 32 + 8 * tq + 4 * hf) = wk;
                 *reinterpret_cast<bf16x4 *>(vrow + dt * 32 + 8 * tq + 4 * hf) = wv;
             }
+    }
+}
+
+// Sequences of up to 256 keys: one block (acc_mode 0).  Longer ones (S <= 512): the workgroup walks the blocks of 256 keys
+// one after the other in ONE launch (round 2 launched the kernel once per block): Q, dO, O and the fp32 partial dQ of the
+// second pass come out of L2 right behind the first instead of from HBM behind a whole launch.
+template <int DH>
+__global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, int ld, const uint8_t *__restrict__ key_pad,
+                                                            const bf16_t *__restrict__ o, int ld_o, const bf16_t *__restrict__ d_o,
+                                                            int ld_do, const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
+                                                            int ld_dq, int S_arg, int H, float scale, int nblk, float *__restrict__ dq_acc,
+                                                            const int32_t *__restrict__ cu) {
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int mode = nblk == 1 ? 0 : (kb == 0 ? 1 : (kb == nblk - 1 ? 3 : 2));
+        attn_bwd_key_block<DH>(qkv, ld, key_pad, o, ld_o, d_o, ld_do, lse, dqkv, ld_dq, S_arg, H, scale, kb * 256, dq_acc, mode, cu);
     }
 }
 
@@ -781,20 +796,18 @@ int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const
     if (!mfma_shape_ok(S, dh)) return B4C_EUNSUPPORTED;
     const float scale_s = 1.0f / sqrtf((float)dh);
     if (S > 32 * ATT_MAX_KT) {
-        // one launch per block of 256 keys; the partial dQ sums meet in an fp32 accumulator (caller's workspace)
+        // the blocks of 256 keys one after the other inside one launch; their partial dQ sums meet in an fp32 accumulator
+        // (caller's workspace)
         if (!workspace || workspace_bytes < b4c_attn_bwd_mfma_workspace_bytes(B, S, H, dh)) return B4C_EUNSUPPORTED;
         const size_t kstr2 = dh * 2 + 16, tstr2 = 256 * 2 + 16;
         const size_t shm2 = 2 * 256 * kstr2 + 2 * (2 * 32 * kstr2 + 256) + 32 * tstr2;
         const int nblk = (S + 255) / 256;
-        for (int kb = 0; kb < nblk; ++kb) {
-            const int mode = kb == 0 ? 1 : (kb == nblk - 1 ? 3 : 2);
-            if (dh == 64) {
-                allow_lds_attn(attn_bwd_mfma_kernel<64>, shm2);
-                attn_bwd_mfma_kernel<64><<<B * H, 512, shm2, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale_s, kb * 256, (float *)workspace, mode, cu);
-            } else {
-                allow_lds_attn(attn_bwd_mfma_kernel<32>, shm2);
-                attn_bwd_mfma_kernel<32><<<B * H, 512, shm2, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale_s, kb * 256, (float *)workspace, mode, cu);
-            }
+        if (dh == 64) {
+            allow_lds_attn(attn_bwd_mfma_kernel<64>, shm2);
+            attn_bwd_mfma_kernel<64><<<B * H, 512, shm2, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale_s, nblk, (float *)workspace, cu);
+        } else {
+            allow_lds_attn(attn_bwd_mfma_kernel<32>, shm2);
+            attn_bwd_mfma_kernel<32><<<B * H, 512, shm2, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale_s, nblk, (float *)workspace, cu);
         }
         return b4c_check_launch("attn_bwd_mfma (key blocks)");
     }
@@ -818,10 +831,10 @@ int b4c_attn_bwd_mfma(const void *qkv, int ld_qkv, const uint8_t *key_pad, const
     }
     if (dh == 64) {
         allow_lds_attn(attn_bwd_mfma_kernel<64>, shm);
-        attn_bwd_mfma_kernel<64><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, 0, nullptr, 0, cu);
+        attn_bwd_mfma_kernel<64><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, 1, nullptr, cu);
     } else {
         allow_lds_attn(attn_bwd_mfma_kernel<32>, shm);
-        attn_bwd_mfma_kernel<32><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, 0, nullptr, 0, cu);
+        attn_bwd_mfma_kernel<32><<<B * H, 512, shm, st>>>((const bf16_t *)qkv, ld_qkv, key_pad, (const bf16_t *)o, ld_o, (const bf16_t *)d_o, ld_do, lse, (bf16_t *)dqkv, ld_dqkv, S, H, scale, 1, nullptr, cu);
     }
     return b4c_check_launch("attn_bwd_mfma");
 }

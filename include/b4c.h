@@ -171,8 +171,8 @@ int b4c_attn_bwd(const void *qkv, int ld_qkv, const uint8_t *key_pad, const void
                  const void *d_o, int ld_do, const float *lse, float *delta, void *dqkv, int ld_dqkv, int B,
                  int S, int H, int dh, int dtype, void *stream);
 
-/* same with a caller-provided scratch: bf16 sequences of 256 < S <= 512 run the MFMA backward once per block of 256 keys
- * and sum the partial dQ in an fp32 accumulator of b4c_attn_bwd_workspace_bytes(B, S, H, dh, dtype) bytes (0 when no
+/* same with a caller-provided scratch: bf16 sequences of 256 < S <= 512 run the MFMA backward block by block of 256 keys
+ * (one launch) and sum the partial dQ in an fp32 accumulator of b4c_attn_bwd_workspace_bytes(B, S, H, dh, dtype) bytes (0 when no
  * workspace is needed).  Without it those shapes fall back to the fp32-math row kernels (a notice is printed once). */
 int64_t b4c_attn_bwd_workspace_bytes(int B, int S, int H, int dh, int dtype);
 int b4c_attn_bwd_ws(const void *qkv, int ld_qkv, const uint8_t *key_pad, const void *o, int ld_o,
