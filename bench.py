@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--d_model', type=int, default=128)
     ap.add_argument('--layers', type=int, default=4)
     ap.add_argument('--heads', type=int, default=2)
+    ap.add_argument('--dff', type=int, default=100, help='encoder FFN width: 100 = the reference (hard-coded, clickstream_transformer.py:225); '
+                    '4 * d_model (512 at C2) = the BERT4Rec paper\'s width (SURVEY D4)')
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--n_batches', type=int, default=8, help='distinct resident batches cycled through')
@@ -99,7 +101,7 @@ def build_model(a, device):
         dims = {f: a.d_model for f in dims}
     model = ClickstreamTransformer(chains, vocabs, dims, head,
                                    value_to_head='[MASK]', num_encoder_layers=a.layers, num_attention_heads=a.heads,
-                                   dropout_rate=a.dropout, feature_combine='sum' if a.feature_sum else 'concat',
+                                   dropout_rate=a.dropout, feature_combine='sum' if a.feature_sum else 'concat', encoder_ff_dim=a.dff,
                                    compute_dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
     return model.to(device)
 
@@ -163,7 +165,7 @@ def cpu_baseline(a):
     threads = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
     rng = np.random.default_rng(1234)
-    P = nr.init_params(rng, {'items': a.vocab + 11}, {'items': a.d_model}, a.layers, 100, [1024, 512, 256, 128], a.vocab)
+    P = nr.init_params(rng, {'items': a.vocab + 11}, {'items': a.d_model}, a.layers, a.dff, [1024, 512, 256, 128], a.vocab)
     P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in P.items()}
     m = {k: torch.zeros_like(v) for k, v in P.items()}
     vv = {k: torch.zeros_like(v) for k, v in P.items()}
@@ -346,14 +348,46 @@ class Training:
         return loss
 
 
+def visible_gpus():
+    """Number of GPUs this process may use, WITHOUT bringing up the HIP / HSA runtime (the launcher must stay a process that has
+    never touched the GPU): the KFD topology nodes that have SIMDs (CPUs are nodes too, with simd_count 0), narrowed by the
+    *_VISIBLE_DEVICES variables the runtime honours.  None when the topology cannot be read."""
+    import glob
+    n = 0
+    nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            with open(f) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get('simd_count', '0')) > 0:
+            n += 1
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
+
+
 def self_launch(a):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process -- which has made no GPU call -- starts
     the N ranks (torch.distributed.run on 127.0.0.1, one process per GPU over RCCL) as a child, passes its output through
     and exits with its code.  Fewer devices than ranks (a one-GPU box): the ranks share the devices round-robin and the
-    exchange goes over gloo -- a rehearsal of the N-rank path, labelled as such in the line's `config.parallelism`."""
+    exchange goes over gloo -- a rehearsal of the N-rank path, labelled as such in the line's `config.parallelism`.
+    Under a profiler's preloaded library the GPU is initialised before this program's first line: a launcher that starts
+    other programs is then exactly the hop the pool forbids -- profiled runs are single-rank."""
     import socket
     import subprocess
-    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    pre = ' '.join(os.environ.get(k, '') for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB'))
+    if 'rocprof' in pre or any(k.startswith('ROCPROFILER_') or k.startswith('ROCPROF_') for k in os.environ):
+        raise SystemExit('bench.py: --gpus %d under a profiler: profiled runs are single-rank (start the ranks with '
+                         'torch.distributed.run yourself and profile one of them)' % a.gpus)
+    ndev = visible_gpus()
+    if ndev is None:                          # no KFD topology to read: let the ranks find out (they fall back to gloo themselves)
+        ndev = a.gpus
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
@@ -449,10 +483,11 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if a.dtype == 'bf16' else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BERT4Rec Cloze training step: vocab=%d seq_len=%d d_model=%d layers=%d heads=%d dff=100 '
+            'config': {'workload': 'BERT4Rec Cloze training step: vocab=%d seq_len=%d d_model=%d layers=%d heads=%d dff=%d%s '
                                    'head=[1024,512,256,128]->V%s batch=%d seq/GPU x %d GPU, 10 masked/seq, dropout=%.2f, Zipf(1.1) ids, '
                                    '%d resident batches, [MASK] indices %s%s; encoder on %s'
-                                   % (a.vocab, a.seq, a.d_model, a.layers, a.heads,
+                                   % (a.vocab, a.seq, a.d_model, a.layers, a.heads, a.dff,
+                                      ' (reference-hard-coded)' if a.dff == 100 else ' (NOT the reference\'s 100: the paper-faithful width)',
                                       ' (sampled softmax, %d shared log-uniform negatives)' % a.sampled if a.sampled else '',
                                       a.batch, world, a.dropout, len(batches),
                                       'precomputed on the host' if a.host_flat_idx else 'generated on the device inside the step',

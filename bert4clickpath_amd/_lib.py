@@ -143,8 +143,23 @@ def lib():
             'b4c_rows_gather_f32': (i32, [vp, i32, vp, vp, i32, i64, i32, vp]),
             'b4c_rows_scatter_add_f32': (i32, [vp, i32, vp, vp, i32, i64, i32, vp]),
         }
+        # The argument lists below belong to ONE ABI version: a library that exports the same names with older lists would
+        # take a device pointer for a stream and fault on the GPU.  Compare before anything is bound.
+        try:
+            L.b4c_abi_version.restype = i32
+            have = int(L.b4c_abi_version())
+        except AttributeError:
+            raise B4CError('%s does not export b4c_abi_version: not a libb4c_hip.so of this tree; rebuild it '
+                           '(`make -C bert4clickpath_amd/csrc`)' % LIB_PATH) from None
+        if have != ABI_VERSION:
+            raise B4CError('%s is ABI %d, this binding expects ABI %d; rebuild it (`make -C bert4clickpath_amd/csrc`)'
+                           % (LIB_PATH, have, ABI_VERSION))
         for name, (res, args) in sig.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                raise B4CError('%s (ABI %d) does not export %s; rebuild it (`make -C bert4clickpath_amd/csrc`)'
+                               % (LIB_PATH, have, name)) from None
             fn.restype = res
             fn.argtypes = args
         _lib = L

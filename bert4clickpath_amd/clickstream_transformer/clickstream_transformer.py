@@ -97,8 +97,11 @@ class TransformerInputPrep:
 class ClickstreamTransformer(nn.Module):
     def __init__(self, sequential_input_config, feature_vocabs, embedding_dims, head_unit, segment_to_head=None,
                  value_to_head=None, num_encoder_layers=1, num_attention_heads=1, dropout_rate=0.1,
-                 compute_dtype=torch.float32, feature_combine='concat', **kwargs):
+                 compute_dtype=torch.float32, feature_combine='concat', encoder_ff_dim=100, **kwargs):
         super().__init__()
+        # encoder_ff_dim: the reference hard-codes the FFN width 100 in this constructor (:225) and takes it as an argument of the
+        # inner API (transformer.Transformer); 4 * d_model is the BERT4Rec paper's width.  Default = the reference's.
+        self.encoder_ff_dim = int(encoder_ff_dim)
         self.feature_combine = feature_combine      # 'sum': the features' embedding rows are added (extension, transformer.Transformer)
         self.sequential_input_config = sequential_input_config
         self.feature_vocabs = feature_vocabs
@@ -117,7 +120,7 @@ class ClickstreamTransformer(nn.Module):
         self.transformer = Transformer(
             embedding_sizes={f: self.embedding_sizes[f] for f in self.embedding_dims.keys()},
             embedding_dims=self.embedding_dims, num_layers=num_encoder_layers,
-            num_attention_heads=num_attention_heads, encoder_ff_dim=100,   # hard-coded in the reference (:225)
+            num_attention_heads=num_attention_heads, encoder_ff_dim=self.encoder_ff_dim,   # 100: hard-coded in the reference (:225)
             dropout_rate=dropout_rate, compute_dtype=compute_dtype, feature_combine=feature_combine)
         if hasattr(self.head, 'tie') and getattr(self.head, '_table', None) is None:
             # tied-weight head: project back onto the FIRST embedded feature's table (the items)
@@ -139,7 +142,8 @@ class ClickstreamTransformer(nn.Module):
                 'embedding_dims': self.embedding_dims, 'head_unit': self.head, 'segment_to_head': self.segment_to_head,
                 'value_to_head': self.value_to_head, 'num_encoder_layers': self.num_encoder_layers,
                 'num_attention_heads': self.num_attention_heads, 'dropout_rate': self.dropout_rate,
-                **({'feature_combine': 'sum'} if self.feature_combine == 'sum' else {})}
+                **({'feature_combine': 'sum'} if self.feature_combine == 'sum' else {}),
+                **({'encoder_ff_dim': self.encoder_ff_dim} if self.encoder_ff_dim != 100 else {})}
 
     @staticmethod
     def _create_lookup_tables(vocabularies, tokens_to_prepend=None):
@@ -410,9 +414,9 @@ class ClickstreamTransformer(nn.Module):
 
     @torch.no_grad()
     def predict_topk(self, inputs, k, labels=None, flat_idx=None, packed=None, n_real_tokens=None):
-        """Top-k item ids (label space) at every masked position, ranked over all V items.  Ranks the
-        logits (softmax is monotone); returns (topk_idx (R,k) int32, hit (R,), ndcg (R,)) -- the
-        latter two when labels are given."""
+        """Top-k item ids (label space) at every masked position, ranked over all V items: the fp32 path ranks the fp32
+        probabilities as the reference's metrics do (utils.py:176, 245), the bf16 path the fp32 logits (head.SoftMaxHead.topk);
+        returns (topk_idx (R,k) int32, hit (R,), ndcg (R,)) -- the latter two when labels are given."""
         rows, _ = self._masked_rows(inputs, False, flat_idx, pack=self._use_packed(inputs, packed, n_real_tokens),
                                     n_real_tokens=n_real_tokens)
         lab = None
@@ -424,7 +428,10 @@ class ClickstreamTransformer(nn.Module):
         if hasattr(self.head, 'topk'):           # logits-free where the head's kernels cover it (head.SoftMaxHead.topk)
             idx, hit, ndcg = self.head.topk(rows, k, lab)
         else:
-            idx, hit, ndcg = ops.topk_rows(self.head.logits(rows, out_fp32=True), self.head.output_vocab_size, k, lab)
+            scores = self.head.logits(rows, out_fp32=True)
+            if rows.dtype == torch.float32:
+                scores = ops.softmax_rows(scores, self.head.output_vocab_size)
+            idx, hit, ndcg = ops.topk_rows(scores, self.head.output_vocab_size, k, lab)
         if self._packed is not None and n_real_tokens is not None:
             # a caller-given token count that the device's own contradicts: ids -1, hit / ndcg NaN (no read-back)
             flag = self._packed.ids_packed

@@ -102,8 +102,14 @@ class SoftMaxHead(nn.Module):
 
     def topk(self, x2d, k, labels_i32=None, trunk_done=False):
         """-> (ids [R, k] int32, hit [R], ndcg [R]) of the V scores of every row, ranked as tf.math.top_k ranks (ties -> lower
-        index first).  bf16 / 64- or 128-wide projection input: the scores never reach memory (b4c_vocab_topk); rows with
-        mass ties at the selection threshold, and every other configuration, are ranked on materialised fp32 logits."""
+        index first).
+        fp32 (the parity path): what is ranked is what the reference ranks -- the fp32 softmax OUTPUT (utils.py:176, 245 call
+        tf.math.top_k on y_pred, the head's probabilities): distinct logits whose fp32 probabilities round to the same value
+        tie there and go to the lower index.
+        bf16 (the throughput path): the fp32 LOGITS are ranked (softmax is monotone; no probability is ever formed) -- 64- or
+        128-wide projection input: the scores never reach memory (b4c_vocab_topk); rows with mass ties at the selection
+        threshold, and every other configuration, on materialised fp32 logits.  Logits that differ although their
+        probabilities would tie are ordered strictly: a documented deviation (tests/test_gpu_rank.py)."""
         V = self.output_vocab_size
         with torch.no_grad():
             h = x2d if trunk_done else self.trunk(x2d)
@@ -119,7 +125,10 @@ class SoftMaxHead(nn.Module):
                     if hit is not None:
                         hit[bad], ndcg[bad] = h2, n2
                 return idx, hit, ndcg
-            return ops.topk_rows(self._project(h, out_fp32=True), V, k, labels_i32)
+            scores = self._project(h, out_fp32=True)
+            if h.dtype == torch.float32:
+                scores = ops.softmax_rows(scores, V)
+            return ops.topk_rows(scores, V, k, labels_i32)
 
     def forward(self, inputs, **kwargs):
         """inputs (B, M, d) -> probabilities (B, M, V), materialised as the reference does."""

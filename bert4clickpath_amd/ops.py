@@ -226,7 +226,23 @@ def embed_concat_pe_fwd(ids_list, tables, pe, scale, rate, seed, dtype, packed=N
 
 
 library_sort = True      # b4c_sort_ids (6 - 9 launches) instead of torch.sort (14 launches through rocPRIM)
-_sort_ws = {}
+
+
+# ---- scratch memory the library's entry points take from the caller -----------------------------------------------------
+# One growing buffer per (purpose, device, launch stream): launches of ONE stream use it one after the other, so the stream
+# order keeps them apart; two models that train on streams of their own get buffers of their own (a buffer shared across
+# streams would be written by two kernels at once).  Nothing here belongs to a training step: the buffers hold no results.
+_workspaces = {}
+
+
+def _workspace(kind, device, need, floor=0):
+    """uint8 scratch tensor of at least `need` bytes for launches of `kind` on `device`'s current stream"""
+    key = (kind, device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(int(need), int(floor), 1), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
 
 
 def _sort_order(ids, n_rows):
@@ -242,10 +258,7 @@ def _sort_order(ids, n_rows):
         if n == 0:
             return order
         need = L.lib().b4c_sort_ids_workspace_bytes(n, n_rows)
-        ws = _sort_ws.get(ids.device)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=ids.device)
-            _sort_ws[ids.device] = ws
+        ws = _workspace('sort', ids.device, need, 1 << 20)
         L.check(L.lib().b4c_sort_ids(_p(flat), n, n_rows, _p(order), ws.data_ptr(), ws.numel(), _st()), 'sort_ids')
         return order
     flat = ids.view(-1).clamp(0, n_rows - 1)
@@ -372,7 +385,6 @@ def gemm_tn(a, g, K, N, want_bias=True, into=None):
     return _gemm_tn_impl(a, g, K, N, want_bias, into)
 
 
-_tn_ws = {}      # device -> scratch for the split partial tiles of gemm_tn (shared by all calls of a stream)
 tn_deterministic = True     # False: no workspace, partial tiles are added with float atomics
 
 
@@ -382,10 +394,7 @@ def _tn_workspace(a, M, K, N):
     need = L.lib().b4c_gemm_tn_workspace_bytes(M, K, N, dt_code(a.dtype))
     if need == 0:
         return None, 0
-    ws = _tn_ws.get(a.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=a.device)
-        _tn_ws[a.device] = ws
+    ws = _workspace('gemm_tn', a.device, need, 32 << 20)      # the split partial tiles of gemm_tn
     return ws.data_ptr(), ws.numel()
 
 
@@ -419,27 +428,28 @@ def _gemm_tn_impl(a, g, K, N, want_bias, into):
 # consumes them), so in arena mode they are queued and launched together (b4c_gemm_tn_group: one main + one reduce
 # kernel per layer instead of four of each, and ~6x less partial-tile traffic).
 grouped_dw = True
-_pending_dw = []        # (a, g, K, N, dWs, dbs, params) -- the tensors are kept alive until the flush
 
 
-def queue_dw(a, g, K, N, dWs, dbs, params):
-    """dW_i += a^T g (column segments), db_i += colsum(g) -- now or with the next flush_pending_dw()."""
-    ok = grouped_dw and a.dtype == torch.bfloat16 and a.stride(0) % 8 == 0 and g.stride(0) % 8 == 0 and \
+def queue_dw(c, a, g, K, N, dWs, dbs, params):
+    """dW_i += a^T g (column segments), db_i += colsum(g) -- now or with the next flush_pending_dw(c).  `c`: the ArenaContext
+    of the step in flight (the queue lives there: a step that fails leaves nothing behind for the next one)."""
+    ok = c is not None and grouped_dw and a.dtype == torch.bfloat16 and a.stride(0) % 8 == 0 and g.stride(0) % 8 == 0 and \
         a.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and a.shape[0] >= 4096
     if not ok:
         gemm_tn(a, g, K, N, into=(dWs, dbs))
         _ready(*params)
         return
-    if _pending_dw and (_pending_dw[0][0].shape[0] != a.shape[0] or len(_pending_dw) == 8):
-        flush_pending_dw()
-    _pending_dw.append((a, g, K, N, dWs, dbs, params))
+    q = c.pending_dw
+    if q and (q[0][0].shape[0] != a.shape[0] or len(q) == 8):
+        flush_pending_dw(c)
+    q.append((a, g, K, N, dWs, dbs, params))
 
 
-def flush_pending_dw():
-    if not _pending_dw:
+def flush_pending_dw(c):
+    if c is None or not c.pending_dw:
         return
-    items = list(_pending_dw)
-    del _pending_dw[:]
+    items = list(c.pending_dw)
+    del c.pending_dw[:]
     M = items[0][0].shape[0]
     descs = (L.TNDesc * len(items))()
     nbytes = flops = 0
@@ -452,11 +462,7 @@ def flush_pending_dw():
         nbytes += M * (K + N) * a.element_size() + K * N * 4
         flops += 2 * M * K * N
     need = L.lib().b4c_gemm_tn_group_workspace_bytes(descs, len(items), M)
-    dev = items[0][0].device
-    ws = _tn_ws.get(dev)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=dev)
-        _tn_ws[dev] = ws
+    ws = _workspace('gemm_tn', items[0][0].device, need, 32 << 20)
     with _record('gemm_tn' if 2 * M >= rec_hints.get('token_rows', 0) else 'gemm_tn_rows', nbytes, flops):
         L.check(L.lib().b4c_gemm_tn_group(descs, len(items), M, L.BF16, ws.data_ptr(), ws.numel(), _st()), 'gemm_tn_group')
     for it in items:
@@ -475,6 +481,9 @@ flash_ce = True          # bf16 training: vocabulary projection + CE without the
 class ArenaContext:
     def __init__(self):
         self.grad_ready_cb = None     # parallel.GradReducer: called with each parameter whose gradient has just been produced
+        # weight-gradient GEMMs of the layer in flight, queued for one grouped launch (queue_dw / flush_pending_dw): the
+        # entries hold that step's activations and gradient tensors
+        self.pending_dw = []
         # side-stream work (the vocabulary head's background dW sweep, see "Vocabulary-head weight gradient BESIDE ...")
         self.queue = []               # closures to run on the side stream, in order: pieces of sweeps, label terms, event records
         self.pending = []             # (event recorded on the side stream, parameters whose gradient it completes, main stream)
@@ -482,20 +491,22 @@ class ArenaContext:
         self.counting = False         # inside a backward pass that feeds the queue
         self.kicks = 0                # attention-backward launches seen in this pass
         self.kicks_expected = 0       # ... in the previous backward pass: the plan of the next one
+        self.side_launched = None     # device whose side stream has been given work since the last join (None: nothing in flight)
 
     def reset(self):
-        """Drop side-stream work that a failed step left behind (closures hold that step's tensors and would add a stale
-        gradient into the next one).  Called at the start of every step: FlatArena.zero_grad, GradReducer.begin_backward."""
-        global _active_ctx
+        """Drop what a failed step left behind: queued weight-gradient GEMMs and side-stream closures hold that step's tensors
+        and would add a stale gradient into the next one; side-stream kernels that step ALREADY launched (the first piece of the
+        background sweep goes out before anything can fail) add into the gradient arena with float atomics, so the stream that
+        is about to zero the arena waits for them first.  Called at the start of every step: FlatArena.zero_grad,
+        GradReducer.begin_backward."""
+        del self.pending_dw[:]
         del self.queue[:]
+        if self.side_launched is not None:
+            torch.cuda.current_stream(self.side_launched).wait_stream(_side_stream(self.side_launched))
+            self.side_launched = None
         del self.pending[:]
         self.slots = self.kicks = 0
         self.counting = False
-        if _active_ctx is self:
-            _active_ctx = None
-
-
-_active_ctx = None        # the context whose backward pass is feeding side-stream work right now (attn_bwd -> _background_kick)
 
 
 def arena_context(*params):
@@ -576,19 +587,12 @@ def attn_fwd(qkv, key_pad, B, S, H, dh, cu=None):
     return o, lse
 
 
-_attn_ws = {}
-
-
-def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, cu=None):
+def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, cu=None, actx=None):
+    """actx: the ArenaContext of the training step in flight (its background work gets a launch opportunity behind this kernel)"""
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     need = L.lib().b4c_attn_bwd_workspace_bytes(B, S, H, dh, dt_code(qkv.dtype))     # > 0 only for bf16 256 < S <= 512
-    ws = None
-    if need:
-        ws = _attn_ws.get(qkv.device)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
-            _attn_ws[qkv.device] = ws
+    ws = _workspace('attn_bwd', qkv.device, need) if need else None
     T_tok = qkv.shape[0]
     pairs = rec_hints.get('sum_len_sq', T_tok * S) if cu is not None else T_tok * S
     with _record('attn_bwd', T_tok * 8 * H * dh * qkv.element_size(), 10 * pairs * H * dh):
@@ -600,7 +604,7 @@ def attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, cu=None):
             L.check(L.lib().b4c_attn_bwd_varlen(_p(qkv), qkv.stride(0), _p(key_pad), _p(cu), _p(o), o.stride(0), _p(d_o),
                                                 d_o.stride(0), _p(lse), _p(delta), _p(dqkv), dqkv.stride(0), B, S, H, dh, _p(ws),
                                                 need, dt_code(qkv.dtype), _st()), 'attn_bwd_varlen')
-    _background_kick()      # the next piece of the vocabulary head's dW sweep starts when this kernel has left the CUs
+    _background_kick(actx)      # the next piece of the vocabulary head's dW sweep starts when this kernel has left the CUs
     return dqkv
 
 
@@ -775,21 +779,13 @@ def relu_gate(g, act):
     return out
 
 
-_vce_ws = {}
-
-
 def vocab_ce_supported(h, K):
     """The logits-free path: bf16 head input of width 64 / 128 (include/b4c.h b4c_vocab_ce_fwd)."""
     return h.dtype == torch.bfloat16 and K in (64, 128) and h.shape[1] == K
 
 
 def _vce_workspace(h, R, V, K):
-    need = L.lib().b4c_vocab_ce_workspace_bytes(R, V, K)
-    ws = _vce_ws.get(h.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=h.device)
-        _vce_ws[h.device] = ws
-    return ws
+    return _workspace('vocab_ce', h.device, L.lib().b4c_vocab_ce_workspace_bytes(R, V, K))
 
 
 def vocab_ce_fwd(h, wt, bias, labels_i32, grad_scale, V, variant=L.CE_TF):
@@ -871,16 +867,10 @@ def vocab_softmax(h, wt, bias, Np, V):
 
 
 fused_rank = True      # bf16 scoring path: ranks / top-k ids without the (R x V) scores in memory (b4c_vocab_rank, b4c_vocab_topk)
-_rank_ws = {}
 
 
 def _rank_workspace(h, R, V, K):
-    need = L.lib().b4c_vocab_rank_workspace_bytes(R, V, K)
-    ws = _rank_ws.get(h.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=h.device)
-        _rank_ws[h.device] = ws
-    return ws
+    return _workspace('vocab_rank', h.device, L.lib().b4c_vocab_rank_workspace_bytes(R, V, K))
 
 
 def vocab_rank(h, wt, bias, labels_i32, V):
@@ -951,15 +941,15 @@ class VocabSoftmaxFn(torch.autograd.Function):
         g = _rows_ok(g, probs.dtype)
         dlogits = softmax_rows_bwd(probs, g, ctx.V)
         _, wc, _ = pack.get(h.dtype, h.shape[1], True)
-        if _inplace_ok(kernel, bias):
-            queue_dw(h, dlogits, pack.K, pack.N, [kernel.grad], [bias.grad], (kernel, bias))
+        actx = arena_context(kernel, bias)
+        if actx is not None:
+            queue_dw(actx, h, dlogits, pack.K, pack.N, [kernel.grad], [bias.grad], (kernel, bias))
             dW = db = None
         else:
             dW, db = gemm_tn(h, dlogits, pack.K, pack.N)
         with _timed('vocab_proj_dx'):
             dh = gemm_nt(dlogits, wc, h.shape[1])
-        if dW is None:
-            flush_pending_dw()
+        flush_pending_dw(actx)
         return dh, None, None, dW, db
 
 
@@ -1180,11 +1170,11 @@ class EmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _):
-        flush_pending_dw()
-        if dout is None:
-            return (None,) * (6 + 2 * ctx.n)
         saved = ctx.saved_tensors
         ids, tables = list(saved[:ctx.n]), list(saved[ctx.n:])
+        flush_pending_dw(getattr(tables[0], '_b4c_ctx', None))
+        if dout is None:
+            return (None,) * (6 + 2 * ctx.n)
         dout = dout.reshape(ids[0].shape[0], ids[0].shape[1], -1)
         if _inplace_ok(*tables):
             embed_concat_pe_bwd(ids, tables, dout.contiguous(), ctx.scale, ctx.rate, ctx.seed, into=[t.grad for t in tables])
@@ -1229,26 +1219,27 @@ class AttnBlockFn(torch.autograd.Function):
         B, S, H, dh, rate, seed = ctx.dims
         wq, bq, wk, bk, wv, bv, wo, bo, gam, bet = ctx.params
         d = H * dh
-        inplace = _inplace_ok(*ctx.params)
+        actx = arena_context(*ctx.params)
+        inplace = actx is not None
         dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
                                                           into=(gam.grad, bet.grad) if inplace else None)
         _, wc_o, _ = pk_o.get(x.dtype, d, True)
         _, wc_qkv, _ = pk_qkv.get(x.dtype, d, True)
         if inplace:
-            queue_dw(o, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
+            queue_dw(actx, o, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
         else:
             dWo, dbo = gemm_tn(o, dy, d, d)
         d_o = gemm_nt(dy, wc_o, d)
         with _timed('attn_bwd'):
-            dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, ctx.cu)
+            dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, ctx.cu, actx)
         if inplace:
-            queue_dw(x, dqkv, d, 3 * d, [wq.grad, wk.grad, wv.grad], [bq.grad, bk.grad, bv.grad], (wq, bq, wk, bk, wv, bv))
+            queue_dw(actx, x, dqkv, d, 3 * d, [wq.grad, wk.grad, wv.grad], [bq.grad, bk.grad, bv.grad], (wq, bq, wk, bk, wv, bv))
         else:
             dWqkv, dbqkv = gemm_tn(x, dqkv, d, 3 * d)
         dx = gemm_nt(dqkv, wc_qkv, d, residual=dz)
         if inplace:
             _ready(gam, bet)
-            flush_pending_dw()          # this layer's four weight gradients (two queued by FFNBlockFn.backward) in one launch
+            flush_pending_dw(actx)      # this layer's four weight gradients (two queued by FFNBlockFn.backward) in one launch
             return (dx,) + (None,) * 20
         (gq, gk, gv), (gbq, gbk, gbv) = pk_qkv.split_grads(dWqkv, dbqkv)
         return (dx, None, gq, gbq, gk, gbk, gv, gbv, dWo, dbo, dgamma, dbeta) + (None,) * 9
@@ -1307,21 +1298,22 @@ class MQAttnBlockFn(torch.autograd.Function):
         B, max_len, H, dh, rate, seed = ctx.dims
         wq, bq, wk, bk, wv, bv, wo, bo, gam, bet = ctx.params
         d = H * dh
-        inplace = _inplace_ok(*ctx.params)
+        actx = arena_context(*ctx.params)
+        inplace = actx is not None
         dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
                                                           into=(gam.grad, bet.grad) if inplace else None)
         _, wc_o, _ = pk_o.get(x.dtype, d, True)
         _, wc_qkv, _ = pk_qkv.get(x.dtype, d, True)
         if inplace:
-            queue_dw(o_m, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
+            queue_dw(actx, o_m, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
         else:
             dWo, dbo = gemm_tn(o_m, dy, d, d)
         d_o = gemm_nt(dy, wc_o, d)
         dq, dkv = attn_mq_bwd(q_m, kv, cu, moff, o_m, d_o, lse, B, max_len, H, dh, key_pad)
         if inplace:
-            queue_dw(x_m, dq, d, d, [wq.grad], [bq.grad], (wq, bq))
-            flush_pending_dw()                      # (the query-row problems have R rows, the key / value problem T)
-            queue_dw(x, dkv, d, 2 * d, [wk.grad, wv.grad], [bk.grad, bv.grad], (wk, bk, wv, bv))
+            queue_dw(actx, x_m, dq, d, d, [wq.grad], [bq.grad], (wq, bq))
+            flush_pending_dw(actx)                  # (the query-row problems have R rows, the key / value problem T)
+            queue_dw(actx, x, dkv, d, 2 * d, [wk.grad, wv.grad], [bk.grad, bv.grad], (wk, bk, wv, bv))
         else:
             dWq, dbq = gemm_tn(x_m, dq, d, d)
             dWkv, dbkv = gemm_tn(x, dkv, d, 2 * d)
@@ -1330,7 +1322,7 @@ class MQAttnBlockFn(torch.autograd.Function):
         rows_add_(dx, midx, dx_m)
         if inplace:
             _ready(gam, bet)
-            flush_pending_dw()
+            flush_pending_dw(actx)
             return (dx,) + (None,) * 22
         dWk, dWv = dWkv[:, :d].contiguous(), dWkv[:, d:].contiguous()
         dbk, dbv = dbkv[:d].contiguous(), dbkv[d:].contiguous()
@@ -1368,18 +1360,19 @@ class FFNBlockFn(torch.autograd.Function):
         rate, seed = ctx.dims
         w1, b1, w2, b2, gam, bet = ctx.params
         d, Fp = x.shape[1], h.shape[1]
-        inplace = _inplace_ok(*ctx.params)
+        actx = arena_context(*ctx.params)
+        inplace = actx is not None
         dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
                                                           into=(gam.grad, bet.grad) if inplace else None)
         _, wc1, _ = pk1.get(x.dtype, d, True)
         _, wc2, _ = pk2.get(x.dtype, Fp, True)
         if inplace:
-            queue_dw(h, dy, pk2.K, d, [w2.grad], [b2.grad], (w2, b2))
+            queue_dw(actx, h, dy, pk2.K, d, [w2.grad], [b2.grad], (w2, b2))
         else:
             dW2, db2 = gemm_tn(h, dy, pk2.K, d)
         dh = gemm_nt(dy, wc2, Fp, gate=h)
         if inplace:
-            queue_dw(x, dh, d, pk1.N, [w1.grad], [b1.grad], (w1, b1))
+            queue_dw(actx, x, dh, d, pk1.N, [w1.grad], [b1.grad], (w1, b1))
         else:
             dW1, db1 = gemm_tn(x, dh, d, pk1.N)
         dx = gemm_nt(dh, wc1, d, residual=dz)
@@ -1429,7 +1422,8 @@ class MLPFn(torch.autograd.Function):
         g = _rows_ok(g, acts[0].dtype)      # a pitched [R, Vp] view (empty_rows) is taken as it is
         grads = [None] * (2 * len(packs))
         dx = None
-        inplace = _inplace_ok(*ctx.params)
+        actx = arena_context(*ctx.params)
+        inplace = actx is not None
         for i in range(len(packs) - 1, -1, -1):
             a = acts[i]
             pk = packs[i]
@@ -1437,7 +1431,7 @@ class MLPFn(torch.autograd.Function):
             last = i == len(packs) - 1
             kern, bias = ctx.params[2 * i], ctx.params[2 * i + 1]
             if inplace:          # queued: the layers' weight gradients go out as one grouped launch below
-                queue_dw(a, g, pk.K, pk.N, [kern.grad], [bias.grad], (kern, bias))
+                queue_dw(actx, a, g, pk.K, pk.N, [kern.grad], [bias.grad], (kern, bias))
                 dW = db = None
             else:
                 dW, db = gemm_tn(a, g, pk.K, pk.N)
@@ -1445,8 +1439,7 @@ class MLPFn(torch.autograd.Function):
             with _timed('vocab_proj_dx' if last else 'head_mlp_dx'):
                 g = gemm_nt(g, wc, a.shape[1], gate=a if i > 0 else None)
             dx = g
-        if inplace:
-            flush_pending_dw()
+        flush_pending_dw(actx)
         return (dx, None, None, None) + tuple(grads)
 
 
@@ -1512,13 +1505,13 @@ def _background_slot(c):
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
     side.wait_stream(main)
+    c.side_launched = main.device
     with torch.cuda.stream(side):
         for _ in range(n):
             c.queue.pop(0)()
 
 
-def _background_kick():
-    c = _active_ctx
+def _background_kick(c):
     if c is None or not c.counting:
         return
     c.kicks += 1
@@ -1532,6 +1525,7 @@ def _background_drain(c):
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
     side.wait_stream(main)
+    c.side_launched = main.device
     with torch.cuda.stream(side):
         while c.queue:
             c.queue.pop(0)()
@@ -1542,20 +1536,21 @@ def join_side_work(c):
     then announced (grad-ready callback), each parameter once and only after EVERY piece has been waited for.  Runs at the
     end of every backward pass that used the side stream (autograd engine callback); optimizers and reducers call it too --
     it is a no-op when nothing is pending."""
-    global _active_ctx
     if c is None:
         return
     if c.counting:                  # the pass is over: its number of attention launches is the plan of the next one
         c.counting, c.kicks_expected = False, c.kicks
     _background_drain(c)            # fewer attention launches than planned: what is left of the sweeps goes out now
     c.slots = 0
-    if _active_ctx is c:
-        _active_ctx = None
     done, c.pending[:] = list(c.pending), []
     cur = torch.cuda.current_stream() if done else None
     for ev, _, stream in done:
         stream.wait_event(ev)               # the stream backward ran on (this may be the engine's thread, with another current stream)
         cur.wait_event(ev)
+    if c.side_launched is not None:
+        if not done:                        # (side-stream work without a closing event: wait for the stream itself)
+            torch.cuda.current_stream(c.side_launched).wait_stream(_side_stream(c.side_launched))
+        c.side_launched = None
     seen, params = set(), []
     for _, ps, _ in done:
         for p in ps:
@@ -1589,14 +1584,12 @@ def _dw_pieces(c, h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts):
 def _queue_background_dw(c, h, wt, b, labels_i32, rowscal, V, kernel, bias):
     """(inside a backward pass) the dW sweep of the vocabulary head as kicks + 1 background pieces: one now, one behind
     every attention backward launch of this pass"""
-    global _active_ctx
-    if _active_ctx is not None and (_active_ctx.counting or _active_ctx.queue):
-        join_side_work(_active_ctx)     # a second head in the same backward pass: finish the first one's sweep first
+    if c.counting or c.queue:
+        join_side_work(c)               # a second head on this arena in the same backward pass: finish the first one's sweep first
     cuts = _background_plan((V + 127) // 128, c.kicks_expected)
     c.queue.extend(_dw_pieces(c, h, wt, b, labels_i32, rowscal, V, kernel, bias, cuts))
     c.slots = len(c.queue)
     c.counting, c.kicks = True, 0
-    _active_ctx = c
     _background_slot(c)
     torch.autograd.Variable._execution_engine.queue_callback(lambda: join_side_work(c))
 

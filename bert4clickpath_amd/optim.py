@@ -68,7 +68,7 @@ class Adam:
         a = self.arena
         if not a.flat.is_cuda:
             raise ops.B4CError('Adam.step runs on the HIP device only')
-        ops.flush_pending_dw()
+        ops.flush_pending_dw(a.ctx)
         ops.join_side_work(a.ctx)
         self.iterations += 1
         t = self.iterations

@@ -24,7 +24,10 @@ def init_distributed(backend=None):
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
             # "nccl" IS RCCL on ROCm.  B4C_DIST_BACKEND=gloo rehearses the N > 1 path on fewer GPUs than ranks.
-            backend = os.environ.get('B4C_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            # More ranks than devices on this node (LOCAL_WORLD_SIZE ranks share them): RCCL refuses two ranks on one device.
+            local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+            fits = torch.cuda.is_available() and torch.cuda.device_count() >= local_world
+            backend = os.environ.get('B4C_DIST_BACKEND') or ('nccl' if fits else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -152,7 +155,7 @@ class GradReducer:
     def finish(self):
         """Call after loss.backward(): reduces whatever has not been launched and waits."""
         from . import ops
-        ops.flush_pending_dw()          # queued weight-gradient GEMMs (ops.queue_dw) must land before their bucket is reduced
+        ops.flush_pending_dw(self.arena.ctx)          # queued weight-gradient GEMMs (ops.queue_dw) must land before their bucket is reduced
         ops.join_side_work(self.arena.ctx)     # and so must what runs on the side stream (the vocabulary head's dW sweep)
         if self.world <= 1:
             self._touched.clear()

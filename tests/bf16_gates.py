@@ -40,12 +40,18 @@ class GateRecorder:
     def __exit__(self, *exc):
         self.ops.gemm_nt = self._orig
 
-    def relu_for(self, num_layers, n_head_layers, rows_flat, B, S):
+    def relu_for(self, num_layers, n_head_layers, rows_flat, B, S, token_rows=None):
         """-> relu(name, z) for the oracle.  patterns: one per FFN in layer order ([B*S or T or R rows][F padded]), then one per head
         trunk layer ([R][width]).  A rows-only last layer (masked-query form) recorded its pattern at the [MASK] rows only:
-        the other positions of that layer reach no output, the oracle keeps its own there."""
+        the other positions of that layer reach no output, the oracle keeps its own there.  token_rows (packed layout): the dense
+        position b*S + s of each of the T packed rows -- the pad positions, which the packed layout does not compute and whose
+        gradient is zero, keep the oracle's own pattern.
+        Every call also books, per layer, how far the device's pattern is from the oracle's own (self.flips[name] = (fraction of
+        the compared units whose gate differs, largest |pre-activation| among those units in the oracle / rms pre-activation)):
+        a kernel error that shifts pre-activations shows up here even when the loss barely moves (check_flips)."""
         pats = list(self.patterns)
         assert len(pats) == num_layers + n_head_layers, (len(pats), num_layers, n_head_layers)
+        self.flips = {}
 
         def relu(name, z):
             kind, i = name.split('.')
@@ -55,12 +61,36 @@ class GateRecorder:
                 F = z.shape[-1]
                 flat = own.reshape(-1, F).clone()
                 if pat.shape[0] == flat.shape[0]:
+                    rows = None
                     flat = pat[:, :F]
+                elif token_rows is not None and pat.shape[0] == token_rows.shape[0]:
+                    rows = token_rows
+                    flat[rows] = pat[:, :F]
                 else:                                   # rows-only pattern of the last layer
                     assert pat.shape[0] == rows_flat.shape[0], (pat.shape, rows_flat.shape)
-                    flat[rows_flat] = pat[:, :F]
+                    rows = rows_flat
+                    flat[rows] = pat[:, :F]
                 mask = flat.reshape(z.shape)
+                zc, oc, mc = z.detach().reshape(-1, F), own.reshape(-1, F), flat
+                if rows is not None:
+                    zc, oc, mc = zc[rows], oc[rows], mc[rows]
             else:
                 mask = pat[:, :z.shape[-1]]
+                zc, oc, mc = z.detach(), own, mask
+            diff = oc != mc
+            rms = float(zc.double().pow(2).mean().sqrt()) or 1.0
+            self.flips[name] = (float(diff.double().mean()), float(zc[diff].abs().max()) / rms if bool(diff.any()) else 0.0)
             return z * mask.to(z.dtype)
         return relu
+
+    def check_flips(self, max_fraction=0.02, max_preactivation=0.25):
+        """The device pass and the fp64 oracle may disagree on a ReLU gate only where the oracle's pre-activation is close to zero
+        (bf16 rounding of the layer's input moves it across): at most `max_fraction` of a layer's units (measured ~0.5 %), each
+        with |pre-activation| below `max_preactivation` x the layer's rms pre-activation.  A wrong bias or a dropped K slice
+        flips units far from zero and fails here, although the loss moves by less than its 2e-3 bound."""
+        assert self.flips, 'relu_for(...) has not been used by an oracle pass yet'
+        for name, (frac, far) in self.flips.items():
+            assert frac <= max_fraction, 'layer %s: %.2f %% of the ReLU gates differ from the fp64 oracle\'s' % (name, 100 * frac)
+            assert far <= max_preactivation, ('layer %s: a unit with |pre-activation| = %.3f x rms has the other gate than the '
+                                              'fp64 oracle' % (name, far))
+        return self.flips

@@ -84,7 +84,7 @@ def test_two_models_take_turns_in_one_process():
             lp.append(p.step_on(*batches[i % 2]))
         torch.cuda.synchronize()
         c = a.opt.arena.ctx
-        assert not c.queue and not c.pending and not c.counting and ops._active_ctx is None
+        assert not c.queue and not c.pending and not c.counting and not c.pending_dw and c.side_launched is None
         assert c.kicks_expected == (2 if ops.mq_last_layer else 3) and c.grad_ready_cb is None
         for kind, losses, model in (('arena', la, a.model), ('plain', lp, p.model)):
             l0, w0 = alone[kind]
@@ -193,7 +193,7 @@ def test_a_failed_backward_leaves_nothing_for_the_next_step(monkeypatch):
         monkeypatch.setattr(ops, 'attn_bwd', real)
         got.append(t.step_on(*batches[1]))               # zero_grad() -> ctx.reset(): the stale pieces never run
         torch.cuda.synchronize()
-        assert not ctx.queue and not ctx.pending and ops._active_ctx is None
+        assert not ctx.queue and not ctx.pending and not ctx.pending_dw and ctx.side_launched is None
         assert left > 0, 'the injected failure came before any side-stream work was queued: the test checks nothing'
         assert np.allclose(got, want, rtol=1e-4, atol=0), (got, want)
         w0 = _weights(ref.model)
@@ -202,5 +202,65 @@ def test_a_failed_backward_leaves_nothing_for_the_next_step(monkeypatch):
                 continue
             assert float((w - w0[n]).abs().max()) <= 2.5e-3, n
             assert float((w - w0[n]).norm()) <= 2e-2 * float(w0[n].norm()) + 1e-6, n
+    finally:
+        ops.background_workgroups = prev
+
+
+def test_a_failed_backward_leaves_no_queued_weight_gradient(monkeypatch):
+    """The grouped weight-gradient queue (ops.queue_dw: the dW GEMMs of a layer wait for one launch) belongs to the arena's
+    context: a backward pass that raises between FFNBlockFn.backward (queues two problems) and the flush at the end of the
+    attention block's backward leaves entries that hold the failed step's tensors; the next zero_grad() drops them.  The batch has
+    >= 4,096 token rows (below that queue_dw launches at once and there is nothing to leave behind).  The gradients of the
+    step after the failure are those of an undisturbed run -- bit for bit where the summation order is fixed."""
+    from bert4clickpath_amd import input_pipeline, ops
+    prev = ops.background_workgroups
+    ops.background_workgroups = 8
+    try:
+        def big(seed):
+            b = input_pipeline.synthetic_cloze_batch(256, S, V, seed=seed, min_len=20)
+            return (torch.from_numpy(b['ids'])[:, 2:S - 1].contiguous().cuda(), torch.from_numpy(b['labels_padded']).cuda(),
+                    int((b['ids'] != 0).sum()))
+        batches = [big(61), big(62)]
+        assert batches[1][2] >= 4096
+
+        def grads_of(t, batch):
+            t.opt.zero_grad()
+            loss = t.model.cloze_loss({'asin': batch[0]}, batch[1], training=True, max_masked_per_row=10, n_real_tokens=batch[2])
+            loss.backward()
+            ops.flush_pending_dw(t.opt.arena.ctx)
+            ops.join_side_work(t.opt.arena.ctx)
+            torch.cuda.synchronize()
+            return float(loss.detach()), {n: p.grad.detach().clone() for n, p in t.model.named_parameters()}
+
+        # (both models start from the same seeded weights and take no optimizer step first: an Adam step would carry the
+        # last-bit differences of the float-atomic reductions -- LayerNorm dgamma / dbeta, embedding run tails -- into the weights)
+        ref = _ArenaAdam(_model(6, 3))
+        want_loss, want = grads_of(ref, batches[1])
+
+        t = _ArenaAdam(_model(6, 3))
+        grads_of(t, batches[0])                       # one ordinary pass first: the context has a plan and a used side stream
+        real = ops.attn_bwd
+
+        def failing(*a, **k):
+            raise RuntimeError('injected: attention backward fails')
+        monkeypatch.setattr(ops, 'attn_bwd', failing)
+        t.opt.zero_grad()
+        loss = t.model.cloze_loss({'asin': batches[1][0]}, batches[1][1], training=True, max_masked_per_row=10,
+                                  n_real_tokens=batches[1][2])
+        with pytest.raises(RuntimeError, match='injected'):
+            loss.backward()
+        ctx = t.opt.arena.ctx
+        queued = len(ctx.pending_dw)
+        assert queued >= 2, 'the injected failure found no queued weight gradient: the test checks nothing (%d)' % queued
+        assert ctx.side_launched is not None          # the first piece of the background sweep is on the side stream already
+        monkeypatch.setattr(ops, 'attn_bwd', real)
+        got_loss, got = grads_of(t, batches[1])       # zero_grad() -> ctx.reset()
+        assert not ctx.pending_dw and not ctx.queue and not ctx.pending and ctx.side_launched is None
+        assert got_loss == want_loss
+        for n, g in want.items():
+            if '.ffn.' in n or '.mha.' in n:          # fixed-order GEMM reductions: a stale dW added in would show in every bit
+                if n.endswith('kernel'):
+                    assert torch.equal(got[n], g), n
+            assert float((got[n] - g).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-9, n
     finally:
         ops.background_workgroups = prev

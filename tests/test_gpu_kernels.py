@@ -487,11 +487,12 @@ def test_gemm_tn_group_matches_single_launches(ops):
         dW = a[:, :K].double().T @ g[:, :N].double()
         refs.append((dW, g[:, :N].double().sum(0)))
     assert ops.grouped_dw
+    c = ops.ArenaContext()             # the queue belongs to an arena's context (nothing process-wide)
     for it in items:
-        ops.queue_dw(*it)
-    assert len(ops._pending_dw) == 4
-    ops.flush_pending_dw()
-    assert not ops._pending_dw
+        ops.queue_dw(c, *it)
+    assert len(c.pending_dw) == 4
+    ops.flush_pending_dw(c)
+    assert not c.pending_dw
     for (a, g, K, N, dWs, dbs, _), (dW, db) in zip(items, refs):
         got = torch.cat(dWs, dim=1).double() - 1.0
         assert torch.equal(got, dW), (K, N)

@@ -254,7 +254,7 @@ def test_background_dw_sweep_gives_the_foreground_gradients():
                     torch.cuda.synchronize()
                     out.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
                     if mode:
-                        assert not c.queue and not c.counting and not c.pending and ops._active_ctx is None
+                        assert not c.queue and not c.counting and not c.pending and not c.pending_dw and c.side_launched is None
                         assert c.kicks_expected == (layers - 1 if ops.mq_last_layer else layers)
                 grads[(layers, mode)] = out
             for step in range(3):

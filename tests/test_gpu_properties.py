@@ -531,12 +531,13 @@ def test_embedding_stage_any_shape(ops, seed, B, S, n_feat, d8, combine, rate, d
 @settings(**dict(SET, max_examples=12))
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 12), S=st.integers(6, 70), L=st.integers(1, 3), H=st.sampled_from([1, 2, 4]),
        dh=st.sampled_from([16, 32, 64]), V=st.integers(12, 400), trunk=st.sampled_from([(16,), (32, 16), (8, 24, 16)]),
-       two=st.sampled_from(['one', 'concat', 'sum']), packed=st.booleans())
-def test_whole_model_random_configurations_fp32(ops, seed, B, S, L, H, dh, V, trunk, two, packed):
+       two=st.sampled_from(['one', 'concat', 'sum']), packed=st.booleans(), dff=st.sampled_from([100, 100, 8, 64, 200, 512]))
+def test_whole_model_random_configurations_fp32(ops, seed, B, S, L, H, dh, V, trunk, two, packed, dff):
     """ClickstreamTransformer + SoftMaxHead at randomly drawn sizes (layers, heads, head depth, sequence length, vocabulary, head
     trunk, one / two concatenated / two summed features), fp32: probabilities (1e-6), Cloze loss (1e-5) and every gradient
     (2e-4 of the tensor's largest entry) against the fp64 restatement of the reference dataflow.  (Head depths 16 / 32 / 64: the
-    attention kernels take {16, 32, 64, 128} and refuse anything else with an error.)"""
+    attention kernels take {16, 32, 64, 128} and refuse anything else with an error.)  The FFN width is part of the draw
+    (`encoder_ff_dim`, transformer.py:163-167: the reference's 100, widths that are and are not multiples of the tile sizes)."""
     from bert4clickpath_amd import input_pipeline
     from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
     from oracle import torch_ref as tr
@@ -551,7 +552,8 @@ def test_whole_model_random_configurations_fp32(ops, seed, B, S, L, H, dh, V, tr
         chains['actions'], vocabs['actions'] = ['act'], ['a%d' % i for i in range(Va)]
         dims = {'items': d, 'actions': d} if two == 'sum' else {'items': d - 8, 'actions': 8}
     m = ClickstreamTransformer(chains, vocabs, dims, SoftMaxHead(list(trunk), V), value_to_head='[MASK]', num_encoder_layers=L,
-                               num_attention_heads=H, dropout_rate=0.0, feature_combine='sum' if two == 'sum' else 'concat').cuda()
+                               num_attention_heads=H, dropout_rate=0.0, feature_combine='sum' if two == 'sum' else 'concat',
+                               encoder_ff_dim=dff).cuda()
     with torch.no_grad():
         for n, p in m.named_parameters():
             if n.endswith('bias') or n.endswith('beta'):
@@ -599,25 +601,34 @@ def test_whole_model_random_configurations_fp32(ops, seed, B, S, L, H, dh, V, tr
         disc = 1.0 / (np.log(np.arange(2, kk + 2, dtype=np.float32)) / np.log(np.float32(2.0)))
         assert np.allclose(ndcg.cpu().numpy(), (pos * disc[None]).sum(1), atol=1e-6)
     # the bf16 throughput path on the same weights and batch (MFMA attention needs head depth 32 / 64 for the padding-free
-    # layout): a coarse net for shape / stride / layout mistakes -- loss within 1 %, every sizeable gradient within 25 % L2
-    # (the tight bf16 bound needs the device pass's ReLU patterns: tests/bf16_gates.py)
+    # layout): loss within 1 %; gradients against the fp64 oracle evaluated with the DEVICE pass's ReLU on / off patterns
+    # (tests/bf16_gates.py: with the patterns shared the comparison measures the kernels' arithmetic, not which side of zero a
+    # pre-activation fell on), every sizeable tensor within 2 x the end-to-end bound -- the draw's tensors are small (8 - 32 unit
+    # trunks, a handful of rows), so a tensor's error is measured against the larger of its own norm and a tenth of the largest
     if dh in (32, 64) and labels.numel() and int((labels != -1).sum()) > 0:
+        from bf16_gates import BF16_GRAD_BOUND, GateRecorder
         m16 = ClickstreamTransformer(chains, vocabs, dims, SoftMaxHead(list(trunk), V), value_to_head='[MASK]', num_encoder_layers=L,
                                      num_attention_heads=H, dropout_rate=0.0, feature_combine='sum' if two == 'sum' else 'concat',
-                                     compute_dtype=torch.bfloat16).cuda()
+                                     compute_dtype=torch.bfloat16, encoder_ff_dim=dff).cuda()
         m16.load_state_dict(m.state_dict())
-        l16 = m16.cloze_loss(feats, labels, training=True, **kw)
+        with GateRecorder(ops) as rec:
+            l16 = m16.cloze_loss(feats, labels, training=True, **kw)
         l16.backward()
         assert abs(float(l16.detach()) - ref_v) < 1e-2 * max(1.0, abs(ref_v))
-        # (gradients only with enough masked rows to average over: one ReLU of the 16-wide trunk that flips between the bf16
-        # and the fp64 pass moves a one-row gradient by tens of per cent)
-        if int((labels != -1).sum()) >= 30:
-            gmax = max(float(P[n].grad.norm()) for n, _ in m16.named_parameters() if P[n].grad is not None)
-            for n, p in m16.named_parameters():
-                gr = P[n].grad
-                if gr is None or float(gr.norm()) < 0.1 * gmax:
-                    continue
-                assert float((p.grad.cpu().double() - gr).norm() / gr.norm()) < 0.5, n      # (a net for gross mistakes: those are 100 %)
+        token_rows = torch.from_numpy(np.flatnonzero(b['ids'].reshape(-1) != 0)).long()
+        relu = rec.relu_for(L, len(trunk), torch.from_numpy(b['flat_idx']).long(), B, S, token_rows=token_rows)
+        for v in P.values():
+            v.grad = None
+        ref2, _ = tr.model_loss(ids.cpu(), torch.from_numpy(b['labels']).long(), P, L, H, len(trunk), extra_features=extra,
+                                combine='sum' if two == 'sum' else 'concat', relu=relu)
+        ref2.backward()
+        gmax = max(float(P[n].grad.norm()) for n, _ in m16.named_parameters() if P[n].grad is not None)
+        for n, p in m16.named_parameters():
+            gr = P[n].grad
+            if gr is None or n.endswith('mha.wk.bias'):
+                continue
+            err = float((p.grad.cpu().double() - gr).norm())
+            assert err < 2 * BF16_GRAD_BOUND * max(float(gr.norm()), 0.1 * gmax), (n, err / max(float(gr.norm()), 1e-30))
 
 
 @settings(**dict(SET, max_examples=25))
@@ -806,11 +817,15 @@ def test_sampled_softmax_head_any_shape(ops, seed, V, K8, R, Ns, p_ign, dtype):
         labels[0], keep[0] = 0, True
     lab = labels.cuda()
     samples, logq = ops.log_uniform_sample(seed % 9973, Ns, V, 'cuda')
-    loss = head.cloze_ce(x, lab, 0, samples=(samples, logq))
+    from bf16_gates import BF16_GRAD_BOUND, GateRecorder
+    with GateRecorder(ops) as rec:
+        loss = head.cloze_ce(x, lab, 0, samples=(samples, logq))
     loss.backward()
     P = {n: p.detach().cpu().double().clone().requires_grad_(True) for n, p in head.named_parameters()}
     xr = x.detach().cpu().double().requires_grad_(True)
-    h = tr.dense_stack(xr, P, 2)
+    # bf16: the oracle's trunk takes the device pass's ReLU on / off patterns (tests/bf16_gates.py), so the comparison measures
+    # the arithmetic and not which side of zero a pre-activation fell on
+    h = tr.dense_stack(xr, P, 2, **({'relu': rec.relu_for(0, 2, None, 0, 0)} if dt == torch.bfloat16 else {}))
     W, b = P['output_embedding'], P['output_bias']
     yl, s = labels[keep].long(), samples.cpu()
     zt = (h[keep] * W[yl]).sum(1) + b[yl] - torch.from_numpy(nr.log_uniform_logq(yl.numpy(), V, Ns))
@@ -823,14 +838,12 @@ def test_sampled_softmax_head_any_shape(ops, seed, V, K8, R, Ns, p_ign, dtype):
         tol = 3e-4
     else:
         assert abs(float(loss.detach()) - float(ref.detach())) < 2e-2 * max(1.0, abs(float(ref.detach())))
-        tol = 0.5       # bf16 weights, activations and logits (8 significant bits); with a 24-unit trunk and a few rows one ReLU
-                        # that flips between the two passes is a large share of a gradient: a net for gross mistakes only
+        tol = 2 * BF16_GRAD_BOUND      # bf16 weights, activations and logits (8 significant bits), ReLU patterns shared with the oracle
     big = max(float(P[n].grad.norm()) for n in P)
-    if dt == torch.float32 or (int(keep.sum()) >= 40 and Kd >= 32):       # (bf16 gradients: only where enough rows and units average the ReLU flips)
-        assert float((x.grad.cpu().double() - xr.grad).norm()) < tol * max(float(xr.grad.norm()), 1e-3 * big)
-        for n, p in head.named_parameters():
-            gr = P[n].grad
-            assert float((p.grad.cpu().double() - gr).norm()) < tol * max(float(gr.norm()), 0.02 * big), n
+    assert float((x.grad.cpu().double() - xr.grad).norm()) < tol * max(float(xr.grad.norm()), 1e-3 * big)
+    for n, p in head.named_parameters():
+        gr = P[n].grad
+        assert float((p.grad.cpu().double() - gr).norm()) < tol * max(float(gr.norm()), 0.02 * big), n
     touched = torch.zeros(V, dtype=torch.bool)
     touched[head.touched_rows().cpu()] = True
     if bool((~touched).any()):
@@ -992,7 +1005,7 @@ def test_arena_step_equals_plain_autograd_step_bf16(ops, seed, B, S, L, H, dh, V
         a, c = p.grad.float(), gp[n].grad.float()
         assert float((a - c).abs().max()) <= 2e-3 * float(c.abs().max()) + 1e-9, n
     c = opt.arena.ctx
-    assert not c.queue and not c.pending and ops._active_ctx is None
+    assert not c.queue and not c.pending and not c.pending_dw and c.side_launched is None
 
 
 @settings(**dict(SET, max_examples=12))

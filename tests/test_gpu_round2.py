@@ -432,6 +432,7 @@ def test_tied_head_forward_loss_and_gradients(gpu, dtype):
             v.grad = None
         ref2, _, _ = oracle_loss(relu=rec.relu_for(1, 2, torch.from_numpy(b['flat_idx']).long(), ids.shape[0], ids.shape[1]))
         ref2.backward()
+        rec.check_flips()      # the shared patterns differ from the oracle's own at few units, all near zero
         tol = BF16_GRAD_BOUND
     for n, p in model.named_parameters():
         gr = P[n].grad
