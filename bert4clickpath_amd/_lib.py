@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('B4C_LIB_PATH') or os.path.join(_HERE, 'libb4c_hip.so')     # override: A/B of two builds (scratch)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'b4c.h')
 
-ABI_VERSION = 8      # include/b4c.h; b4c_abi_version() of the library must agree
+ABI_VERSION = 9      # include/b4c.h; b4c_abi_version() of the library must agree
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
 CE_TF, CE_PLAIN = 0, 1
@@ -120,6 +120,7 @@ def lib():
             'b4c_topk_rows': (i32, [vp, i32, i64, i32, i32, vp, vp, vp, vp, i32, vp]),
             'b4c_topk_rows_ws': (i32, [vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
             'b4c_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
+            'b4c_adam_rows': (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp, i32, f32, f32, f32, f32, i32, vp]),
             'b4c_dropout': (i32, [vp, vp, i64, f32, u64, i32, vp]),
             'b4c_softmax_rows_bwd': (i32, [vp, i32, vp, i32, vp, i32, i64, i32, i32, vp]),
             'b4c_sparse_ce_from_probs_bwd': (i32, [vp, i32, vp, vp, vp, i32, i64, i32, i32, i32, vp]),

@@ -24,7 +24,7 @@ int b4c_check_launch(const char *what) {
     return B4C_OK;
 }
 extern "C" const char *b4c_last_error(void) { return g_err; }
-extern "C" int b4c_abi_version(void) { return 8; }
+extern "C" int b4c_abi_version(void) { return 9; }
 extern "C" int b4c_keep(uint64_t seed, uint64_t e, float rate) { return b4c_keep_elem(seed, e, rate) ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------
@@ -886,6 +886,13 @@ extern "C" int b4c_pack_weights_batched(const b4c_pack_desc *d_desc, int n_desc,
 // ------------------------------------------------------------------------------------------
 // Adam over a flat fp32 arena
 // ------------------------------------------------------------------------------------------
+// one element, one step: the ONLY place the update is written down (adam_kernel and adam_rows_kernel must agree bit for bit)
+__device__ __forceinline__ void adam_elem(float &pp, float gk, float &mm, float &vv, float lr_t, float b1, float b2, float eps) {
+    mm = mm * b1 + gk * (1.f - b1);
+    vv = vv * b2 + gk * gk * (1.f - b2);
+    pp = pp - lr_t * mm / (sqrtf(vv) + eps);
+}
+
 __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, int64_t n, float lr_t, float b1, float b2,
                                                    float eps, float gmul) {
@@ -895,10 +902,9 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
         f32x4 mm = reinterpret_cast<f32x4 *>(m)[i], vv = reinterpret_cast<f32x4 *>(v)[i];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gk = gg[k] * gmul;
-            mm[k] = mm[k] * b1 + gk * (1.f - b1);
-            vv[k] = vv[k] * b2 + gk * gk * (1.f - b2);
-            pp[k] = pp[k] - lr_t * mm[k] / (sqrtf(vv[k]) + eps);
+            float pk = pp[k], mk = mm[k], vk = vv[k];
+            adam_elem(pk, gg[k] * gmul, mk, vk, lr_t, b1, b2, eps);
+            pp[k] = pk; mm[k] = mk; vv[k] = vk;
         }
         reinterpret_cast<f32x4 *>(p)[i] = pp;
         reinterpret_cast<f32x4 *>(m)[i] = mm;
@@ -906,12 +912,101 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
     }
     // tail
     for (int64_t i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float gk = g[i] * gmul;
-        const float mk = m[i] * b1 + gk * (1.f - b1);
-        const float vk = v[i] * b2 + gk * gk * (1.f - b2);
-        m[i] = mk; v[i] = vk;
-        p[i] = p[i] - lr_t * mk / (sqrtf(vk) + eps);
+        float pk = p[i], mk = m[i], vk = v[i];
+        adam_elem(pk, g[i] * gmul, mk, vk, lr_t, b1, b2, eps);
+        p[i] = pk; m[i] = mk; v[i] = vk;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam for row-sparse tables (config 5: two 2M-row tables of which < 0.1 % of the rows carry a gradient in a step).
+// Keras' Adam is dense-equivalent: the moments of EVERY row decay every step and the row moves by its momentum
+// (SURVEY 8c iii), which as one kernel is a pass over 28 B per parameter per step.  Here a row keeps the number of the last
+// step it is current through (stamp[row]); a row is brought up to date only when somebody is about to read it or when it
+// receives a gradient, by replaying the zero-gradient steps it missed -- the SAME fp32 operations in the same order as
+// adam_kernel executes them with g = 0, with each missed step's own lr_t out of lr_hist[] -- so the table is, bit for bit,
+// what the dense kernel would have made of it.  A row whose moments are all zero (never touched) replays to itself.
+//   mode 0 (catch up): rows are brought to step t (all zero-gradient steps).  Before the forward pass reads them.
+//   mode 1 (step):     rows are brought to step t - 1, then take step t with their gradient row; the gradient row is
+//                      zeroed behind it (the table's gradient is all zeros between steps: no 3 GB fill per step).
+// ids != NULL: one wave per entry of ids; a row that occurs several times is claimed once (atomicMax on its stamp).
+// ids == NULL: rows [row_lo, row_lo + n): each exactly once -- the rotating catch-up that bounds every row's staleness,
+//              the full catch-up in front of a checkpoint, and the dense fallback of a data-parallel step.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256) adam_rows_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                        float *__restrict__ v, int32_t *__restrict__ stamp,
+                                                        const int64_t *__restrict__ ids, int64_t n, int64_t row_lo, int64_t rows,
+                                                        int width, const float *__restrict__ lr_hist, int t, float b1, float b2,
+                                                        float eps, float gmul) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t i = blockIdx.x * 4ll + wave;
+    if (i >= n) return;
+    int64_t r;
+    int old;
+    if (ids) {
+        r = ids[i];
+        r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);          // clamped as the gather kernels clamp ids
+        // cheap look first: once the row is claimed the other occurrences of a hot id leave without an atomic
+        old = __hip_atomic_load(&stamp[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old < t) {
+            if (lane == 0) old = atomicMax(&stamp[r], t);
+            old = __builtin_amdgcn_readfirstlane(old);
+        }
+        if (old >= t) return;                                  // current already, or another wave has the row
+    } else {
+        r = row_lo + i;
+        old = stamp[r];
+        if (old >= t || (MODE == 0 && old == 0)) return;       // (stamp 0: never touched, all moments zero -- nothing to replay)
+    }
+    const int t_replay = MODE == 0 ? t : t - 1;                // zero-gradient steps old + 1 .. t_replay
+    for (int c = lane * 4; c < width; c += 256) {
+        const int64_t o = r * (int64_t)width + c;
+        const f32x4 p4 = *reinterpret_cast<f32x4 *>(p + o), m4 = *reinterpret_cast<f32x4 *>(m + o), v4 = *reinterpret_cast<f32x4 *>(v + o);
+        f32x4 gg = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 1) gg = *reinterpret_cast<const f32x4 *>(g + o);
+        float pp[4] = {p4[0], p4[1], p4[2], p4[3]}, mm[4] = {m4[0], m4[1], m4[2], m4[3]}, vv[4] = {v4[0], v4[1], v4[2], v4[3]};
+        // a row that never received a gradient has m = v = 0 and every zero-gradient step leaves it as it is
+        const bool live = (mm[0] != 0.f) | (mm[1] != 0.f) | (mm[2] != 0.f) | (mm[3] != 0.f) | (vv[0] != 0.f) | (vv[1] != 0.f) |
+                          (vv[2] != 0.f) | (vv[3] != 0.f);
+        if (old > 0 && live) {
+            for (int s = old + 1; s <= t_replay; ++s) {
+                const float lr_s = lr_hist[s];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) adam_elem(pp[k], 0.f, mm[k], vv[k], lr_s, b1, b2, eps);
+            }
+        }
+        if (MODE == 1) {
+            const float lr_t = lr_hist[t];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) adam_elem(pp[k], gg[k] * gmul, mm[k], vv[k], lr_t, b1, b2, eps);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(g + o) = z;
+        }
+        const f32x4 po = {pp[0], pp[1], pp[2], pp[3]}, mo = {mm[0], mm[1], mm[2], mm[3]}, vo = {vv[0], vv[1], vv[2], vv[3]};
+        *reinterpret_cast<f32x4 *>(p + o) = po;
+        *reinterpret_cast<f32x4 *>(m + o) = mo;
+        *reinterpret_cast<f32x4 *>(v + o) = vo;
+    }
+    if (!ids && lane == 0) stamp[r] = t;
+}
+
+extern "C" int b4c_adam_rows(float *p, float *g, float *m, float *v, int32_t *stamp, const int64_t *ids, int64_t n, int64_t row_lo,
+                             int64_t rows, int width, const float *lr_hist, int t, float beta1, float beta2, float eps,
+                             float grad_mul, int mode, void *stream) {
+    B4C_REQUIRE(p && m && v && stamp && lr_hist && rows > 0 && width > 0 && t >= 0, "adam_rows: bad argument");
+    B4C_REQUIRE(mode == 0 || (mode == 1 && g), "adam_rows: mode %d (0 = catch up, 1 = step; the step needs the gradient table)", mode);
+    B4C_REQUIRE(width % 4 == 0 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+                "adam_rows: width %d must be a multiple of 4 and the tables 16-byte aligned", width);
+    B4C_REQUIRE(ids || (row_lo >= 0 && row_lo + n <= rows), "adam_rows: rows [%lld, %lld) outside the table of %lld rows",
+                (long long)row_lo, (long long)(row_lo + n), (long long)rows);
+    if (n <= 0) return 0;
+    const int64_t blocks = (n + 3) / 4;
+    B4C_REQUIRE(blocks < (1ll << 31), "adam_rows: %lld rows in one call", (long long)n);
+    if (mode == 0) adam_rows_kernel<0><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, stamp, ids, n, row_lo, rows, width, lr_hist, t, beta1, beta2, eps, grad_mul);
+    else adam_rows_kernel<1><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, stamp, ids, n, row_lo, rows, width, lr_hist, t, beta1, beta2, eps, grad_mul);
+    return b4c_check_launch("adam_rows");
 }
 
 extern "C" int b4c_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float beta1,

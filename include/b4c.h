@@ -328,6 +328,19 @@ int b4c_topk_rows_ws(const void *scores, int ld, int64_t R, int V, int k, int32_
 int b4c_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float beta1,
                   float beta2, float eps, float grad_mul, void *stream);
 
+/* Adam for a row-sparse table inside the arena (config 5: 2M-row tables, < 0.1 % of the rows touched per step) -- the same
+ * dense-equivalent Keras update (main.py:87), evaluated lazily per row: stamp[row] (int32, 0 = never touched) is the last
+ * step the row is current through; a row is brought up to date by replaying the zero-gradient steps it missed with the
+ * fp32 operations of b4c_adam_step in the same order (lr_hist[s] = the lr_t the host used at step s, s = 1 .. t), so
+ * the table equals the dense kernel's bit for bit once every row is caught up.
+ *   mode 0: bring the rows to step t (zero-gradient steps only): before anything reads them.
+ *   mode 1: bring the rows to step t - 1, take step t with the gradient rows of g, zero those gradient rows.
+ * ids (int64 [n], clamped to the table; a row named several times is handled once) or, ids == NULL, the rows
+ * [row_lo, row_lo + n).  p, g, m, v: the table's [rows][width] slices of the four arenas (width % 4 == 0). */
+int b4c_adam_rows(float *p, float *g, float *m, float *v, int32_t *stamp, const int64_t *ids, int64_t n, int64_t row_lo,
+                  int64_t rows, int width, const float *lr_hist, int t, float beta1, float beta2, float eps,
+                  float grad_mul, int mode, void *stream);
+
 /* keep-mask hash used by every dropout site (exposed so hosts/tests can regenerate masks):
  * returns 1 if element e is kept under (seed, rate). */
 int b4c_keep(uint64_t seed, uint64_t e, float rate);
