@@ -76,6 +76,8 @@ def parse():
     ap.add_argument('--action_vocab', type=int, default=1000)
     ap.add_argument('--feature_sum', action='store_true', help='config 4 as BASELINE.json words it ("dual embedding gather + sum"): items and '
                     'actions are both d_model wide and their rows are ADDED (feature_combine=\'sum\', an extension: the reference concatenates)')
+    ap.add_argument('--dense_adam', action='store_true', help='config 5 A/B: the dense Adam pass over all 770 M parameters every step instead '
+                    'of the row-lazy form (optim.LazyRows: same arithmetic, bit-identical tables, rows updated when they are used)')
     ap.add_argument('--traffic_json', default=None, help='optional JSON with PMC-derived HBM bytes per launch')
     a = ap.parse_args()
     if a.config == 'c4':
@@ -308,10 +310,13 @@ class Training:
     def __init__(self, a, rank, world, device):
         from bert4clickpath_amd import ops, optim, parallel
         self.a, self.rank, self.world, self.device = a, rank, world, device
-        self.model = build_model(a, device)
-        self.opt = optim.Adam(self.model.parameters(), order=backward_order(self.model))
+        self.model = model = build_model(a, device)
+        # config 5: the two 2M-row tables (item embedding, vocabulary-major sampled projection) take their Adam update row by
+        # row, when a row is used (bit-identical to the dense update; `--dense_adam` for the A/B)
+        lazy = [p for n, p in model.named_parameters() if 'embedding_layers' in n or n == 'head.output_embedding'] \
+            if (a.sampled and not a.dense_adam) else []
+        self.opt = optim.Adam(model.parameters(), order=backward_order(model), lazy_rows=lazy)
         arena = self.opt.arena
-        model = self.model
         emb_start = min(arena.slice_of(p)[0] for n, p in model.named_parameters() if 'embedding_layers' in n)
         # (head parameters placed behind the tables -- the projection under ops.overlap_vocab_dw -- belong to the last bucket)
         head_end = max(arena.slice_of(p)[1] for n, p in model.named_parameters()
@@ -488,7 +493,8 @@ def main():
                                    '%d resident batches, [MASK] indices %s%s; encoder on %s'
                                    % (a.vocab, a.seq, a.d_model, a.layers, a.heads, a.dff,
                                       ' (reference-hard-coded)' if a.dff == 100 else ' (NOT the reference\'s 100: the paper-faithful width)',
-                                      ' (sampled softmax, %d shared log-uniform negatives)' % a.sampled if a.sampled else '',
+                                      (' (sampled softmax, %d shared log-uniform negatives; Adam on the 2M-row tables %s)'
+                                       % (a.sampled, 'as a dense pass' if a.dense_adam else 'row-lazy: bit-identical to the dense pass')) if a.sampled else '',
                                       a.batch, world, a.dropout, len(batches),
                                       'precomputed on the host' if a.host_flat_idx else 'generated on the device inside the step',
                                       ('; two SUMMED features items(%d)+actions(%d, vocab %d) (feature_combine=sum: an extension, the reference concatenates)'

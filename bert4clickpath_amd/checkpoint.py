@@ -26,6 +26,8 @@ def save_checkpoint(path, model, optimizer=None, epoch=0, metrics=None):
     """Write one checkpoint file.  `path` gets '.pt' appended when it has no extension."""
     if not os.path.splitext(path)[1]:
         path += '.pt'
+    if optimizer is not None and hasattr(optimizer, 'sync_rows'):
+        optimizer.sync_rows()      # a row-lazy optimizer's tables (optim.LazyRows): every row current before it is written out
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     blob = {
         'format': FORMAT,
@@ -98,6 +100,8 @@ def load_checkpoint(path, model, optimizer=None, strict=True):
                 optimizer.v[off:off + p.numel()].view(p.shape).copy_(o['v'][n])
         optimizer.iterations, optimizer.lr = int(o['iterations']), float(o['lr'])
         optimizer.beta_1, optimizer.beta_2, optimizer.epsilon = o['beta_1'], o['beta_2'], o['epsilon']
+    if optimizer is not None and hasattr(optimizer, 'reset_rows'):
+        optimizer.reset_rows()     # (the loaded tables are current through `iterations`, whatever the optimizer held before)
     ds = blob.get('dropout_seed')
     if ds:
         _tr.dropout_seeds.base, _tr.dropout_seeds.counter = int(ds['base']), int(ds['counter'])

@@ -977,6 +977,17 @@ def adam_step_(p, g, m, v, lr_t, beta1, beta2, eps, grad_mul=1.0):
                 'adam_step')
 
 
+def adam_rows_(p, g, m, v, stamp, ids, n, row_lo, rows, width, lr_hist, t, beta1, beta2, eps, grad_mul, mode):
+    """b4c_adam_rows over one row-sparse table of the arena (optim.LazyRows): mode 0 = bring rows to step t, 1 = take step t.
+    Booked bytes: the rows NAMED (an upper bound of the distinct rows; rec_hints['adam_distinct_rows'] when the host knows it)."""
+    if n <= 0:
+        return
+    nrows = min(n, rec_hints.get('adam_distinct_rows', n)) if ids is not None else n
+    with _record('adam' if mode == 1 else 'adam_catch_up', nrows * width * (32 if mode == 1 else 24) + (n * 8 if ids is not None else 0)):
+        L.check(L.lib().b4c_adam_rows(_p(p), _p(g), _p(m), _p(v), _p(stamp), _p(ids), n, row_lo, rows, width, _p(lr_hist), t,
+                                      beta1, beta2, eps, grad_mul, mode, _st()), 'adam_rows')
+
+
 def rand64_host(seed, ctr):
     """Host restatement of b4c_rand64 (csrc/common.h): Threefry-2x32, 12 rounds, key = seed, counter = ctr (uint64 array)."""
     import numpy as np
@@ -1150,7 +1161,7 @@ class EmbedFn(torch.autograd.Function):
             else:
                 n, packed = n
         ids, tables = list(args[:n]), list(args[n:])
-        out, key_pad = embed_concat_pe_fwd(ids, [t.detach() for t in tables], pe, scale, rate, seed, dtype, packed, combine)
+        dense_ids = ids
         if packed is not None:
             # backward works on the packed ids (one gather per feature): B = 1, S = T rows
             pk_ids = []
@@ -1162,6 +1173,12 @@ class EmbedFn(torch.autograd.Function):
                 L.check(L.lib().b4c_gather_i64(_p(flat), _p(packed.tok_src), _p(o), packed.T, _st()), 'gather_i64')
                 pk_ids.append(o)
             ids = pk_ids
+        # a table under a row-lazy optimizer (optim.LazyRows): the rows about to be read are brought up to date first
+        for j, (t, i) in enumerate(zip(tables, ids)):
+            lz = getattr(t, '_b4c_lazy', None)
+            if lz is not None:
+                lz.catch_up(i, note=ctx.needs_input_grad[6 + n + j])
+        out, key_pad = embed_concat_pe_fwd(dense_ids, [t.detach() for t in tables], pe, scale, rate, seed, dtype, packed, combine)
         ctx.save_for_backward(*ids, *tables)
         ctx.n, ctx.scale, ctx.rate, ctx.seed = n, scale, rate, seed
         ctx.mark_non_differentiable(key_pad)
@@ -1947,6 +1964,9 @@ class TiedPackedLinear(PackedLinear):
         t = self.table.detach()
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise B4CError('embedding tables must be contiguous float32')
+        lz = getattr(self.table, '_b4c_lazy', None)
+        if lz is not None:          # row-lazy optimizer: the whole table is about to be read
+            lz.sync()
         rows = t[self.tied_offset:self.tied_offset + self.N]
         ent['bias'][:self.N].copy_(self.bias_p.detach())
         # as a Keras kernel [K' = V][N' = K]:  wt'[n'][k'] = src[k'][n'] is our wc [K][V],  wc'[k'][n'] is our wt [V][K]
@@ -2034,10 +2054,14 @@ class SampledCEFn(torch.autograd.Function):
         valid = valid_m.sum().to(torch.float32)
         scale = torch.where(valid > 0, 1.0 / valid.clamp(min=1.0), torch.zeros_like(valid)).reshape(1)
         tab = table.detach()
+        idx_y = torch.where(valid_m, labels_i32, torch.full_like(labels_i32, -1)).to(torch.int64)
+        lz = getattr(table, '_b4c_lazy', None)
+        if lz is not None:          # row-lazy optimizer: the sampled and the label rows are brought up to date before they are read
+            lz.catch_up(samples, note=ctx.needs_input_grad[1])
+            lz.catch_up(idx_y, note=ctx.needs_input_grad[1])
         Ws = rows_gather_f32(tab, samples).to(h.dtype)                               # [Ns, K]
         bs = (bias.detach()[samples] - logq).contiguous()
         Z = gemm_nt(h, Ws, Ns, bs)                                                   # negatives' logits, bias - logQ folded in
-        idx_y = torch.where(valid_m, labels_i32, torch.full_like(labels_i32, -1)).to(torch.int64)
         Wy = rows_gather_f32(tab, idx_y).to(h.dtype)                                 # [R, K], zero rows where ignored
         ztrue = row_dot(h, Wy) + bias.detach()[idx_y.clamp(min=0)]
         item = torch.empty(h.shape[0], dtype=torch.float32, device=h.device)

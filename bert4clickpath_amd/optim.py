@@ -88,15 +88,16 @@ class LazyRows:
             ids = ids.to(torch.int64).contiguous()
         return ids
 
-    def catch_up(self, ids):
+    def catch_up(self, ids, note=True):
         """rows `ids` (any integer tensor on the device; repeats and out-of-range values as the gather kernels take them) are
-        brought to the optimizer's current step and remembered as this step's candidates for a gradient"""
+        brought to the optimizer's current step and -- note=True: the read is part of a pass that will be differentiated --
+        remembered as this step's candidates for a gradient"""
         ids = self._ids(ids)
         if ids.numel() == 0:
             return
         if self.opt.iterations > 0:
             self._launch(ids, ids.numel(), 0, self.opt.iterations, 0)
-        if torch.is_grad_enabled():
+        if note:
             self.touched.append(ids)
 
     def note(self, ids):

@@ -192,9 +192,12 @@ class GradReducer:
         counts = [torch.zeros_like(n) for _ in range(self.world)]
         dist.all_gather(counts, n, group=self.group)
         nmax = int(max(int(c) for c in counts))
+        lazy = getattr(p, '_b4c_lazy', None)      # row-lazy optimizer (optim.LazyRows): it steps the rows that received a gradient
         if nmax * self.world > self.sparse_max_fill * rows_total:
             self.last_exchange[id(p)] = 'dense'
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            if lazy is not None:
+                lazy.all_rows = True              # (which rows the other ranks touched is not known here: the whole table steps)
             return
         self.last_exchange[id(p)] = 'sparse'
         idx = torch.full((max(nmax, 1),), -1, dtype=torch.int64, device=g.device)
@@ -208,3 +211,5 @@ class GradReducer:
         _rows_scatter_add(g, idx, -rows)
         for r in range(self.world):
             _rows_scatter_add(g, all_idx[r], all_rows[r])
+            if lazy is not None and r != dist.get_rank(self.group):
+                lazy.note(all_idx[r].clamp(min=0))    # rows this rank has not read: they take the step (and a catch-up) too

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)          # loads without a GPU: no device call at load time
     for n in names:
         assert hasattr(L, n), 'libb4c_hip.so does not export %s' % n
-    assert _lib.lib().b4c_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.lib().b4c_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_keep_mask_hash_host_vs_library():
@@ -271,3 +271,15 @@ def test_a_missing_library_is_an_error_not_a_fallback():
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr
     assert 'B4CError' in out.stdout and 'no CPU fallback' in out.stdout and 'loaded' not in out.stdout
+
+
+def test_a_library_of_another_abi_is_refused_at_load(monkeypatch):
+    """The argument lists bound in _lib.lib() belong to one ABI version; a library that answers another one must not be bound
+    (same names, older lists: a device pointer would be taken for a stream).  B4CError, not AttributeError."""
+    from bert4clickpath_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'ABI_VERSION', _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.B4CError, match='ABI'):
+        _lib.lib()
+    monkeypatch.setattr(_lib, 'ABI_VERSION', _lib.ABI_VERSION - 1)
+    assert _lib.lib().b4c_abi_version() == _lib.ABI_VERSION
