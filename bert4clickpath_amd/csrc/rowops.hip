@@ -887,10 +887,17 @@ extern "C" int b4c_pack_weights_batched(const b4c_pack_desc *d_desc, int n_desc,
 // Adam over a flat fp32 arena
 // ------------------------------------------------------------------------------------------
 // one element, one step: the ONLY place the update is written down (adam_kernel and adam_rows_kernel must agree bit for bit)
+// Every rounding is spelled out and contraction is off: left to the compiler, `m * b1 + g * (1 - b1)` became fma(m, b1, g (1 - b1))
+// in one kernel and fma(g, 1 - b1, m b1) in the other (one ulp apart now and then: found by tests/test_gpu_lazy_adam.py).
 __device__ __forceinline__ void adam_elem(float &pp, float gk, float &mm, float &vv, float lr_t, float b1, float b2, float eps) {
-    mm = mm * b1 + gk * (1.f - b1);
-    vv = vv * b2 + gk * gk * (1.f - b2);
-    pp = pp - lr_t * mm / (sqrtf(vv) + eps);
+#pragma clang fp contract(off)
+    const float gm = gk * (1.f - b1);
+    const float gv = (gk * gk) * (1.f - b2);
+    mm = __builtin_fmaf(mm, b1, gm);
+    vv = __builtin_fmaf(vv, b2, gv);
+    const float num = lr_t * mm;
+    const float den = sqrtf(vv) + eps;
+    pp = pp - num / den;
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,

@@ -137,11 +137,22 @@ struct VceArgs {
     int64_t R;
     int V, parts, variant;
     int ntt;              // 128-token tiles
+    // "lse first" form of the forward (vce_exact_kernel): the row's lse and largest logit are known before the one sweep that
+    // accumulates U and Ud, both against that final lse
+    const float *rowstat; // [R][2]: lse2, max x  (NULL: the online form, statistics per part in st1)
+    int parts_st;         // vocabulary parts of the sweep that filled st1 (the lse sweep's own split)
 };
 
 // merge the per-part statistics of one row: lse2 = log2 sum_j 2^(x_j log2e), clipped flag, and (optionally) the
 // factor f_p = 2^(m2_p - M2) / l that turns part p's un-normalised sums into probabilities
 __device__ __forceinline__ void vce_row_stats(const VceArgs &a, int64_t row, float &lse2, bool &clipped, float &pmax) {
+    if (a.rowstat) {          // the lse-first form: one merged record per row; whether the row is clipped is read off the sweep's counts
+        const f32x2 s = *reinterpret_cast<const f32x2 *>(a.rowstat + row * 2);
+        lse2 = s[0];
+        pmax = __builtin_amdgcn_exp2f(s[1] * VCE_LOG2E - lse2);
+        clipped = a.variant == B4C_CE_TF;
+        return;
+    }
     float M = -INFINITY, l = 0.f, mn = INFINITY, mx = -INFINITY;
     for (int p = 0; p < a.parts; ++p) {
         const f32x4 s = *reinterpret_cast<const f32x4 *>(a.st1 + ((int64_t)p * a.R + row) * 4);
@@ -185,6 +196,10 @@ extern "C" int b4c_debug_vce_stamps(void *dst, size_t nbytes) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_vce_stamps), nbytes < sizeof(g_vce_stamps) ? nbytes : sizeof(g_vce_stamps));
 }
 #define VCE_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[k] += t_ - t0_; t0_ = t_; } while (0)
+__device__ unsigned long long g_vce_xstamps[2048 * 4 * 8];       // vce_exact_kernel: per wave, per pipeline step
+extern "C" int b4c_debug_vce_xstamps(void *dst, size_t nbytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_vce_xstamps), nbytes < sizeof(g_vce_xstamps) ? nbytes : sizeof(g_vce_xstamps));
+}
 #else
 #define VCE_STAMP(k) do { } while (0)
 #endif
@@ -491,6 +506,294 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K2x (round 4): the "lse first" form of the forward.  The row's lse is known (lse sweep: vce_token_kernel<KD, 0> +
+// vce_rowstat_kernel), so ONE sweep forms the final probabilities p = 2^(x log2e - lse2) and accumulates BOTH products from the
+// same P and the same W fragments:  U = P W  and  Ud = P (1 - u) W  (the entries below TF's clip range), with Pc, the counts
+// and the dominant entry kept apart exactly as vce_token_kernel<KD, 2> keeps them.  No running maximum, no lazily raised
+// reference, no rescaling: the max / raise chain of the online sweep (21 % of a tile there) does not exist.
+//
+// One workgroup = 128 tokens x one part of the vocabulary, 256 threads = ONE WAVE PER SIMD with up to 512 registers per lane:
+// both accumulator sets (2 x 64 registers at K = 128), two logits tiles, double-buffered fragment sets.  A wave has no partner
+// to overlap with, so the overlap is made inside the wave: the loop over the four 32-row tiles of a W tile is software-
+// pipelined -- step k issues the logits MFMAs of tile k + 1 and the 16 P W MFMAs of tile k - 1 between the VALU
+// instructions of tile k's probabilities (two thirds of an entry's ~6 instructions per MFMA, at most one exponential per gap:
+// the issue costs of MI355X_MICROARCH.md fit the MFMA's 32 cycles), and the LDS fragment reads of step k + 1.
+// sched_barrier(0) after every MFMA's group pins the interleave.  Three GEMM units per W tile (3,072 cycles of matrix pipe
+// per SIMD) cover the tile's arrival by LDS-DMA (~2,900 cycles per CU) at 128 tokens per workgroup.
+// ------------------------------------------------------------------------------------------
+template <int KD> static size_t vce_exact_lds() {
+    const size_t tiles = 2 * (size_t)VTile<KD>::BYTES + 2 * 128 * 4;
+    const size_t outs = (size_t)4 * 32 * (KD + 4) * 4 + 4 * 64 * 16;
+    return tiles > outs ? tiles : outs;
+}
+
+template <int KD>
+__global__ void __launch_bounds__(256, 1) vce_exact_kernel(VceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NKS = KD / 16, NDT = KD / 32, STR = VTile<KD>::STR;
+    constexpr int TILE_B = VTile<KD>::BYTES;
+    constexpr int NPF = 2 * NDT;                        // transposed fragments of one 32-row tile
+    float *sBias = reinterpret_cast<float *>(smem + 2 * TILE_B);     // [2][128]
+    const int unit = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int64_t tok0 = (int64_t)(unit % a.ntt) * 128;
+    const int64_t tok = tok0 + wave * 32 + r;
+    const int part = unit / a.ntt;
+    const int nvt = (a.V + 127) >> 7;
+    const int vt0 = (int)((int64_t)nvt * part / a.parts), vt1 = (int)((int64_t)nvt * (part + 1) / a.parts);
+
+    float lse2 = INFINITY;                              // rows past R: p = 2^(-inf) = 0
+    float pmax = 0.f;
+    if (tok < a.R) {
+        const f32x2 rs = *reinterpret_cast<const f32x2 *>(a.rowstat + tok * 2);
+        lse2 = rs[0];
+        pmax = __builtin_amdgcn_exp2f(rs[1] * VCE_LOG2E - lse2);
+    }
+    // (block-uniform) some row here has a dominant entry, the one probability that may exceed 1 - 1e-7: counted apart, see
+    // vce_token_kernel<KD, 2>
+    const bool anyhi = __syncthreads_or(pmax > 0.4f);
+
+    bf16x8 hfr[NKS];
+    vce_load_hfrag<KD>(a.h, a.ld_h, tok, a.R, hf, hfr);
+    int foff[NKS], toff[NDT][2];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) foff[ks] = VTile<KD>::frag_off(r, ks, hf);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+        toff[dt][0] = VTile<KD>::tr_off(hf, li, g, dt, 0);
+        toff[dt][1] = VTile<KD>::tr_off(hf, li, g, dt, 1);
+    }
+
+    float breg = 0.f;
+    auto fetch = [&](int vt, int buf) {
+        VTile<KD>::template dma<256>(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, smem + buf * TILE_B, tid);
+        if (tid < 128) {
+            const int v = vt * 128 + tid;
+            breg = (vt < vt1 && v < a.V) ? (a.bias ? a.bias[v] : 0.f) : -INFINITY;   // rows past V: logit = -inf, p = 0
+        }
+    };
+    fetch(vt0, 0);
+    if (tid < 128) sBias[tid] = breg;
+    VCE_DMA_WAIT();
+    __syncthreads();
+
+#ifdef VCE_SCAN_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
+#define XSTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[k] += t_ - t0_; t0_ = t_; } while (0)
+#else
+#define XSTAMP(k) do { } while (0)
+#endif
+    float Pc = 0.f;                 // sum of the probabilities below the clip range
+    unsigned nlow = 0, nhi = 0;     // entries below the range (rows past V among them: p = 0) / dominant entries (p > 1/2)
+    f32x16 U[NDT], Ud[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { U[dt][t] = 0.f; Ud[dt][t] = 0.f; }
+
+    // ---- the pieces of one 32-row tile ----
+    // direct (A operand of the logits chain) and transposed (A operand of P W) fragments of tile rt
+    auto ldL = [&](const char *w, int rt, bf16x8 (&f)[NKS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) f[ks] = *reinterpret_cast<const bf16x8 *>(w + rt * 32 * STR + foff[ks]);
+    };
+    auto ldL1 = [&](const char *w, int rt, bf16x8 (&f)[NKS], int ks) __attribute__((always_inline)) {
+        f[ks] = *reinterpret_cast<const bf16x8 *>(w + rt * 32 * STR + foff[ks]);
+    };
+    auto ldP1 = [&](const char *w, int rt, bf16x8 (&f)[NPF], int i) __attribute__((always_inline)) {
+        const int s2 = i / NDT, dt = i % NDT;
+        const char *wb = w + (rt * 32 + 16 * s2) * STR;
+        f[i] = vce_frag_tr2(wb + toff[dt][0], wb + toff[dt][1]);
+    };
+    // the logits accumulator of tile rt starts as the rows' bias (straight from LDS into the accumulator's registers)
+    auto ldB = [&](const float *bs, int rt, f32x16 &acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(bs + rt * 32 + 8 * tq + 4 * hf);
+            acc[4 * tq] = q[0]; acc[4 * tq + 1] = q[1]; acc[4 * tq + 2] = q[2]; acc[4 * tq + 3] = q[3];
+        }
+    };
+
+    // One pipeline step over a W tile in LDS (`w`, bias `bs`), all indices compile-time:
+    //   VALU : the probabilities of tile K (logits in acc[K % 3]) -> pk[K & 1] (all entries, bf16) / pl[K & 1] (the ones below
+    //          the clip range), Pc, nlow, nhi
+    //   MFMA : DO_L: the logits chain of tile K + 1 into acc[(K + 1) % 3] from Lf;
+    //          DO_P: U / Ud += W^T P of tile K - 1 from Pf, pk / pl[(K - 1) & 1]
+    //   LDS  : every fragment register is re-loaded right behind the MFMA that consumed it, with the fragment the NEXT step's
+    //          MFMA of the same slot needs (LD_L: direct fragment of tile K + 2; LD_P: transposed fragment of tile K): one set of
+    //          fragment registers, a full step of latency cover.  LD_L also: the bias of tile K + 2 into acc[(K + 2) % 3], the
+    //          accumulator whose probabilities were finished a step ago (three logits accumulators: 48 registers).
+    // The accumulators of the logits chain must be ordinary VGPRs: the VALU reads every entry, and with more than 256 registers
+    // in use the compiler keeps MFMA results in the accumulation half of the file (one v_accvgpr_read per entry: +14 % vector
+    // instructions).  The chain's MFMA is therefore written as inline assembly with VGPR operands; its results are first read
+    // a whole step (>= 16 MFMAs) later, so no hazard wait is due.  The two accumulations (Pc, counts) are inline assembly as
+    // well: left to the compiler they sink to the end of the tile (64 masks and 64 values kept alive: spills), out of the
+    // MFMA gaps they are meant to fill.
+    f32x16 acc[3];
+    bf16x8 Lf[NKS], Pf[NPF], pk[2][2], pl[2][2];
+    const float l2e = VCE_LOG2E;
+    auto step = [&](auto KK, auto DOE, auto DOL, auto DOP, auto LDL, auto LDP, auto HI, const char *w, const float *bs) __attribute__((always_inline)) {
+        constexpr int K = decltype(KK)::value;
+        constexpr bool do_e = decltype(DOE)::value, do_l = decltype(DOL)::value, do_p = decltype(DOP)::value;
+        constexpr bool ld_l = decltype(LDL)::value, ld_p = decltype(LDP)::value, hi = decltype(HI)::value;
+        constexpr int cur = K & 1, prv = (K + 1) & 1;                          // (K - 1) & 1 == (K + 1) & 1
+        constexpr int ac = (K + 3) % 3, an = (K + 4) % 3, an2 = (K + 5) % 3;    // accumulators of tiles K, K + 1, K + 2
+        constexpr int n_l = do_l ? NKS : 0, n_p = do_p ? 4 * NDT : 0, n_mfma = n_l + n_p;
+        constexpr int n_gap = n_mfma > 0 ? n_mfma : 1;
+        float pv0 = 0.f, pv1 = 0.f, pl0 = 0.f, pl1 = 0.f;
+        // one entry: probability against the row's final lse, its share of Pc and of the counts
+        auto entry = [&](int t, float &pv, float &plo) __attribute__((always_inline)) {
+            pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[ac][t], l2e, -lse2));
+            const bool low = pv < VCE_EPS;
+            plo = low ? pv : 0.f;
+            asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(Pc) : "v"(plo));
+            asm volatile("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(nlow) : "s"(__builtin_amdgcn_ballot_w64(low)) : "vcc");
+            unsigned &nhi_ = nhi;          // (named outside the discarded branch: the capture must not depend on `hi`)
+            if constexpr (hi) asm volatile("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(nhi_) : "s"(__builtin_amdgcn_ballot_w64(pv > 0.5f)) : "vcc");
+        };
+        // the 24 chunks of a tile's VALU work: entry 2 j | entry 2 j + 1 | their two packs
+        auto chunk = [&](int c) __attribute__((always_inline)) {
+            const int j = c / 3, ph = c % 3, t0 = 2 * j, t1 = 2 * j + 1;
+            if (ph == 0) entry(t0, pv0, pl0);
+            else if (ph == 1) entry(t1, pv1, pl1);
+            else {
+                // entries t0, t1: elements (t & 7) of the k-step (t >> 3) of the B operand
+                pk[cur][t0 >> 3][t0 & 7] = (bf16_t)pv0; pk[cur][t0 >> 3][t1 & 7] = (bf16_t)pv1;
+                pl[cur][t0 >> 3][t0 & 7] = (bf16_t)pl0; pl[cur][t0 >> 3][t1 & 7] = (bf16_t)pl1;
+            }
+        };
+        if (ld_l) ldB(bs, K + 2, acc[an2]);
+#pragma unroll
+        for (int i = 0; i < n_gap; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < n_l) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[an]) : "v"(Lf[i]), "v"(hfr[i]));
+                if (ld_l) ldL1(w, K + 2, Lf, i);
+            } else if (i < n_mfma) {
+                const int q = i - n_l, f = q / 2;                 // fragment f = s2 * NDT + dt serves U then Ud
+                const int s2 = f / NDT, dt = f % NDT;
+                if ((q & 1) == 0) U[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Pf[f], pk[prv][s2], U[dt], 0, 0, 0);
+                else {
+                    Ud[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Pf[f], pl[prv][s2], Ud[dt], 0, 0, 0);
+                    if (ld_p) ldP1(w, K, Pf, f);
+                }
+            }
+            if (do_e) {
+#pragma unroll
+                for (int c = (i * 24) / n_gap; c < ((i + 1) * 24) / n_gap; ++c) chunk(c);
+            }
+        }
+        // a step without P W MFMAs has no slot behind which the transposed fragments could be re-loaded: load them here
+        if (ld_p && !do_p) {
+#pragma unroll
+            for (int f = 0; f < NPF; ++f) ldP1(w, K, Pf, f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr std::integral_constant<bool, true> Y{};
+    constexpr std::integral_constant<bool, false> N{};
+    constexpr std::integral_constant<int, 0> K0{};
+    constexpr std::integral_constant<int, 1> K1{};
+    constexpr std::integral_constant<int, 2> K2{};
+    constexpr std::integral_constant<int, 3> K3{};
+    constexpr std::integral_constant<int, 4> K4{};
+    constexpr std::integral_constant<int, -1> KM{};
+
+    auto tile = [&](auto BUF, auto HI, int vt) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::value;
+        const char *w = smem + buf * TILE_B;
+        const float *bs = sBias + buf * 128;
+        // fragments of tile 0, bias of tiles 0 and 1, the DMA requests of the next W tile (the other buffer was last read one tile
+        // ago, behind the previous barrier), then the logits chain of tile 0, every fragment register re-loaded for tile 1 behind
+        // its MFMA
+        XSTAMP(7);
+        ldL(w, 0, Lf); ldB(bs, 0, acc[0]); ldB(bs, 1, acc[1]);
+        fetch(vt + 1, buf ^ 1);
+        //            VALU   chain   P W     re-loads
+        step(KM, N, Y, N, N, N, HI, w, bs);      //        | chain(0)         |
+        ldL(w, 1, Lf);
+        // (the chain above is inline assembly: the compiler places no hazard wait between it and the first read of its result)
+        asm volatile("s_nop 15\n\ts_nop 7");
+        XSTAMP(0);
+        step(K0, Y, Y, N, Y, Y, HI, w, bs);      // p(0)   | chain(1)         | L(2), bias(2), P(0)
+        XSTAMP(1);
+        step(K1, Y, Y, Y, Y, Y, HI, w, bs);      // p(1)   | chain(2), PW(0)  | L(3), bias(3), P(1)
+        XSTAMP(2);
+        step(K2, Y, Y, Y, N, Y, HI, w, bs);      // p(2)   | chain(3), PW(1)  | P(2)
+        XSTAMP(3);
+        step(K3, Y, N, Y, N, Y, HI, w, bs);      // p(3)   | PW(2)            | P(3)
+        XSTAMP(4);
+        step(K4, N, N, Y, N, N, HI, w, bs);      //        | PW(3)
+        XSTAMP(5);
+        if (tid < 128) sBias[(buf ^ 1) * 128 + tid] = breg;
+        VCE_DMA_WAIT();
+        B4C_LDS_BARRIER();
+        XSTAMP(6);
+    };
+    auto sweep = [&](auto HI) __attribute__((always_inline)) {
+        for (int vt = vt0; vt < vt1; vt += 2) {
+            tile(std::integral_constant<int, 0>{}, HI, vt);
+            if (vt + 1 < vt1) tile(std::integral_constant<int, 1>{}, HI, vt + 1);
+        }
+    };
+    if (anyhi) sweep(Y); else sweep(N);
+#ifdef VCE_SCAN_STAMPS
+    if (lane == 0 && blockIdx.x < 2048)
+        for (int k = 0; k < 8; ++k) g_vce_xstamps[(blockIdx.x * 4 + wave) * 8 + k] = st_[k];
+#endif
+    __syncthreads();   // all tiles consumed: LDS is reused below
+
+    // U^T / Ud^T tiles -> LDS [token][d] per wave -> row-major partial sums of this vocabulary part; per-lane scalars summed
+    // over the two lanes of a token
+    constexpr int USTR = KD + 4;
+    float *sU = reinterpret_cast<float *>(smem) + wave * 32 * USTR;
+    auto flush = [&](f32x16 (&X)[NDT], float *dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                const f32x4 v = {X[dt][4 * tq], X[dt][4 * tq + 1], X[dt][4 * tq + 2], X[dt][4 * tq + 3]};
+                *reinterpret_cast<f32x4 *>(sU + r * USTR + dt * 32 + 8 * tq + 4 * hf) = v;
+            }
+        __syncthreads();
+        for (int c = tid; c < 128 * (KD / 4); c += 256) {
+            const int t = c / (KD / 4), q = c % (KD / 4);
+            if (tok0 + t < a.R)
+                *reinterpret_cast<f32x4 *>(dst + (tok0 + t) * KD + q * 4) =
+                    *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(smem) + t * USTR + q * 4);
+        }
+        __syncthreads();
+    };
+    flush(U, a.u + (int64_t)part * a.R * KD);
+    flush(Ud, a.ud + (int64_t)part * a.R * KD);
+    f32x4 *sS = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(smem) + 4 * 32 * USTR);   // [wave][lane]
+    // (n_low counts the rows past V of the last W tile too -- their p is 0: the combine kernel takes them out again)
+    sS[wave * 64 + lane] = (f32x4){(float)nlow, Pc, (float)nhi, 0.f};
+    __syncthreads();
+    if (tid < 128 && tok0 + tid < a.R) {
+        const int tgi = tid >> 5, ri = tid & 31;
+        *reinterpret_cast<f32x4 *>(a.sp + ((int64_t)part * a.R + tok0 + tid) * 4) = sS[tgi * 64 + ri] + sS[tgi * 64 + ri + 32];
+    }
+}
+
+// {lse2, max x} per row from the per-part statistics of the lse sweep (vce_token_kernel<KD, 0>: m2, l, -, max x)
+__global__ void __launch_bounds__(256) vce_rowstat_kernel(VceArgs a, float *__restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.R) return;
+    float M = -INFINITY, l = 0.f, mx = -INFINITY;
+    for (int p = 0; p < a.parts_st; ++p) {
+        const f32x4 s = *reinterpret_cast<const f32x4 *>(a.st1 + ((int64_t)p * a.R + row) * 4);
+        const float M2 = fmaxf(M, s[0]);
+        l = l * __builtin_amdgcn_exp2f(M - M2) + s[1] * __builtin_amdgcn_exp2f(s[0] - M2);
+        M = M2;
+        mx = fmaxf(mx, s[3]);
+    }
+    *reinterpret_cast<f32x2 *>(out + row * 2) = (f32x2){M + __log2f(l), mx};
+}
+
+// ------------------------------------------------------------------------------------------
 // K3: one wave per row.  loss, dh, row scalars for the dW sweep.
 //   dL/dx_j = p_j (u_j / S - G) - [j = y] u_y p_y / clip(p_y),  G = Pu / S - u_y p_y / clip(p_y)
 //   (u = 1, S = 1, G = 0 on rows that never leave the clip range; plain variant: p_j - [j = y])
@@ -528,8 +831,9 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
         U[e] = 0.f;
         Ud[e] = 0.f;
         for (int p = 0; p < a.parts; ++p) {
-            // part p's sums are relative to its own reference m2_p: 2^(m2_p - lse2) makes them probabilities
-            const float f = __builtin_amdgcn_exp2f(a.st1[((int64_t)p * a.R + row) * 4] - lse2);
+            // part p's sums are relative to its own reference m2_p: 2^(m2_p - lse2) makes them probabilities (the lse-first
+            // sweep accumulated probabilities to begin with)
+            const float f = a.rowstat ? 1.f : __builtin_amdgcn_exp2f(a.st1[((int64_t)p * a.R + row) * 4] - lse2);
             U[e] += f * a.u[((int64_t)p * a.R + row) * KD + d];
             if (clipped) Ud[e] += a.ud[((int64_t)p * a.R + row) * KD + d];     // the second sweep ran against lse2 itself
         }
@@ -549,12 +853,19 @@ __global__ void __launch_bounds__(256) vce_combine_kernel(VceArgs a) {
             const f32x4 q = *reinterpret_cast<const f32x4 *>(a.sp + ((int64_t)p * a.R + row) * 4);
             nu += q[0]; Pc += q[1]; ntop += q[2];
         }
+        // (the lse-first sweep counts the entries BELOW the range, the padding rows of the last W tile among them)
+        if (a.rowstat) nu = (float)a.V - (nu - (float)(((a.V + 127) >> 7) * 128 - a.V)) - ntop;
         // Does the dominant entry (p > 1/2, if the row has one) exceed 1 - 1e-7?  Exactly when all the OTHER entries together
         // stay below 1e-7: none of them inside the clip range (each of those alone is >= 1e-7) and the mass Pc of the ones
         // below it -- a sum of tiny numbers, exact to fp32 rounding -- under 1e-7.  (1 - p itself is not representable
         // there, and 2^(x log2e - lse2) is off by 1e-6 at logits of +-50: a decision read off p flipped between the kernels.)
         all_out = ntop > 0.5f && nu < 0.5f && Pc < VCE_EPS;
-        if (all_out) {
+        // (lse-first form: every row went through the clipped sweep; one with every probability inside the range -- all V
+        // entries counted -- is an unclipped row and takes the unclipped formulas, to the bit)
+        if (a.rowstat && nu + ntop >= (float)a.V) { clipped = false; all_out = false; }
+        if (!clipped) {
+            loss = lse - xy;
+        } else if (all_out) {
             // every probability is outside the clip range: the loss is a constant of the row, its gradient exactly zero
             const float S = (1.0f - VCE_EPS) + VCE_EPS * ((float)a.V - 1.0f);
             loss = logf(S) - logf(py > 0.5f ? 1.0f - VCE_EPS : VCE_EPS);
@@ -926,14 +1237,73 @@ template <int KD> static size_t vce_dw_lds() {
 
 extern "C" int64_t b4c_vocab_ce_workspace_bytes(int64_t R, int V, int K) {
     if (R <= 0 || V <= 0 || !vce_shape_ok(K)) return 0;
-    const int64_t fwd = (int64_t)8 * R * (4 + 2 * (int64_t)K + 4) * 4;   // 8 = the largest vocabulary split
+    // 8 = the largest vocabulary split; + the lse-first form's own statistics (8 parts x R x 4, and 2 per row merged)
+    const int64_t fwd = (int64_t)8 * R * (4 + 2 * (int64_t)K + 4) * 4 + (int64_t)R * (8 * 4 + 2) * 4 + 64;
     // vocabulary-major scratch of the label term; deterministic form: + sort keys, order and the sort's own workspace
     const int64_t dw = (int64_t)V * K * 4 + 64 + R * 12 + b4c_sort_ids_workspace_bytes(R, V + 1);
     return fwd > dw ? fwd : dw;
 }
 
+// The "lse first" form (round 4): lse sweep -> per-row {lse2, max x} -> ONE exact sweep at one wave per SIMD -> combine.
+// B4C_VCE_FORM=online|exact selects (A/B on one library); TF's clip semantics only (the plain variant needs one sweep as it is).
+static bool vce_exact_form() {
+    static const char *e = getenv("B4C_VCE_FORM");
+    return e ? (e[0] == 'e') : false;
+}
+
+template <int KD>
+static int vce_fwd_exact_launch(VceArgs a, hipStream_t st) {
+    // workspace: [exact sweep: sp | u | ud (its own `parts`)] [lse sweep: st1 (parts_st)] [rowstat]
+    const int nh = vce_token_nh(a.R);
+    const int64_t ntt_l = ceil_div64(a.R, 128 * nh), ntt = ceil_div64(a.R, 128);
+    const int nvt = (a.V + 127) / 128;
+    float *ws = a.st1;
+    VceArgs l = a;                                     // the lse sweep (MODE 0 of the token kernel)
+    l.parts = vce_pick_split(ntt_l, nvt, 0.005);
+    l.ntt = (int)ntt_l;
+    a.parts = vce_pick_split(ntt, nvt, 0.01);
+    a.ntt = (int)ntt;
+    a.sp = ws;
+    a.u = a.sp + (int64_t)a.parts * a.R * 4;
+    a.ud = a.u + (int64_t)a.parts * a.R * KD;
+    l.st1 = a.ud + (int64_t)a.parts * a.R * KD;
+    float *rowstat = l.st1 + (int64_t)l.parts * a.R * 4;
+    a.st1 = l.st1;
+    a.parts_st = l.parts_st = l.parts;
+    a.rowstat = rowstat;
+    const size_t lds_l = vce_token_lds<KD>(), lds_x = vce_exact_lds<KD>();
+    static thread_local bool done = false;
+    if (!done) {
+        vce_allow_lds(vce_token_kernel<KD, 0, 1>, lds_l); vce_allow_lds(vce_token_kernel<KD, 0, 2>, lds_l);
+        vce_allow_lds(vce_exact_kernel<KD>, lds_x);
+        done = true;
+    }
+    static const bool dbg = getenv("B4C_VCE_TIMING") != nullptr;
+    static hipEvent_t ev[4];
+    static bool have = false;
+    if (dbg) {
+        if (have && hipEventQuery(ev[3]) == hipSuccess) {
+            float t1 = 0, t2 = 0, t3 = 0;
+            (void)hipEventElapsedTime(&t1, ev[0], ev[1]); (void)hipEventElapsedTime(&t2, ev[1], ev[2]); (void)hipEventElapsedTime(&t3, ev[2], ev[3]);
+            fprintf(stderr, "[vce_fwd exact] previous call: lse sweep %.3f ms, exact sweep %.3f ms, combine %.3f ms (parts %d / %d)\n", t1, t2, t3, l.parts, a.parts);
+        }
+        if (!have) { for (auto &e : ev) (void)hipEventCreate(&e); have = true; }
+        (void)hipEventRecord(ev[0], st);
+    }
+    if (nh == 2) vce_token_kernel<KD, 0, 2><<<(unsigned)(ntt_l * l.parts), 512, lds_l, st>>>(l);
+    else vce_token_kernel<KD, 0, 1><<<(unsigned)(ntt_l * l.parts), 512, lds_l, st>>>(l);
+    vce_rowstat_kernel<<<(unsigned)ceil_div64(a.R, 256), 256, 0, st>>>(l, rowstat);
+    if (dbg) (void)hipEventRecord(ev[1], st);
+    vce_exact_kernel<KD><<<(unsigned)(ntt * a.parts), 256, lds_x, st>>>(a);
+    if (dbg) (void)hipEventRecord(ev[2], st);
+    vce_combine_kernel<KD><<<(unsigned)ceil_div64(a.R, 4), 256, 0, st>>>(a);
+    if (dbg) (void)hipEventRecord(ev[3], st);
+    return b4c_check_launch("vocab_ce_fwd (lse first)");
+}
+
 template <int KD>
 static int vce_fwd_launch(VceArgs a, hipStream_t st) {
+    if (a.variant == B4C_CE_TF && vce_exact_form()) return vce_fwd_exact_launch<KD>(a, st);
     const int nh = vce_token_nh(a.R);
     const int64_t ntt = ceil_div64(a.R, 128 * nh);
     const int nvt = (a.V + 127) / 128;

@@ -67,7 +67,9 @@ class GateRecorder:
                     rows = token_rows
                     flat[rows] = pat[:, :F]
                 else:                                   # rows-only pattern of the last layer
-                    assert pat.shape[0] == rows_flat.shape[0], (pat.shape, rows_flat.shape)
+                    # (the sync-free form runs on B x max_masked_per_row rows: the real ones first, in mask order, zero rows after)
+                    assert pat.shape[0] >= rows_flat.shape[0], (pat.shape, rows_flat.shape)
+                    pat = pat[:rows_flat.shape[0]]
                     rows = rows_flat
                     flat[rows] = pat[:, :F]
                 mask = flat.reshape(z.shape)
@@ -75,7 +77,7 @@ class GateRecorder:
                 if rows is not None:
                     zc, oc, mc = zc[rows], oc[rows], mc[rows]
             else:
-                mask = pat[:, :z.shape[-1]]
+                mask = pat[:z.shape[0], :z.shape[-1]]
                 zc, oc, mc = z.detach(), own, mask
             diff = oc != mc
             rms = float(zc.double().pow(2).mean().sqrt()) or 1.0
