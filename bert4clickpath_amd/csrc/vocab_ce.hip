@@ -91,6 +91,37 @@ template <int KD> struct VTile {
                                                      (row * ld + ((slot ^ swz(row)) << 3)) * 2, 0, 0, 0);
         }
     }
+    // one DMA instruction of the same transfer (piece i of NIT * 512 / NT; a 256-thread workgroup spreads them over its loop)
+    template <int NT>
+    static __device__ __forceinline__ void dma_piece(const bf16_t *__restrict__ P, int ld, int64_t row0, int64_t nrows, char *dst, int tid, int i) {
+        const int64_t left = nrows - row0;
+        const __amdgpu_buffer_rsrc_t rs = vce_rsrc(P + row0 * ld, left < 128 ? left : 128, (int64_t)ld * 2);
+        const int c = tid + i * NT, row = c / CH, slot = c % CH;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst + ((c & ~63) << 4)), 16,
+                                                 (row * ld + ((slot ^ swz(row)) << 3)) * 2, 0, 0, 0);
+    }
+    // The same piece as inline assembly, for a loop whose LDS slots are run-time values: through the builtin the compiler
+    // cannot tell the DMA's destination from the slots the loop's ds_reads address and parks every wave on vmcnt(0) after
+    // each piece (400 cycles per piece measured).  Here it sees no LDS write at all: the caller orders the tile's arrival
+    // against its first read itself (s_waitcnt vmcnt(0) + barrier), as every sweep of this file does anyway.
+    // lds_base: LDS byte address of the slot (wave-uniform); wave: the wave's index (wave-uniform).
+    template <int NT>
+    static __device__ __forceinline__ void dma_piece_asm(const bf16_t *__restrict__ P, int ld, int64_t row0, int64_t nrows, unsigned lds_base,
+                                                         int wave, int lane, int i) {
+        const int64_t left = nrows - row0;
+        int64_t bytes = (left < 0 ? 0 : (left < 128 ? left : 128)) * (int64_t)ld * 2;
+        if (bytes > 0x3FFFFFF0ll) bytes = 0x3FFFFFF0ll;
+        const uint64_t base = (uint64_t)(P + row0 * ld);
+        vu32x4 rs;
+        rs[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
+        rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xFFFFu);
+        rs[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+        rs[3] = 0x00020000u;
+        const int c = wave * 64 + lane + i * NT, row = c / CH, slot = c % CH;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((wave * 64 + i * NT) << 4));
+        const unsigned voff = (unsigned)((row * ld + ((slot ^ swz(row)) << 3)) * 2);
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(voff), "s"(rs) : "m0");
+    }
     // per-lane offsets, relative to a row base that is a multiple of 16 rows:
     //   direct fragment (row r, k-step ks, half hf): 16 B
     static __device__ __forceinline__ int frag_off(int r, int ks, int hf) { return chunk_off(r, 2 * ks + hf); }
@@ -522,7 +553,7 @@ __global__ void __launch_bounds__(512, 2) vce_token_kernel(VceArgs a) {
 // per SIMD) cover the tile's arrival by LDS-DMA (~2,900 cycles per CU) at 128 tokens per workgroup.
 // ------------------------------------------------------------------------------------------
 template <int KD> static size_t vce_exact_lds() {
-    const size_t tiles = 2 * (size_t)VTile<KD>::BYTES + 2 * 128 * 4;
+    const size_t tiles = 3 * (size_t)VTile<KD>::BYTES + 3 * 128 * 4;          // a ring of three W tiles + their bias
     const size_t outs = (size_t)4 * 32 * (KD + 4) * 4 + 4 * 64 * 16;
     return tiles > outs ? tiles : outs;
 }
@@ -533,7 +564,8 @@ __global__ void __launch_bounds__(256, 1) vce_exact_kernel(VceArgs a) {
     constexpr int NKS = KD / 16, NDT = KD / 32, STR = VTile<KD>::STR;
     constexpr int TILE_B = VTile<KD>::BYTES;
     constexpr int NPF = 2 * NDT;                        // transposed fragments of one 32-row tile
-    float *sBias = reinterpret_cast<float *>(smem + 2 * TILE_B);     // [2][128]
+    constexpr int NDMA = VTile<KD>::NIT * 2;              // DMA instructions per thread and W tile (256 threads)
+    constexpr int BIAS0 = 3 * TILE_B;                   // bias ring [3][128] floats behind the tile ring
     const int unit = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -557,25 +589,50 @@ __global__ void __launch_bounds__(256, 1) vce_exact_kernel(VceArgs a) {
 
     bf16x8 hfr[NKS];
     vce_load_hfrag<KD>(a.h, a.ld_h, tok, a.R, hf, hfr);
-    int foff[NKS], toff[NDT][2];
+
+    // ---- W tiles: a ring of three LDS slots.  Tile t is read while the chain of tile t + 1's first rows already runs and
+    // tile t + 2 is on its way (LDS-DMA).  Slot bases are run-time values: every per-lane LDS address is a VGPR (fragment
+    // offset + slot base) + an immediate (the 32-row tile inside the W tile) ----
+    int aLc[NKS], aLn[NKS];          // direct fragments: this W tile / the next one
+    int aP[NDT][2];                  // transposed fragments: this W tile
+    int aBc, aBn;                    // bias quads
+    // (absolute LDS byte addresses: formed from `smem + offset` the compiler re-adds the array's base in front of every read)
+    const int lds0i = (int)(size_t)(__attribute__((address_space(3))) char *)smem;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) foff[ks] = VTile<KD>::frag_off(r, ks, hf);
+    for (int ks = 0; ks < NKS; ++ks) { aLc[ks] = lds0i + VTile<KD>::frag_off(r, ks, hf); aLn[ks] = aLc[ks] + TILE_B; }
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-        toff[dt][0] = VTile<KD>::tr_off(hf, li, g, dt, 0);
-        toff[dt][1] = VTile<KD>::tr_off(hf, li, g, dt, 1);
+        aP[dt][0] = lds0i + VTile<KD>::tr_off(hf, li, g, dt, 0);
+        aP[dt][1] = lds0i + VTile<KD>::tr_off(hf, li, g, dt, 1);
     }
+    aBc = lds0i + BIAS0 + 16 * hf;
+    aBn = aBc + 512;
+    int slot_c = 0;                  // ring slot of the W tile whose probabilities are being formed
 
+    // the DMA of W tile vt into ring slot `slot`, one piece (1 KiB per wave instruction) at a time, and the tile's bias
+    const unsigned lds0 = (unsigned)lds0i;
     float breg = 0.f;
-    auto fetch = [&](int vt, int buf) {
-        VTile<KD>::template dma<256>(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, smem + buf * TILE_B, tid);
+    auto dma_piece = [&](int vt, int slot, int i) __attribute__((always_inline)) {
+        VTile<KD>::template dma_piece_asm<256>(a.wt, a.ld_w, (int64_t)vt * 128, vt < vt1 ? a.V : 0, lds0 + (unsigned)(slot * TILE_B), wave, lane, i);
+    };
+    auto bias_fetch = [&](int vt) __attribute__((always_inline)) {
         if (tid < 128) {
             const int v = vt * 128 + tid;
             breg = (vt < vt1 && v < a.V) ? (a.bias ? a.bias[v] : 0.f) : -INFINITY;   // rows past V: logit = -inf, p = 0
         }
     };
-    fetch(vt0, 0);
-    if (tid < 128) sBias[tid] = breg;
+    auto bias_store = [&](int slot) __attribute__((always_inline)) {
+        if (tid < 128) *reinterpret_cast<float *>(smem + BIAS0 + slot * 512 + tid * 4) = breg;
+    };
+    // tiles vt0 (slot 0) and vt0 + 1 (slot 1) before anything else
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) dma_piece(vt0, 0, i);
+    bias_fetch(vt0);
+    bias_store(0);
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) dma_piece(vt0 + 1, 1, i);
+    bias_fetch(vt0 + 1);
+    bias_store(1);
     VCE_DMA_WAIT();
     __syncthreads();
 
@@ -593,63 +650,70 @@ __global__ void __launch_bounds__(256, 1) vce_exact_kernel(VceArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) { U[dt][t] = 0.f; Ud[dt][t] = 0.f; }
 
-    // ---- the pieces of one 32-row tile ----
-    // direct (A operand of the logits chain) and transposed (A operand of P W) fragments of tile rt
-    auto ldL = [&](const char *w, int rt, bf16x8 (&f)[NKS]) __attribute__((always_inline)) {
+    // The pipeline: global step s (one 32-row tile of the vocabulary) does
+    //   VALU : probabilities of tile s (logits in acc[s & 3]) -> pk / pl[s & 1], Pc, counts
+    //   MFMA : logits chain of tile s + 1 into acc[(s + 1) & 3];  U / Ud += W^T P of tile s - 1 (pk / pl[(s - 1) & 1])
+    //   LDS  : every fragment register is re-loaded right behind the MFMA that consumed it with what the NEXT step's MFMA of
+    //          that slot needs: the direct fragments (and the bias, into acc[(s + 2) & 3]) of tile s + 2, the transposed
+    //          fragments of tile s.  One set of fragment registers, a full step of latency cover; four logits accumulators.
+    // A W tile is four steps (RT = 0 .. 3): the re-loads of RT = 2, 3 reach into the NEXT W tile (aLn / aBn).
+    // The accumulators of the logits chain must be ordinary VGPRs: the VALU reads every entry, and with more than 256
+    // registers in use the compiler keeps MFMA results in the accumulation half of the file (one v_accvgpr_read per entry).
+    // The chain's MFMA is therefore inline assembly with VGPR operands; its results are first read a whole step later
+    // (>= 16 MFMAs), so no hazard wait is due -- except after the fill step, which waits explicitly.  The two accumulations
+    // (Pc, counts) are inline assembly as well: left to the compiler they sink to the end of the W tile (64 masks and values
+    // kept alive: spills), out of the MFMA gaps they are meant to fill.
+    f32x16 acc[4];
+    bf16x8 Lf[NKS], Pf[NPF], pk[2][2], pl[2][2];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) f[ks] = *reinterpret_cast<const bf16x8 *>(w + rt * 32 * STR + foff[ks]);
+    for (int i = 0; i < NPF; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Pf[i][j] = (bf16_t)0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { pk[i][k][j] = (bf16_t)0.f; pl[i][k][j] = (bf16_t)0.f; }
+    const float l2e = VCE_LOG2E;
+    typedef const __attribute__((address_space(3))) bf16x8 *lds_bf8_t;
+    typedef const __attribute__((address_space(3))) f32x4 *lds_f4_t;
+    typedef vs16x4 __attribute__((address_space(3))) *lds_tr_t;
+    auto ldsL = [&](int addr, int imm) __attribute__((always_inline)) { return *(lds_bf8_t)(size_t)(unsigned)(addr + imm); };
+    auto ldsT = [&](int a0, int a1, int imm) __attribute__((always_inline)) {
+        const vs16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(size_t)(unsigned)(a0 + imm));
+        const vs16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(size_t)(unsigned)(a1 + imm));
+        const vs16x8 w = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+        return __builtin_bit_cast(bf16x8, w);
     };
-    auto ldL1 = [&](const char *w, int rt, bf16x8 (&f)[NKS], int ks) __attribute__((always_inline)) {
-        f[ks] = *reinterpret_cast<const bf16x8 *>(w + rt * 32 * STR + foff[ks]);
-    };
-    auto ldP1 = [&](const char *w, int rt, bf16x8 (&f)[NPF], int i) __attribute__((always_inline)) {
-        const int s2 = i / NDT, dt = i % NDT;
-        const char *wb = w + (rt * 32 + 16 * s2) * STR;
-        f[i] = vce_frag_tr2(wb + toff[dt][0], wb + toff[dt][1]);
-    };
-    // the logits accumulator of tile rt starts as the rows' bias (straight from LDS into the accumulator's registers)
-    auto ldB = [&](const float *bs, int rt, f32x16 &acc) __attribute__((always_inline)) {
+    auto ldsB = [&](int addr, int rt, f32x16 &acc_) __attribute__((always_inline)) {
 #pragma unroll
         for (int tq = 0; tq < 4; ++tq) {
-            const f32x4 q = *reinterpret_cast<const f32x4 *>(bs + rt * 32 + 8 * tq + 4 * hf);
-            acc[4 * tq] = q[0]; acc[4 * tq + 1] = q[1]; acc[4 * tq + 2] = q[2]; acc[4 * tq + 3] = q[3];
+            const f32x4 q = *(lds_f4_t)(size_t)(unsigned)(addr + (rt * 32 + 8 * tq) * 4);
+            acc_[4 * tq] = q[0]; acc_[4 * tq + 1] = q[1]; acc_[4 * tq + 2] = q[2]; acc_[4 * tq + 3] = q[3];
         }
     };
-
-    // One pipeline step over a W tile in LDS (`w`, bias `bs`), all indices compile-time:
-    //   VALU : the probabilities of tile K (logits in acc[K % 3]) -> pk[K & 1] (all entries, bf16) / pl[K & 1] (the ones below
-    //          the clip range), Pc, nlow, nhi
-    //   MFMA : DO_L: the logits chain of tile K + 1 into acc[(K + 1) % 3] from Lf;
-    //          DO_P: U / Ud += W^T P of tile K - 1 from Pf, pk / pl[(K - 1) & 1]
-    //   LDS  : every fragment register is re-loaded right behind the MFMA that consumed it, with the fragment the NEXT step's
-    //          MFMA of the same slot needs (LD_L: direct fragment of tile K + 2; LD_P: transposed fragment of tile K): one set of
-    //          fragment registers, a full step of latency cover.  LD_L also: the bias of tile K + 2 into acc[(K + 2) % 3], the
-    //          accumulator whose probabilities were finished a step ago (three logits accumulators: 48 registers).
-    // The accumulators of the logits chain must be ordinary VGPRs: the VALU reads every entry, and with more than 256 registers
-    // in use the compiler keeps MFMA results in the accumulation half of the file (one v_accvgpr_read per entry: +14 % vector
-    // instructions).  The chain's MFMA is therefore written as inline assembly with VGPR operands; its results are first read
-    // a whole step (>= 16 MFMAs) later, so no hazard wait is due.  The two accumulations (Pc, counts) are inline assembly as
-    // well: left to the compiler they sink to the end of the tile (64 masks and 64 values kept alive: spills), out of the
-    // MFMA gaps they are meant to fill.
-    f32x16 acc[3];
-    bf16x8 Lf[NKS], Pf[NPF], pk[2][2], pl[2][2];
-    const float l2e = VCE_LOG2E;
-    auto step = [&](auto KK, auto DOE, auto DOL, auto DOP, auto LDL, auto LDP, auto HI, const char *w, const float *bs) __attribute__((always_inline)) {
-        constexpr int K = decltype(KK)::value;
-        constexpr bool do_e = decltype(DOE)::value, do_l = decltype(DOL)::value, do_p = decltype(DOP)::value;
-        constexpr bool ld_l = decltype(LDL)::value, ld_p = decltype(LDP)::value, hi = decltype(HI)::value;
-        constexpr int cur = K & 1, prv = (K + 1) & 1;                          // (K - 1) & 1 == (K + 1) & 1
-        constexpr int ac = (K + 3) % 3, an = (K + 4) % 3, an2 = (K + 5) % 3;    // accumulators of tiles K, K + 1, K + 2
-        constexpr int n_l = do_l ? NKS : 0, n_p = do_p ? 4 * NDT : 0, n_mfma = n_l + n_p;
+    // DOE: probabilities of this step's tile; DOC: chain of the next; DOP: P W of the previous; LDP: re-load the transposed
+    // fragments; DMA: the W tile after the next one is requested piece by piece in this step's gaps (vt_dma -> slot_dma)
+    auto step = [&](auto RTT, auto DOE, auto DOC, auto DOP, auto LDP, auto DMA, auto HI, int vt_dma, int slot_dma) __attribute__((always_inline)) {
+        constexpr int RT = decltype(RTT)::value;
+        constexpr bool do_e = decltype(DOE)::value, do_c = decltype(DOC)::value, do_p = decltype(DOP)::value;
+        constexpr bool ld_p = decltype(LDP)::value, dma = decltype(DMA)::value, hi = decltype(HI)::value;
+        constexpr int cur = RT & 1, prv = (RT + 1) & 1;
+        constexpr int ac = RT & 3, an = (RT + 1) & 3, an2 = (RT + 2) & 3;
+        constexpr int rt2 = (RT + 2) & 3;                      // the 32-row tile the direct re-loads fetch ...
+        constexpr bool nextw = RT >= 2;                          // ... of the next W tile
+        constexpr int n_c = do_c ? NKS : 0, n_p = do_p ? 4 * NDT : 0, n_mfma = n_c + n_p;
         constexpr int n_gap = n_mfma > 0 ? n_mfma : 1;
         float pv0 = 0.f, pv1 = 0.f, pl0 = 0.f, pl1 = 0.f;
-        // one entry: probability against the row's final lse, its share of Pc and of the counts
         auto entry = [&](int t, float &pv, float &plo) __attribute__((always_inline)) {
             pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[ac][t], l2e, -lse2));
             const bool low = pv < VCE_EPS;
             plo = low ? pv : 0.f;
             asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(Pc) : "v"(plo));
             asm volatile("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(nlow) : "s"(__builtin_amdgcn_ballot_w64(low)) : "vcc");
+            // (tried: compare, select and carry-in through VCC in one assembly block -- v_cmp_e32 / s_nop 1 / v_cndmask_e32 /
+            // v_addc_co_e32 -- 1.5 % faster and WRONG on the lanes with bit 2 clear; not understood, not kept)
             unsigned &nhi_ = nhi;          // (named outside the discarded branch: the capture must not depend on `hi`)
             if constexpr (hi) asm volatile("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(nhi_) : "s"(__builtin_amdgcn_ballot_w64(pv > 0.5f)) : "vcc");
         };
@@ -664,81 +728,97 @@ __global__ void __launch_bounds__(256, 1) vce_exact_kernel(VceArgs a) {
                 pl[cur][t0 >> 3][t0 & 7] = (bf16_t)pl0; pl[cur][t0 >> 3][t1 & 7] = (bf16_t)pl1;
             }
         };
-        if (ld_l) ldB(bs, K + 2, acc[an2]);
+        if (do_c) ldsB(nextw ? aBn : aBc, rt2, acc[an2]);
 #pragma unroll
         for (int i = 0; i < n_gap; ++i) {
             __builtin_amdgcn_sched_barrier(0);
-            if (i < n_l) {
+            if (i < n_c) {
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[an]) : "v"(Lf[i]), "v"(hfr[i]));
-                if (ld_l) ldL1(w, K + 2, Lf, i);
+                Lf[i] = ldsL(nextw ? aLn[i] : aLc[i], rt2 * 32 * STR);
             } else if (i < n_mfma) {
-                const int q = i - n_l, f = q / 2;                 // fragment f = s2 * NDT + dt serves U then Ud
+                const int q = i - n_c, f = q / 2;                 // fragment f = s2 * NDT + dt serves U then Ud
                 const int s2 = f / NDT, dt = f % NDT;
                 if ((q & 1) == 0) U[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Pf[f], pk[prv][s2], U[dt], 0, 0, 0);
                 else {
                     Ud[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Pf[f], pl[prv][s2], Ud[dt], 0, 0, 0);
-                    if (ld_p) ldP1(w, K, Pf, f);
+                    if (ld_p) {
+                        const int o = (RT * 32 + 16 * s2) * STR;
+                        Pf[f] = ldsT(aP[dt][0], aP[dt][1], o);
+                    }
                 }
+            }
+            if (dma) {
+#pragma unroll
+                for (int d = (i * NDMA) / n_gap; d < ((i + 1) * NDMA) / n_gap; ++d) dma_piece(vt_dma, slot_dma, d);
             }
             if (do_e) {
 #pragma unroll
                 for (int c = (i * 24) / n_gap; c < ((i + 1) * 24) / n_gap; ++c) chunk(c);
             }
         }
-        // a step without P W MFMAs has no slot behind which the transposed fragments could be re-loaded: load them here
-        if (ld_p && !do_p) {
-#pragma unroll
-            for (int f = 0; f < NPF; ++f) ldP1(w, K, Pf, f);
-        }
         __builtin_amdgcn_sched_barrier(0);
     };
     constexpr std::integral_constant<bool, true> Y{};
     constexpr std::integral_constant<bool, false> N{};
-    constexpr std::integral_constant<int, 0> K0{};
-    constexpr std::integral_constant<int, 1> K1{};
-    constexpr std::integral_constant<int, 2> K2{};
-    constexpr std::integral_constant<int, 3> K3{};
-    constexpr std::integral_constant<int, 4> K4{};
-    constexpr std::integral_constant<int, -1> KM{};
+    constexpr std::integral_constant<int, 0> R0{};
+    constexpr std::integral_constant<int, 1> R1{};
+    constexpr std::integral_constant<int, 2> R2{};
+    constexpr std::integral_constant<int, 3> R3{};
 
-    auto tile = [&](auto BUF, auto HI, int vt) __attribute__((always_inline)) {
-        constexpr int buf = decltype(BUF)::value;
-        const char *w = smem + buf * TILE_B;
-        const float *bs = sBias + buf * 128;
-        // fragments of tile 0, bias of tiles 0 and 1, the DMA requests of the next W tile (the other buffer was last read one tile
-        // ago, behind the previous barrier), then the logits chain of tile 0, every fragment register re-loaded for tile 1 behind
-        // its MFMA
-        XSTAMP(7);
-        ldL(w, 0, Lf); ldB(bs, 0, acc[0]); ldB(bs, 1, acc[1]);
-        fetch(vt + 1, buf ^ 1);
-        //            VALU   chain   P W     re-loads
-        step(KM, N, Y, N, N, N, HI, w, bs);      //        | chain(0)         |
-        ldL(w, 1, Lf);
-        // (the chain above is inline assembly: the compiler places no hazard wait between it and the first read of its result)
-        asm volatile("s_nop 15\n\ts_nop 7");
-        XSTAMP(0);
-        step(K0, Y, Y, N, Y, Y, HI, w, bs);      // p(0)   | chain(1)         | L(2), bias(2), P(0)
-        XSTAMP(1);
-        step(K1, Y, Y, Y, Y, Y, HI, w, bs);      // p(1)   | chain(2), PW(0)  | L(3), bias(3), P(1)
-        XSTAMP(2);
-        step(K2, Y, Y, Y, N, Y, HI, w, bs);      // p(2)   | chain(3), PW(1)  | P(2)
-        XSTAMP(3);
-        step(K3, Y, N, Y, N, Y, HI, w, bs);      // p(3)   | PW(2)            | P(3)
-        XSTAMP(4);
-        step(K4, N, N, Y, N, N, HI, w, bs);      //        | PW(3)
-        XSTAMP(5);
-        if (tid < 128) sBias[(buf ^ 1) * 128 + tid] = breg;
-        VCE_DMA_WAIT();
-        B4C_LDS_BARRIER();
-        XSTAMP(6);
-    };
     auto sweep = [&](auto HI) __attribute__((always_inline)) {
-        for (int vt = vt0; vt < vt1; vt += 2) {
-            tile(std::integral_constant<int, 0>{}, HI, vt);
-            if (vt + 1 < vt1) tile(std::integral_constant<int, 1>{}, HI, vt + 1);
+        // fill: fragments and bias of the first 32-row tile, its chain (as "step 3 of the W tile before": the re-loads reach
+        // into the NEXT W tile, which is the first one), then a wait: nothing orders the inline-assembly MFMAs' results
+        // against the VALU reads that follow at once
+        {
+            // the first W tile plays "next": aLn / aBn point at slot 0 for the fill step
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) aLn[ks] -= TILE_B;
+            aBn -= 512;
+            ldsB(aBn, 0, acc[0]);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) Lf[ks] = ldsL(aLn[ks], 0);
+            step(R3, N, Y, N, N, N, HI, 0, 0);      // chain(0) into acc[0]; re-loads: L(1), bias(1) -> acc[1]
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) aLn[ks] += TILE_B;
+            aBn += 512;
+            asm volatile("s_nop 15\n\ts_nop 7");
         }
+        for (int vt = vt0; vt < vt1; ++vt) {
+            XSTAMP(7);
+            step(R0, Y, Y, Y, Y, N, HI, 0, 0);
+            XSTAMP(0);
+            step(R1, Y, Y, Y, Y, N, HI, 0, 0);
+            XSTAMP(1);
+            // W tile vt + 1 has landed (requested a tile ago) and every wave is past its last read of tile vt - 1: that slot
+            // takes tile vt + 2, requested in the gaps of the next step
+            bias_store((slot_c + 1) % 3);      // the bias requested together with tile vt + 1, one W tile ago
+            VCE_DMA_WAIT();
+            B4C_LDS_BARRIER();
+            XSTAMP(6);
+            const int slot_n2 = (slot_c + 2) % 3;
+            bias_fetch(vt + 2);
+            step(R2, Y, Y, Y, Y, Y, HI, vt + 2, slot_n2);
+            XSTAMP(2);
+            step(R3, Y, Y, Y, Y, N, HI, 0, 0);
+            XSTAMP(3);
+            // the ring turns: next -> current
+            const int d_c = ((slot_c + 1) % 3 - slot_c) * TILE_B, d_n = ((slot_c + 2) % 3 - (slot_c + 1) % 3) * TILE_B;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) { aLc[ks] += d_c; aLn[ks] += d_n; }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) { aP[dt][0] += d_c; aP[dt][1] += d_c; }
+            aBc += d_c / TILE_B * 512;
+            aBn += d_n / TILE_B * 512;
+            slot_c = (slot_c + 1) % 3;
+        }
+        // drain: P W of the last 32-row tile
+        step(R0, N, N, Y, N, N, HI, 0, 0);
+        XSTAMP(4);
     };
     if (anyhi) sweep(Y); else sweep(N);
+    // the last W tile's request (a tile past this part: zeros) may still be on its way into the ring, and the compiler knows
+    // nothing of the inline-assembly DMA: it must have landed before the ring's memory is reused below
+    VCE_DMA_WAIT();
 #ifdef VCE_SCAN_STAMPS
     if (lane == 0 && blockIdx.x < 2048)
         for (int k = 0; k < 8; ++k) g_vce_xstamps[(blockIdx.x * 4 + wave) * 8 + k] = st_[k];

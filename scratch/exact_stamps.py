@@ -20,8 +20,8 @@ lib.b4c_debug_vce_xstamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 lib.b4c_debug_vce_xstamps(buf.ctypes.data, buf.nbytes)
 s = buf.reshape(2048, 4, 8).astype(np.float64)
 s = s[s.sum((1, 2)) > 0]
-names = ['prologue: frags + bias + DMA issue + chain(0)', 'K0: p(0) | chain(1)', 'K1: p(1) | chain(2), PW(0)', 'K2: p(2) | chain(3), PW(1)',
-         'K3: p(3) | PW(2)', 'K4: PW(3)', 'bias store, vmcnt(0), barrier', 'loop overhead']
+names = ['R0: p(0) | chain(1), PW(prev 3)', 'R1: p(1) | chain(2), PW(0)', 'R2: p(2) | chain(3), PW(1) + DMA issue', 'R3: p(3) | chain(next 0), PW(2)',
+         'drain (once)', '-', 'bias store, vmcnt(0), barrier', 'ring turn / loop overhead (+ fill, once)']
 tot = s.sum(2).mean()
 ntile = 391 / float(os.environ.get('PARTS', '4'))
 print('workgroups %d; cycles per wave %.0f = %.0f per W tile' % (len(s), tot, tot / ntile))
