@@ -86,6 +86,10 @@ def lib():
             'b4c_attn_bwd_ws': (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
             'b4c_add_dropout_layernorm_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, u64, i32, vp]),
             'b4c_add_dropout_layernorm_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, i32, vp]),
+            'b4c_add_dropout_layernorm_bwd_workspace_bytes': (i64, [i64, i32]),
+            'b4c_add_dropout_layernorm_bwd_ws': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, vp, i64, i32, vp]),
+            'b4c_embed_concat_pe_bwd_sorted_workspace_bytes': (i64, [i32, c.POINTER(i32), i32, i32]),
+            'b4c_embed_concat_pe_bwd_sorted_ws': (i32, [i32, pp, pp, pp, c.POINTER(i32), c.POINTER(i64), f32, vp, i32, i32, i32, i32, f32, u64, vp, i64, i32, vp]),
             'b4c_vocab_rank_workspace_bytes': (i64, [i64, i32, i32]),
             'b4c_vocab_rank': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i64, i64, i32, i32, vp]),
             'b4c_rank_metrics': (i32, [vp, i64, i32, vp, vp, vp]),

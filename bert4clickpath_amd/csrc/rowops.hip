@@ -234,8 +234,12 @@ extern "C" int b4c_embed_concat_pe_bwd(int n_feat, const int64_t *const *h_ids, 
 // (the unsorted kernel runs at the atomic rate, 0.65 ms at C2) become ~2 per distinct id.
 struct EmbedOrder {
     const int32_t *order[B4C_MAX_FEATURES];
+    float *part[B4C_MAX_FEATURES];       // deterministic form: [waves][2][fd] partial sums of the runs that cross a wave boundary
 };
-template <typename T>
+// DET: a run that continues in a neighbouring wave's range is NOT added with float atomics (whose order, and so the sum's last
+// bit, changes from run to run): the wave stores its share -- slot 0: the run comes in from the wave before, slot 1: the run
+// goes on into the wave after -- and embed_bwd_runs_kernel adds the shares of one run in wave order.
+template <typename T, bool DET>
 __global__ void __launch_bounds__(256) embed_bwd_sorted_kernel(EmbedArgs a, EmbedOrder ord, float scale, const T *__restrict__ dout,
                                                                int ld, int64_t T_tok, int d, float rate, uint64_t seed) {
     const int f = blockIdx.y;
@@ -268,6 +272,14 @@ __global__ void __launch_bounds__(256) embed_bwd_sorted_kernel(EmbedArgs a, Embe
         float acc0 = 0.f, acc1 = 0.f;
         int64_t cur = __shfl(my_id, 0);
         auto flush = [&](int64_t id) {
+            if (DET && (id == prev_id || id == next_id)) {
+                if (on) {
+                    float *dst = ord.part[f] + ((p0 >> 6) * 2 + (id == prev_id ? 0 : 1)) * (int64_t)fd + col;
+                    dst[0] = acc0;
+                    dst[1] = acc1;
+                }
+                return;
+            }
             if (on && (acc0 != 0.f || acc1 != 0.f)) {
                 float *row = table + id * fd + col;
                 if (id == prev_id || id == next_id) {
@@ -323,29 +335,99 @@ __global__ void __launch_bounds__(256) embed_bwd_sorted_kernel(EmbedArgs a, Embe
     }
 }
 
+// One wave per wave boundary b (between the 64-entry ranges b and b + 1) and feature: if a run of one id crosses it AND starts in
+// range b, this wave owns the run: tail share of range b, then the head shares of the ranges after it while the run goes on, added
+// in that order into the id's gradient row (a plain read-modify-write: one owner per run, and no other run has this id).
+__global__ void __launch_bounds__(256) embed_bwd_runs_kernel(EmbedArgs a, EmbedOrder ord, int64_t T_tok) {
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (T_tok + 63) >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b + 1 >= nw) return;
+    const int fd = a.fd[f];
+    const int32_t *order = ord.order[f];
+    const int64_t *ids = a.ids[f];
+    const int64_t nrows = a.rows[f];
+    auto id_at = [&](int64_t p) -> int64_t {
+        int64_t id = ids[order[p]];
+        return id < 0 ? 0 : (id >= nrows ? nrows - 1 : id);
+    };
+    const int64_t pb = b << 6;                              // first entry of range b
+    const int64_t id = id_at(pb + 63);
+    if (id_at(pb + 64) != id) return;                       // nothing crosses this boundary
+    if (id_at(pb) == id && b > 0 && id_at(pb - 1) == id) return;      // the run came in from before range b: not its first range
+    const float *part = ord.part[f];
+    float *table = a.table[f];
+    for (int cb = 0; cb < fd; cb += 128) {
+        const int col = cb + 2 * lane;
+        if (col >= fd) continue;
+        const float *t = part + (b * 2 + 1) * (int64_t)fd + col;
+        float s0 = t[0], s1 = t[1];
+        for (int64_t w = b + 1; w < nw; ++w) {
+            const float *h = part + (w * 2) * (int64_t)fd + col;
+            s0 += h[0];
+            s1 += h[1];
+            const int64_t pw = w << 6, last = (pw + 64 <= T_tok ? pw + 63 : T_tok - 1);
+            if (!(id_at(last) == id && last + 1 < T_tok && id_at(last + 1) == id)) break;      // (wave-uniform)
+        }
+        float *row = table + id * fd + col;
+        row[0] += s0;
+        row[1] += s1;
+    }
+}
+
+extern "C" int64_t b4c_embed_concat_pe_bwd_sorted_workspace_bytes(int n_feat, const int *h_dims, int B, int S) {
+    int64_t total = 0;
+    const int64_t nw = ((int64_t)B * S + 63) / 64;
+    for (int f = 0; f < n_feat; ++f) total += nw * 2 * ((h_dims[f] + 1) / 2 * 2) * 4;
+    return total;
+}
+
 extern "C" int b4c_embed_concat_pe_bwd_sorted(int n_feat, const int64_t *const *h_ids, const int32_t *const *h_order,
                                               float *const *h_dtables, const int *h_dims, const int64_t *h_rows, float scale,
                                               const void *dout, int ld_dout, int B, int S, int d_model, float dropout_rate,
                                               uint64_t seed, int dtype, void *stream) {
+    return b4c_embed_concat_pe_bwd_sorted_ws(n_feat, h_ids, h_order, h_dtables, h_dims, h_rows, scale, dout, ld_dout, B, S, d_model,
+                                             dropout_rate, seed, nullptr, 0, dtype, stream);
+}
+
+extern "C" int b4c_embed_concat_pe_bwd_sorted_ws(int n_feat, const int64_t *const *h_ids, const int32_t *const *h_order,
+                                                 float *const *h_dtables, const int *h_dims, const int64_t *h_rows, float scale,
+                                                 const void *dout, int ld_dout, int B, int S, int d_model, float dropout_rate,
+                                                 uint64_t seed, void *workspace, int64_t workspace_bytes, int dtype, void *stream) {
     EmbedArgs a;
     int rc = fill_embed_args(a, n_feat, h_ids, h_dtables, h_dims, h_rows, d_model);
     if (rc) return rc;
     B4C_REQUIRE(dout && h_order && B > 0 && S > 0 && ld_dout >= d_model && ld_dout % 2 == 0, "embed_bwd_sorted: bad shape");
     B4C_REQUIRE((int64_t)B * S < (1ll << 31), "embed_bwd_sorted: more than 2^31 tokens");
     EmbedOrder ord = {};
+    const int64_t T_tok = (int64_t)B * S;
+    const bool det = workspace != nullptr;
+    B4C_REQUIRE(!det || workspace_bytes >= b4c_embed_concat_pe_bwd_sorted_workspace_bytes(n_feat, h_dims, B, S),
+                "embed_bwd_sorted: workspace too small for the deterministic form");
+    float *wsp = (float *)workspace;
     for (int f = 0; f < n_feat; ++f) {
         B4C_REQUIRE(h_order[f], "embed_bwd_sorted: null order for feature %d", f);
         ord.order[f] = h_order[f];
+        B4C_REQUIRE(!det || h_dims[f] % 2 == 0, "embed_bwd_sorted: odd feature width %d", h_dims[f]);
+        ord.part[f] = wsp;
+        if (det) wsp += ((T_tok + 63) / 64) * 2 * h_dims[f];
     }
-    const int64_t T_tok = (int64_t)B * S;
     dim3 grid((unsigned)ceil_div64(T_tok, 256), (unsigned)n_feat);
     hipStream_t st = (hipStream_t)stream;
+#define EMB_SORTED_LAUNCH(TT) do { if (det) embed_bwd_sorted_kernel<TT, true><<<grid, 256, 0, st>>>(a, ord, scale, (const TT *)dout, ld_dout, T_tok, d_model, dropout_rate, seed); \
+        else embed_bwd_sorted_kernel<TT, false><<<grid, 256, 0, st>>>(a, ord, scale, (const TT *)dout, ld_dout, T_tok, d_model, dropout_rate, seed); } while (0)
     if (dtype == B4C_F32)
-        embed_bwd_sorted_kernel<float><<<grid, 256, 0, st>>>(a, ord, scale, (const float *)dout, ld_dout, T_tok, d_model, dropout_rate, seed);
+        EMB_SORTED_LAUNCH(float);
     else if (dtype == B4C_BF16)
-        embed_bwd_sorted_kernel<bf16_t><<<grid, 256, 0, st>>>(a, ord, scale, (const bf16_t *)dout, ld_dout, T_tok, d_model, dropout_rate, seed);
+        EMB_SORTED_LAUNCH(bf16_t);
     else
         B4C_REQUIRE(false, "embed_bwd_sorted: dtype %d", dtype);
+#undef EMB_SORTED_LAUNCH
+    if (det && T_tok > 64) {
+        dim3 g2((unsigned)ceil_div64((T_tok + 63) / 64, 4), (unsigned)n_feat);
+        embed_bwd_runs_kernel<<<g2, 256, 0, st>>>(a, ord, T_tok);
+    }
     return b4c_check_launch("embed_bwd_sorted");
 }
 
@@ -432,19 +514,23 @@ __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const T *__restrict__ x
 
 // backward: dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dout * gamma.
 // dgamma/dbeta: per-thread partials over the block's rows -> LDS -> one atomic per column per block.
-template <typename T, int G, int NP>
+// DET (deterministic form, `partial` != NULL): the threads' partials meet in a fixed order -- through LDS [row group][2][d], summed
+// group by group, the block's sums stored to partial[block][2][d]; ln_bwd_reduce_kernel then adds the blocks in block order.
+template <typename T, int G, int NP, bool DET>
 __global__ void __launch_bounds__(256, 4) add_ln_bwd_kernel(const T *__restrict__ dout, const T *__restrict__ z,
                                                          const float *__restrict__ stats, const float *__restrict__ gamma,
                                                          T *__restrict__ dz, T *__restrict__ dy, float *__restrict__ dgamma,
                                                          float *__restrict__ dbeta, int64_t rows, int d, float rate,
-                                                         uint64_t seed) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [2][d]
+                                                         uint64_t seed, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [2][d]  (DET: [256 / G][2][d])
     const int lane_in_row = threadIdx.x & (G - 1);
     const int rows_per_block = 256 / G;
     const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
     const float inv_d = 1.0f / (float)d;
-    for (int i = threadIdx.x; i < 2 * d; i += 256) red[i] = 0.f;
-    __syncthreads();
+    if (!DET) {
+        for (int i = threadIdx.x; i < 2 * d; i += 256) red[i] = 0.f;
+        __syncthreads();
+    }
     // NP = passes of G * 8 columns a row needs (1 for d <= 128 at G = 16): a runtime pass count kept the second pass's
     // 64 registers allocated
     float pg[NP][8], pb[NP][8];
@@ -500,6 +586,24 @@ __global__ void __launch_bounds__(256, 4) add_ln_bwd_kernel(const T *__restrict_
             }
         }
     }
+    if (DET) {
+        float *mine = red + (threadIdx.x / G) * 2 * d;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int c = (p * G + lane_in_row) * 8;
+            if (c < d) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { mine[c + k] = pg[p][k]; mine[d + c + k] = pb[p][k]; }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * d; i += 256) {
+            float sum = 0.f;
+            for (int grp = 0; grp < rows_per_block; ++grp) sum += red[grp * 2 * d + i];
+            partial[(int64_t)blockIdx.x * 2 * d + i] = sum;
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         {
@@ -518,6 +622,16 @@ __global__ void __launch_bounds__(256, 4) add_ln_bwd_kernel(const T *__restrict_
         atomicAdd(dgamma + i, red[i]);
         atomicAdd(dbeta + i, red[d + i]);
     }
+}
+
+// dgamma[i] += sum over blocks (in block order) of partial[block][0][i]; dbeta likewise
+__global__ void __launch_bounds__(256) ln_bwd_reduce_kernel(const float *__restrict__ partial, int nblocks, int d, float *__restrict__ dgamma,
+                                                            float *__restrict__ dbeta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * d) return;
+    float sum = 0.f;
+    for (int b = 0; b < nblocks; ++b) sum += partial[(int64_t)b * 2 * d + i];
+    if (i < d) dgamma[i] += sum; else dbeta[i - d] += sum;
 }
 
 static int ln_group(int d) {
@@ -555,19 +669,35 @@ extern "C" int b4c_add_dropout_layernorm_fwd(const void *x, const void *y, const
     return b4c_check_launch("add_ln_fwd");
 }
 
+extern "C" int64_t b4c_add_dropout_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
+    if (rows <= 0 || d <= 0) return 0;
+    return (int64_t)1024 * 2 * d * 4;
+}
+
 extern "C" int b4c_add_dropout_layernorm_bwd(const void *dout, const void *z, const float *stats, const float *gamma,
                                              void *dz, void *dy, float *dgamma, float *dbeta, int64_t rows, int d,
                                              float dropout_rate, uint64_t seed, int dtype, void *stream) {
+    return b4c_add_dropout_layernorm_bwd_ws(dout, z, stats, gamma, dz, dy, dgamma, dbeta, rows, d, dropout_rate, seed, nullptr, 0, dtype, stream);
+}
+
+extern "C" int b4c_add_dropout_layernorm_bwd_ws(const void *dout, const void *z, const float *stats, const float *gamma,
+                                                void *dz, void *dy, float *dgamma, float *dbeta, int64_t rows, int d,
+                                                float dropout_rate, uint64_t seed, void *workspace, int64_t workspace_bytes, int dtype,
+                                                void *stream) {
     B4C_REQUIRE(dout && z && stats && gamma && dz && dgamma && dbeta && rows > 0, "add_ln_bwd: null pointer / empty");
+    B4C_REQUIRE(!workspace || workspace_bytes >= b4c_add_dropout_layernorm_bwd_workspace_bytes(rows, d), "add_ln_bwd: workspace too small");
     B4C_REQUIRE(d > 0 && d % 8 == 0 && d <= 64 * 8 * LN_MAX_PASS, "add_ln_bwd: d=%d must be a multiple of 8, <= 1024", d);
     B4C_REQUIRE(dropout_rate == 0.f || dy, "add_ln_bwd: dy required when dropout_rate > 0");
     const int g = ln_group(d);
     int grid = grid_for(rows * g, 256);
     if (grid > 1024) grid = 1024;  // fewer blocks -> fewer dgamma/dbeta atomics (six per CU measured slower than four)
-    const size_t shm = 2 * (size_t)d * sizeof(float);
+    const bool det = workspace != nullptr;
+    float *partial = (float *)workspace;
+    const size_t shm = (det ? (size_t)(256 / g) : 1) * 2 * (size_t)d * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int npass = (d + g * 8 - 1) / (g * 8);      // 1, or 2 when d > 512
-#define LN_BWD_LAUNCH(TT, GG, NPP) add_ln_bwd_kernel<TT, GG, NPP><<<grid, 256, shm, st>>>((const TT *)dout, (const TT *)z, stats, gamma, (TT *)dz, (TT *)dy, dgamma, dbeta, rows, d, dropout_rate, seed)
+#define LN_BWD_LAUNCH(TT, GG, NPP) do { if (det) add_ln_bwd_kernel<TT, GG, NPP, true><<<grid, 256, shm, st>>>((const TT *)dout, (const TT *)z, stats, gamma, (TT *)dz, (TT *)dy, dgamma, dbeta, rows, d, dropout_rate, seed, partial); \
+        else add_ln_bwd_kernel<TT, GG, NPP, false><<<grid, 256, shm, st>>>((const TT *)dout, (const TT *)z, stats, gamma, (TT *)dz, (TT *)dy, dgamma, dbeta, rows, d, dropout_rate, seed, partial); } while (0)
 #define LN_BWD_DISPATCH(TT)                                                                              \
     switch (g) {                                                                                         \
         case 1: LN_BWD_LAUNCH(TT, 1, 1); break;                                                          \
@@ -584,6 +714,7 @@ extern "C" int b4c_add_dropout_layernorm_bwd(const void *dout, const void *z, co
         LN_BWD_DISPATCH(bf16_t)
     } else
         B4C_REQUIRE(false, "add_ln_bwd: dtype %d", dtype);
+    if (det) ln_bwd_reduce_kernel<<<(2 * d + 255) / 256, 256, 0, st>>>(partial, grid, d, dgamma, dbeta);
     return b4c_check_launch("add_ln_bwd");
 }
 

@@ -271,19 +271,34 @@ def _sort_order(ids, n_rows):
 
 sorted_embed_bwd = True     # sort the tokens of every feature by id (one radix sort per call) and sum runs in registers
 
+# ops.deterministic (B4C_DETERMINISTIC=1): ONE switch for a bit-reproducible training step -- every reduction that otherwise
+# finishes through float atomics (whose arrival order, and with it the last bit of the sum, changes from run to run) takes a
+# fixed-order form instead:
+#   the vocabulary projection's dW / db      one workgroup per vocabulary tile walks every token; label term through a stable sort
+#   the embedding tables' gradient rows      runs of one id that cross the kernel's 64-entry ranges are summed in range order
+#                                            (b4c_embed_concat_pe_bwd_sorted_ws); the unsorted atomic kernel is never taken
+#   LayerNorm dgamma / dbeta                 per-workgroup sums in a fixed order, added block by block (b4c_add_dropout_layernorm_bwd_ws)
+# (the dense weight gradients already are: ops.tn_deterministic).  Not covered: the sampled-softmax head's row scatter (config 5).
+# Two identical runs of bench.py's step then give torch.equal arenas (tests/test_gpu_deterministic.py); cost: DESIGN.md.
+deterministic = os.environ.get('B4C_DETERMINISTIC', '0') == '1'
+
 
 def embed_concat_pe_bwd(ids_list, tables, dout, scale, rate, seed, into=None, order=None):
     B, S = ids_list[0].shape
     d = dout.shape[-1]
     dtabs = into if into is not None else [torch.zeros_like(t) for t in tables]
     n, ids_arr, tab_arr, dims, rows = _feature_arrays(ids_list, dtabs)
-    if sorted_embed_bwd and B * S >= 4096:
+    if (sorted_embed_bwd and B * S >= 4096) or deterministic:
         if order is None:
             order = [_sort_order(i, int(t.shape[0])) for i, t in zip(ids_list, tables)]
         ord_arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in order])
+        ws = None
+        if deterministic:
+            ws = _workspace('embed_bwd', dout.device, L.lib().b4c_embed_concat_pe_bwd_sorted_workspace_bytes(n, dims, B, S))
         with _record('embed_bwd', B * S * d * (4 + dout.element_size())):
-            L.check(L.lib().b4c_embed_concat_pe_bwd_sorted(n, ids_arr, ord_arr, tab_arr, dims, rows, scale, _p(dout), d, B, S, d,
-                                                           rate, seed, dt_code(dout.dtype), _st()), 'embed_concat_pe_bwd_sorted')
+            L.check(L.lib().b4c_embed_concat_pe_bwd_sorted_ws(n, ids_arr, ord_arr, tab_arr, dims, rows, scale, _p(dout), d, B, S, d,
+                                                              rate, seed, _p(ws), ws.numel() if ws is not None else 0,
+                                                              dt_code(dout.dtype), _st()), 'embed_concat_pe_bwd_sorted')
         return dtabs
     with _record('embed_bwd', B * S * d * (4 + dout.element_size())):
         L.check(L.lib().b4c_embed_concat_pe_bwd(n, ids_arr, tab_arr, dims, rows, scale, _p(dout), d, B, S, d, rate, seed,
@@ -658,10 +673,12 @@ def add_dropout_layernorm_bwd(dout, z, stats, gamma, rate, seed, into=None):
         dbeta = torch.zeros(d, dtype=torch.float32, device=z.device)
     if rows == 0:          # no row at all (a batch without a [MASK]): nothing to add to dgamma / dbeta
         return dz, (dy if dy is not None else dz), dgamma, dbeta
+    ws = _workspace('ln_bwd', z.device, L.lib().b4c_add_dropout_layernorm_bwd_workspace_bytes(rows, d)) if deterministic else None
     with _record('add_ln_bwd' if 2 * rows >= rec_hints.get('token_rows', 0) else 'add_ln_bwd_rows',
                  rows * d * z.element_size() * (4 if rate > 0 else 3)):
-        L.check(L.lib().b4c_add_dropout_layernorm_bwd(_p(dout), _p(z), _p(stats), _p(gamma), _p(dz), _p(dy), _p(dgamma),
-                                                      _p(dbeta), rows, d, rate, seed, dt_code(z.dtype), _st()),
+        L.check(L.lib().b4c_add_dropout_layernorm_bwd_ws(_p(dout), _p(z), _p(stats), _p(gamma), _p(dz), _p(dy), _p(dgamma),
+                                                         _p(dbeta), rows, d, rate, seed, _p(ws), ws.numel() if ws is not None else 0,
+                                                         dt_code(z.dtype), _st()),
                 'add_dropout_layernorm_bwd')
     return dz, (dy if dy is not None else dz), dgamma, dbeta
 
@@ -815,7 +832,7 @@ def vocab_ce_dw(h, wt, bias, labels_i32, rowscal, V, dW, db):
     ws = _vce_workspace(h, R, V, K)
     with _record('vocab_ce_dw', R * K * 2 + V * K * 2 + V * K * 4, 4 * R * V * K):
         L.check(L.lib().b4c_vocab_ce_dw(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(labels_i32), _p(rowscal),
-                                        _p(dW), dW.stride(0), _p(db), ws.data_ptr(), ws.numel(), R, V, K, int(deterministic_vocab_dw), _st()),
+                                        _p(dW), dW.stride(0), _p(db), ws.data_ptr(), ws.numel(), R, V, K, int(deterministic_vocab_dw or deterministic), _st()),
                 'vocab_ce_dw')
 
 
@@ -829,7 +846,7 @@ def vocab_ce_dw_sweep(h, wt, bias, rowscal, V, dW, db, tile_begin, tile_end, bac
     with _record('vocab_ce_dw_bg' if background_workgroups > 0 else 'vocab_ce_dw',
                  int(frac * (R * K * 2 + V * K * 2 + V * K * 4)), int(frac * 4 * R * V * K)):
         L.check(L.lib().b4c_vocab_ce_dw_sweep(_p(h), h.stride(0), _p(wt), wt.stride(0), _p(bias), _p(rowscal), _p(dW), dW.stride(0),
-                                              _p(db), R, V, K, tile_begin, tile_end, background_workgroups, int(deterministic_vocab_dw), _st()),
+                                              _p(db), R, V, K, tile_begin, tile_end, background_workgroups, int(deterministic_vocab_dw or deterministic), _st()),
                 'vocab_ce_dw_sweep')
 
 
@@ -840,7 +857,7 @@ def vocab_ce_dw_labels(h, labels_i32, rowscal, V, dW, db):
         return
     ws = _vce_workspace(h, R, V, K)
     L.check(L.lib().b4c_vocab_ce_dw_labels(_p(h), h.stride(0), _p(labels_i32), _p(rowscal), _p(dW), dW.stride(0), _p(db),
-                                           ws.data_ptr(), ws.numel(), R, V, K, int(deterministic_vocab_dw), _st()), 'vocab_ce_dw_labels')
+                                           ws.data_ptr(), ws.numel(), R, V, K, int(deterministic_vocab_dw or deterministic), _st()), 'vocab_ce_dw_labels')
 
 
 fused_softmax_proj = True      # Dense(V, softmax) of the bf16 path in one pass over (R x V): lse sweep + softmax epilogue

@@ -78,6 +78,14 @@ int b4c_embed_concat_pe_bwd_sorted(int n_feat, const int64_t *const *h_ids, cons
                                    float *const *h_dtables, const int *h_dims, const int64_t *h_rows, float scale,
                                    const void *dout, int ld_dout, int B, int S, int d_model, float dropout_rate,
                                    uint64_t seed, int dtype, void *stream);
+/* (ABI 9) the same with a caller scratch: workspace != NULL selects the DETERMINISTIC form -- runs that cross the 64-entry ranges
+ * of the kernel's waves are summed in range order through the scratch instead of meeting through float atomics, so two launches
+ * on the same inputs give the same bits.  workspace == NULL: the form above. */
+int64_t b4c_embed_concat_pe_bwd_sorted_workspace_bytes(int n_feat, const int *h_dims, int B, int S);
+int b4c_embed_concat_pe_bwd_sorted_ws(int n_feat, const int64_t *const *h_ids, const int32_t *const *h_order,
+                                      float *const *h_dtables, const int *h_dims, const int64_t *h_rows, float scale,
+                                      const void *dout, int ld_dout, int B, int S, int d_model, float dropout_rate,
+                                      uint64_t seed, void *workspace, int64_t workspace_bytes, int dtype, void *stream);
 
 /* ---- dense layers (R8 projections, R9 FFN, R12 head) --------------------------------
  * replaces tf.keras.layers.Dense call sites transformer.py:112-116,165-166; head.py:35-36.
@@ -192,6 +200,13 @@ int b4c_add_dropout_layernorm_fwd(const void *x, const void *y, const float *gam
 int b4c_add_dropout_layernorm_bwd(const void *dout, const void *z, const float *stats, const float *gamma,
                                   void *dz, void *dy, float *dgamma, float *dbeta, int64_t rows, int d,
                                   float dropout_rate, uint64_t seed, int dtype, void *stream);
+/* (ABI 9) the same with a caller scratch (b4c_add_dropout_layernorm_bwd_workspace_bytes): workspace != NULL selects the
+ * DETERMINISTIC form of dgamma / dbeta -- per-workgroup sums in a fixed order, added block by block -- instead of float atomics. */
+int64_t b4c_add_dropout_layernorm_bwd_workspace_bytes(int64_t rows, int d);
+int b4c_add_dropout_layernorm_bwd_ws(const void *dout, const void *z, const float *stats, const float *gamma,
+                                     void *dz, void *dy, float *dgamma, float *dbeta, int64_t rows, int d,
+                                     float dropout_rate, uint64_t seed, void *workspace, int64_t workspace_bytes, int dtype,
+                                     void *stream);
 
 /* ---- R11: [MASK]-position index generation and row gather -----------------------------
  * replaces _gather_output_by_raw_value (clickstream_transformer.py:260-297):
