@@ -469,8 +469,20 @@ def main():
             mine = {'vocab': a.vocab, 'batch': a.batch, 'seq': a.seq, 'd_model': a.d_model, 'layers': a.layers, 'dtype': a.dtype}
             if not (a.traffic_json or all(cfg.get(k) == v for k, v in mine.items())):     # counters are valid for that config only
                 traffic = None
+        def measured(fam):
+            """PMC bytes of a family -- attached only when they can be a measurement of the SAME launches: HBM bytes below the
+            launches' algorithmic bytes (less 5 % for counter granularity) mean the file was made from other launches."""
+            t = traffic.get(fam) if traffic else None
+            v = fams.get(fam) if fams else None
+            if not t or not v or not v['launches']:
+                return None
+            alg = v['bytes'] / v['launches']
+            if t.get('hbm_bytes_per_launch', 0.0) < 0.95 * alg and not t.get('on_chip_reuse'):
+                return {'refused': 'PMC bytes per launch %.3g below the algorithmic %.3g: not a measurement of these launches'
+                                   % (t.get('hbm_bytes_per_launch', 0.0), alg)}
+            return t
         if roof and traffic:
-            roof['traffic'] = traffic.get(roof['family'])
+            roof['traffic'] = measured(roof['family'])
             if 'beside' in roof:        # the background sweep's measured HBM bytes beside its algorithmic bytes
                 for f, row in roof['beside']['families'].items():
                     row['traffic'] = traffic.get(f)
@@ -527,7 +539,7 @@ def main():
                 r2.pop('families', None)
                 r2.pop('beside', None)
                 if traffic:
-                    r2['traffic'] = traffic.get(r2['family'])
+                    r2['traffic'] = measured(r2['family'])
                 out['roofline_largest_hbm_family'] = r2
         if world == 1 and a.eval_steps > 0:
             out['eval'] = eval_leg(model, batches, a, peak_tf)
@@ -559,6 +571,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and a.action_dim == 0:
             out['cpu_baseline'] = cpu_baseline(a)
         print(json.dumps(out))
+        ops.dump_family_log()          # (B4C_FAMILY_LOG: the launch -> family notes scratch/pmc_traffic.py pairs PMC dispatches with)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -356,6 +356,15 @@ __global__ void __launch_bounds__(256) embed_bwd_runs_kernel(EmbedArgs a, EmbedO
     const int64_t id = id_at(pb + 63);
     if (id_at(pb + 64) != id) return;                       // nothing crosses this boundary
     if (id_at(pb) == id && b > 0 && id_at(pb - 1) == id) return;      // the run came in from before range b: not its first range
+    // the last range the run reaches into: the entries are sorted by id, so "first entry of range w is this id" is monotone in w
+    // -- a binary search instead of a walk (the hottest id of a Zipf batch fills hundreds of ranges, and every step of a walk
+    // is two dependent loads)
+    int64_t lo = b + 1, hi = nw - 1;                        // range b + 1 starts with this id; find the largest w that does
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (id_at(mid << 6) == id) lo = mid; else hi = mid - 1;
+    }
+    const int64_t e = lo;
     const float *part = ord.part[f];
     float *table = a.table[f];
     for (int cb = 0; cb < fd; cb += 128) {
@@ -363,12 +372,10 @@ __global__ void __launch_bounds__(256) embed_bwd_runs_kernel(EmbedArgs a, EmbedO
         if (col >= fd) continue;
         const float *t = part + (b * 2 + 1) * (int64_t)fd + col;
         float s0 = t[0], s1 = t[1];
-        for (int64_t w = b + 1; w < nw; ++w) {
+        for (int64_t w = b + 1; w <= e; ++w) {               // (independent loads: the order of the adds is what is fixed)
             const float *h = part + (w * 2) * (int64_t)fd + col;
             s0 += h[0];
             s1 += h[1];
-            const int64_t pw = w << 6, last = (pw + 64 <= T_tok ? pw + 63 : T_tok - 1);
-            if (!(id_at(last) == id && last + 1 < T_tok && id_at(last + 1) == id)) break;      // (wave-uniform)
         }
         float *row = table + id * fd + col;
         row[0] += s0;
@@ -624,14 +631,16 @@ __global__ void __launch_bounds__(256, 4) add_ln_bwd_kernel(const T *__restrict_
     }
 }
 
-// dgamma[i] += sum over blocks (in block order) of partial[block][0][i]; dbeta likewise
+// dgamma[i] += sum over blocks of partial[block][0][i]; dbeta likewise.  One wave per column, in a FIXED order: lane l adds the
+// blocks l, l + 64, l + 128, ... one after the other, then the 64 lane sums meet in wave_sum's fixed butterfly.
 __global__ void __launch_bounds__(256) ln_bwd_reduce_kernel(const float *__restrict__ partial, int nblocks, int d, float *__restrict__ dgamma,
                                                             float *__restrict__ dbeta) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= 2 * d) return;
     float sum = 0.f;
-    for (int b = 0; b < nblocks; ++b) sum += partial[(int64_t)b * 2 * d + i];
-    if (i < d) dgamma[i] += sum; else dbeta[i - d] += sum;
+    for (int b = lane; b < nblocks; b += 64) sum += partial[(int64_t)b * 2 * d + i];
+    sum = wave_sum(sum);
+    if (lane == 0) { if (i < d) dgamma[i] += sum; else dbeta[i - d] += sum; }
 }
 
 static int ln_group(int d) {
@@ -714,7 +723,7 @@ extern "C" int b4c_add_dropout_layernorm_bwd_ws(const void *dout, const void *z,
         LN_BWD_DISPATCH(bf16_t)
     } else
         B4C_REQUIRE(false, "add_ln_bwd: dtype %d", dtype);
-    if (det) ln_bwd_reduce_kernel<<<(2 * d + 255) / 256, 256, 0, st>>>(partial, grid, d, dgamma, dbeta);
+    if (det) ln_bwd_reduce_kernel<<<(2 * d + 3) / 4, 256, 0, st>>>(partial, grid, d, dgamma, dbeta);
     return b4c_check_launch("add_ln_bwd");
 }
 

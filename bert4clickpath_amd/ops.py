@@ -67,10 +67,26 @@ def stop_recording(rec=None):
     return out
 
 
+# B4C_FAMILY_LOG=<path> (scratch/pmc_traffic.py): EVERY launch that goes through a recorder site is noted, in host order, with
+# the family the recorder books it under and its algorithmic bytes -- whether the recorder is on or not.  The PMC script pairs the
+# i-th dispatch of a kernel with the i-th note of that kernel's families, so "which launch belongs to which family" has one
+# source: this file's `_record(...)` call sites (token-sized and row-sized launches of one kernel are told apart here only).
+family_log = [] if os.environ.get('B4C_FAMILY_LOG') else None
+
+
+def dump_family_log():
+    if family_log is not None:
+        import json
+        with open(os.environ['B4C_FAMILY_LOG'], 'w') as f:
+            json.dump(family_log, f)
+
+
 class _record:
     def __init__(self, family, nbytes, flops=0):
         self.on = _rec is not None
         self.family, self.nbytes, self.flops = family, nbytes, flops
+        if family_log is not None:
+            family_log.append((family, int(nbytes)))
 
     def __enter__(self):
         if self.on:
@@ -393,7 +409,7 @@ def gemm_tn(a, g, K, N, want_bias=True, into=None):
     into = (list of dW_i [K, N/len], list of db_i [N/len]): accumulate into existing fp32 tensors (column
     segments of equal width) instead of allocating zeros; returns (None, None) then."""
     M = a.shape[0]
-    if M > 0 and _rec is not None:
+    if M > 0 and (_rec is not None or family_log is not None):
         with _record('gemm_tn' if 2 * M >= rec_hints.get('token_rows', 0) else 'gemm_tn_rows',
                      M * (K + N) * a.element_size() + K * N * 4, 2 * M * K * N):
             return _gemm_tn_impl(a, g, K, N, want_bias, into)

@@ -1,43 +1,130 @@
-"""Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/traffic.json:
-HBM bytes per launch for each launch family, corrected as MI355X_MICROARCH.md prescribes for gfx950
-(FETCH_SIZE counts 64 B per 128-B request of a wide streaming read -> x2; WRITE_SIZE is exact; both in KiB)."""
-import csv, glob, json, sys, collections
-# (family, kernels whose traffic counts, the kernel that marks ONE launch of the family)
-FAM = [('attn_mq_fwd', ('attn_mq_fwd',), None), ('attn_mq_bwd', ('attn_mq_bwd',), None), ('gemm_nt_ln', ('gemm_nt_ln_kernel', 'gemm_nt_ln256_kernel'), None), ('vocab_proj', ('gemm_nt_wide',), None), ('gemm_nt', ('gemm_nt_kernel',), None),
-       ('softmax_rows', ('softmax_rows',), None), ('topk_rows', ('topk_rows',), None), ('gemm_tn', ('gemm_tn_', 'tn_reduce_kernel'), 'gemm_tn_'),
-       ('attn_bwd', ('attn_bwd',), None), ('attn_fwd', ('attn_fwd',), None), ('softmax_ce', ('softmax_ce',), None),
-       ('add_ln_fwd', ('add_ln_fwd',), None), ('add_ln_bwd', ('add_ln_bwd',), None), ('embed_bwd', ('embed_bwd',), None),
-       ('embed_fwd', ('embed_fwd',), None), ('adam', ('adam_kernel',), None),
-       ('vocab_rank', ('vce_scan_kernel<128, 0,', 'vce_scan_kernel<64, 0,', 'vce_label_logit'), 'vce_label_logit'),
-       ('vocab_topk', ('vce_scan_kernel', 'vce_tau_kernel', 'vce_select_kernel'), 'vce_select_kernel'),
-       ('vocab_lse', ('vce_token_kernel<128, 0,', 'vce_token_kernel<64, 0,', 'vce_token_kernelILi128ELi0E', 'vce_lse_kernel'), 'vce_lse_kernel'),
-       ('vocab_ce_fwd', ('vce_token_kernel', 'vce_combine_kernel'), 'vce_combine_kernel'),
-       # (the background form goes out in pieces: the label kernel marks one launch of the family per step)
-       ('vocab_ce_dw_bg', ('vce_dw_kernel<128, 1>', 'vce_dw_kernel<64, 1>', 'vce_label'), 'vce_label_kernel'),
-       ('vocab_ce_dw', ('vce_dw_kernel',), 'vce_dw_kernel')]
-def fam_of(name):
-    for f, pats, prim in FAM:
-        if any(p in name for p in pats): return f, (prim is None or prim in name)
+"""Two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py -> profiles/traffic*.json: HBM bytes per launch of every
+launch FAMILY of bert4clickpath_amd.ops' recorder, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts
+64 B per 128-B request of a wide streaming read -> x 2; WRITE_SIZE is exact; both in KiB).
+
+Which launch belongs to which family has ONE source: the recorder's own call sites.  bench.py, run with B4C_FAMILY_LOG=<path>,
+notes (family, algorithmic bytes) for every launch that passes a recorder site, in host order; here the i-th dispatch of a kernel
+GROUP (the kernels one site can launch) is paired with the i-th note of that group's families.  Token-sized and row-sized
+launches of one kernel (gemm_nt / gemm_nt_rows, ...) are told apart that way and no other.
+
+usage: pmc_traffic.py <fetch pass dir> <write pass dir> <family_log.json> <out.json> ['{"vocab": ..., ...}']"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+# group: (families a recorder site books these kernels under, kernel-name patterns, pattern of the kernel that marks ONE launch)
+GROUPS = [
+    (('gemm_nt', 'gemm_nt_rows', 'vocab_proj'), ('gemm_nt_kernel', 'gemm_nt_wide'), None),
+    (('gemm_nt_ln', 'gemm_nt_ln_rows'), ('gemm_nt_ln_kernel', 'gemm_nt_ln256_kernel'), None),
+    (('gemm_tn', 'gemm_tn_rows'), ('gemm_tn_', 'tn_reduce_kernel'), 'gemm_tn_'),
+    (('add_ln_bwd', 'add_ln_bwd_rows'), ('add_ln_bwd_kernel', 'ln_bwd_reduce_kernel'), 'add_ln_bwd_kernel'),
+    (('add_ln_fwd',), ('add_ln_fwd',), None),
+    (('attn_mq_fwd',), ('attn_mq_fwd',), None), (('attn_mq_bwd',), ('attn_mq_bwd',), None),
+    (('attn_bwd',), ('attn_bwd',), None), (('attn_fwd',), ('attn_fwd',), None),
+    (('softmax_rows',), ('softmax_rows',), None), (('topk_rows',), ('topk_rows',), 'topk_rows_bf16_reg|topk_rows_kernel'),
+    (('softmax_ce',), ('softmax_ce',), None),
+    (('embed_bwd',), ('embed_bwd',), 'embed_bwd_sorted_kernel|embed_bwd_kernel'), (('embed_fwd',), ('embed_fwd',), None),
+    (('adam', 'adam_catch_up'), ('adam_kernel', 'adam_rows_kernel'), None),
+    (('vocab_rank',), ('vce_scan_kernel<128, 0,', 'vce_scan_kernel<64, 0,', 'vce_label_logit'), 'vce_label_logit'),
+    (('vocab_topk',), ('vce_scan_kernel', 'vce_tau_kernel', 'vce_select_kernel'), 'vce_select_kernel'),
+    (('vocab_lse',), ('vce_token_kernel<128, 0,', 'vce_token_kernel<64, 0,', 'vce_lse_kernel'), 'vce_lse_kernel'),
+    (('vocab_ce_fwd',), ('vce_token_kernel', 'vce_combine_kernel', 'vce_exact_kernel', 'vce_rowstat_kernel'), 'vce_combine_kernel'),
+    # (the background form goes out in pieces: every piece is a note; the label kernels ride on the last piece)
+    (('vocab_ce_dw_bg', 'vocab_ce_dw'), ('vce_dw_kernel', 'vce_label'), 'vce_dw_kernel'),
+]
+
+
+def group_of(name):
+    for gi, (fams, pats, prim) in enumerate(GROUPS):
+        if any(p in name for p in pats):
+            primary = prim is None or any(q in name for q in prim.split('|'))
+            return gi, primary
     return None, False
+
+
 def load(d, counter):
+    """-> {dispatch id: (kernel name, counter value)} of one pass"""
     f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True))[-1]
-    agg = collections.defaultdict(lambda: [0.0, set()])
+    out = {}
     for x in csv.DictReader(open(f)):
-        if x['Counter_Name'] != counter: continue
-        fam, primary = fam_of(x['Kernel_Name'])
-        if fam is None: continue
-        agg[fam][0] += float(x['Counter_Value'])
-        if primary: agg[fam][1].add(x['Dispatch_Id'])
-    return {k: (v[0], len(v[1])) for k, v in agg.items()}
-fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
-out = {}
-for fam in fetch:
-    fs, n = fetch[fam]; ws, n2 = write.get(fam, (0.0, n))
-    out[fam] = {'hbm_bytes_per_launch': (2.0 * fs / n + ws / max(n2, 1)) * 1024.0, 'fetch_bytes_per_launch_x2': 2.0 * fs / n * 1024.0,
-                'write_bytes_per_launch': ws / max(n2, 1) * 1024.0, 'launches_sampled': n,
-                'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md gfx950 note, KiB -> bytes'}
-if len(sys.argv) > 4: out['_config'] = json.loads(sys.argv[4])
-json.dump(out, open(sys.argv[3], 'w'), indent=1)
-for k, v in out.items():
-    if k.startswith('_'): continue
-    print('%-12s %8.1f MB/launch (fetch x2 %8.1f, write %8.1f) n=%d' % (k, v['hbm_bytes_per_launch']/1e6, v['fetch_bytes_per_launch_x2']/1e6, v['write_bytes_per_launch']/1e6, v['launches_sampled']))
+        if x['Counter_Name'] == counter:
+            out[int(x['Dispatch_Id'])] = (x['Kernel_Name'], float(x['Counter_Value']))
+    return out
+
+
+def per_family(disp, log):
+    """pair dispatches with the recorder's notes, group by group -> {family: [sum of counter values, launches]}"""
+    notes = collections.defaultdict(list)           # group -> families in note order
+    fam_group = {}
+    for gi, (fams, _, _) in enumerate(GROUPS):
+        for f in fams:
+            fam_group[f] = gi
+    for fam, _ in log:
+        if fam in fam_group:
+            notes[fam_group[fam]].append(fam)
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    cursor = collections.defaultdict(int)
+    current = {}
+    mismatch = {}
+    for did in sorted(disp):
+        name, val = disp[did]
+        gi, primary = group_of(name)
+        if gi is None:
+            continue
+        if primary:
+            k = cursor[gi]
+            cursor[gi] += 1
+            if k >= len(notes[gi]):
+                mismatch[gi] = mismatch.get(gi, 0) + 1
+                current[gi] = None
+                continue
+            current[gi] = notes[gi][k]
+            agg[current[gi]][1] += 1
+        fam = current.get(gi)
+        if fam is not None:
+            agg[fam][0] += val
+    for gi in notes:
+        if cursor[gi] != len(notes[gi]):
+            mismatch[gi] = cursor[gi] - len(notes[gi])
+    return agg, {GROUPS[g][0][0]: n for g, n in mismatch.items()}
+
+
+def main():
+    fetch_dir, write_dir, log_path, out_path = sys.argv[1:5]
+    log = json.load(open(log_path))
+    alg = collections.defaultdict(lambda: [0.0, 0])
+    for fam, nbytes in log:
+        alg[fam][0] += nbytes
+        alg[fam][1] += 1
+    fetch, bad_f = per_family(load(fetch_dir, 'FETCH_SIZE'), log)
+    write, bad_w = per_family(load(write_dir, 'WRITE_SIZE'), log)
+    if bad_f or bad_w:
+        print('WARNING: dispatches and recorder notes do not pair up (dispatches - notes):', bad_f, bad_w)
+    out = {}
+    for fam in sorted(fetch):
+        fs, n = fetch[fam]
+        ws, n2 = write.get(fam, (0.0, n))
+        if n == 0:
+            continue
+        e = {'hbm_bytes_per_launch': (2.0 * fs / n + ws / max(n2, 1)) * 1024.0, 'fetch_bytes_per_launch_x2': 2.0 * fs / n * 1024.0,
+             'write_bytes_per_launch': ws / max(n2, 1) * 1024.0, 'launches_sampled': n,
+             'algorithmic_bytes_per_launch': alg[fam][0] / max(alg[fam][1], 1),
+             'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md gfx950 note, '
+                       'KiB -> bytes; launches paired with the recorder\'s own family notes (B4C_FAMILY_LOG)'}
+        e['ratio_to_algorithmic'] = e['hbm_bytes_per_launch'] / max(e['algorithmic_bytes_per_launch'], 1.0)
+        out[fam] = e
+    if len(sys.argv) > 5:
+        out['_config'] = json.loads(sys.argv[5])
+    json.dump(out, open(out_path, 'w'), indent=1)
+    for k, v in out.items():
+        if k.startswith('_'):
+            continue
+        print('%-16s %8.1f MB/launch (fetch x2 %8.1f, write %8.1f; algorithmic %8.1f: x %.2f) n=%d'
+              % (k, v['hbm_bytes_per_launch'] / 1e6, v['fetch_bytes_per_launch_x2'] / 1e6, v['write_bytes_per_launch'] / 1e6,
+                 v['algorithmic_bytes_per_launch'] / 1e6, v['ratio_to_algorithmic'], v['launches_sampled']))
+
+
+if __name__ == '__main__':
+    main()
