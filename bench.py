@@ -153,6 +153,8 @@ def make_batches(a, rank, device):
                     # specials included) and sum of (masked positions x len)
                     'sum_len_sq': int(((b['lens'] + 3).astype(np.int64) ** 2).sum()),
                     'sum_q_len': int((np.minimum((2 * b['lens']) // 5, 10).astype(np.int64) * (b['lens'] + 3)).sum()),
+                    # distinct table rows the batch reads (the row-lazy Adam's algorithmic bytes: rows, not id occurrences)
+                    'distinct_ids': int(np.unique(b['ids']).size),
                     'R': int(b['labels'].shape[0])})
     return out
 
@@ -335,7 +337,7 @@ class Training:
         model, reducer = self.model, self.reducer
         # host-side facts the launch recorder's algorithmic counts use (nothing on the device depends on them)
         self.ops.set_record_hints(token_rows=a.batch * a.seq if a.dense else b['n_real'], sum_len_sq=b['sum_len_sq'],
-                                  sum_q_len=b['sum_q_len'])
+                                  sum_q_len=b['sum_q_len'], adam_distinct_rows=b['distinct_ids'])
         self.opt.zero_grad()
         reducer.begin_backward()
         if a.host_flat_idx:
@@ -460,7 +462,7 @@ def main():
         fams = ops.stop_recording(fams) if fams is not None else None
         peak_tf = MFMA_BF16_PEAK_TF if a.dtype == 'bf16' else 157.3
         roof = roofline_from(fams, max(nrec, 1), peak_tf) if fams else None
-        tj = a.traffic_json or os.path.join(ROOT, 'profiles', 'traffic.json')
+        tj = a.traffic_json or os.path.join(ROOT, 'profiles', 'traffic.json' if a.config == 'c2' else 'traffic_%s.json' % a.config)
         traffic = None
         if roof and os.path.exists(tj):      # rocprofv3 PMC passes (separate runs), HBM bytes per launch of each family
             with open(tj) as f:
