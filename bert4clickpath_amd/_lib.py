@@ -74,6 +74,8 @@ def lib():
             'b4c_pack_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, vp]),
             'b4c_gemm_nt': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
             'b4c_gemm_nt_add_ln': (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, i32, vp]),
+            'b4c_gemm_dxdw_workspace_bytes': (i64, [i64, i32]),
+            'b4c_gemm_dxdw': (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, pp, pp, i32, i64, vp, i64, vp]),
             'b4c_gemm_tn_group_workspace_bytes': (i64, [vp, i32, i32]),
             'b4c_gemm_tn_group': (i32, [vp, i32, i32, i32, vp, i64, vp]),
             'b4c_gemm_tn_workspace_bytes': (i64, [i32, i32, i32, i32]),

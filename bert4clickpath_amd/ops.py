@@ -455,6 +455,32 @@ def _gemm_tn_impl(a, g, K, N, want_bias, into):
     return dW, db
 
 
+# ---- the whole backward of a Dense layer in one pass over its gradient (csrc/gemm_dxdw.hip) -----------------------------------
+fused_dxdw = os.environ.get('B4C_FUSED_DXDW', '0') == '1'
+
+
+def dxdw_supported(x, g, n_seg):
+    """bf16, 128-wide layer input, gradient of 128 x n_seg columns (n_seg 1 or 3), rows the kernels' 16-B accesses can take"""
+    return x.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and x.shape[1] == 128 and n_seg in (1, 3) and \
+        g.shape[1] == 128 * n_seg and x.stride(0) % 8 == 0 and g.stride(0) % 8 == 0 and x.shape[0] >= 4096
+
+
+def gemm_dxdw(x, g, wc, dWs, dbs, residual=None):
+    """dX = g wc^T (+ residual), dW_s += x^T g_s, db_s += colsum(g_s) with g read once (b4c_gemm_dxdw).
+    x [M, 128], g [M, 128 n_seg], wc [128, >= 128 n_seg] (the dX operand of gemm_nt), dWs / dbs: fp32 gradient tensors."""
+    M, n_seg = x.shape[0], len(dWs)
+    dx = torch.empty(M, 128, dtype=x.dtype, device=x.device)
+    ws = _workspace('gemm_dxdw', x.device, L.lib().b4c_gemm_dxdw_workspace_bytes(M, n_seg))
+    wa = (ctypes.c_void_p * n_seg)(*[t.data_ptr() for t in dWs])
+    ba = (ctypes.c_void_p * n_seg)(*[(t.data_ptr() if t is not None else None) for t in dbs])
+    es = 2
+    with _record('gemm_dxdw', M * (128 * (1 + n_seg) + 128 + (128 if residual is not None else 0)) * es, 4 * M * 128 * 128 * n_seg):
+        L.check(L.lib().b4c_gemm_dxdw(_p(x), x.stride(0), _p(g), g.stride(0), _p(wc), wc.stride(0), _p(residual),
+                                      residual.stride(0) if residual is not None else 0, _p(dx), dx.stride(0), n_seg, wa, ba,
+                                      dWs[0].stride(0), M, ws.data_ptr(), ws.numel(), _st()), 'gemm_dxdw')
+    return dx
+
+
 # ---- grouped weight gradients: the dW GEMMs of an encoder layer are off the critical path (nothing in backward
 # consumes them), so in arena mode they are queued and launched together (b4c_gemm_tn_group: one main + one reduce
 # kernel per layer instead of four of each, and ~6x less partial-tile traffic).
@@ -1282,11 +1308,16 @@ class AttnBlockFn(torch.autograd.Function):
         d_o = gemm_nt(dy, wc_o, d)
         with _timed('attn_bwd'):
             dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, ctx.cu, actx)
-        if inplace:
-            queue_dw(actx, x, dqkv, d, 3 * d, [wq.grad, wk.grad, wv.grad], [bq.grad, bk.grad, bv.grad], (wq, bq, wk, bk, wv, bv))
+        if inplace and fused_dxdw and dxdw_supported(x, dqkv, 3):
+            # dX and dW | db of the fused Q | K | V projection in one pass over dqkv (csrc/gemm_dxdw.hip)
+            dx = gemm_dxdw(x, dqkv, wc_qkv, [wq.grad, wk.grad, wv.grad], [bq.grad, bk.grad, bv.grad], residual=dz)
+            _ready(wq, bq, wk, bk, wv, bv)
         else:
-            dWqkv, dbqkv = gemm_tn(x, dqkv, d, 3 * d)
-        dx = gemm_nt(dqkv, wc_qkv, d, residual=dz)
+            if inplace:
+                queue_dw(actx, x, dqkv, d, 3 * d, [wq.grad, wk.grad, wv.grad], [bq.grad, bk.grad, bv.grad], (wq, bq, wk, bk, wv, bv))
+            else:
+                dWqkv, dbqkv = gemm_tn(x, dqkv, d, 3 * d)
+            dx = gemm_nt(dqkv, wc_qkv, d, residual=dz)
         if inplace:
             _ready(gam, bet)
             flush_pending_dw(actx)      # this layer's four weight gradients (two queued by FFNBlockFn.backward) in one launch

@@ -150,6 +150,18 @@ int b4c_gemm_tn_seg(const void *A, int lda, const void *G, int ldg, int n_seg, f
                     float *const *h_db, int seg_width, int M, int K, int dtype, void *workspace,
                     int64_t workspace_bytes, void *stream);
 
+/* (ABI 9) the whole backward of one Dense layer of the encoder in ONE pass over its output gradient (transformer.py:112-116,
+ * 158, 163-167 seen from the backward pass):   dX = G Wc^T (+ residual)   dW_s += X^T G_s   db_s += colsum(G_s)
+ * X [M][128] the layer's input, G [M][128 n_seg] (n_seg = 3: q | k | v column blocks, 1: a plain layer), Wc [128][128 n_seg]
+ * (row = input feature, the dX operand of b4c_gemm_nt), residual [M][128] or NULL, dX [M][128]; dW_s fp32 [128][ld_dw] Keras
+ * layout, db_s fp32 [128] or NULL (h_dW / h_db: HOST arrays of n_seg device pointers).  bf16, 128-wide layers only; G is read from
+ * HBM once (as b4c_gemm_nt + b4c_gemm_tn it is read twice).  Deterministic: per-workgroup partial sums meet in workgroup order
+ * through the caller's scratch. */
+int64_t b4c_gemm_dxdw_workspace_bytes(int64_t M, int n_seg);
+int b4c_gemm_dxdw(const void *X, int ldx, const void *G, int ldg, const void *Wc, int ldw, const void *residual, int ldr,
+                  void *dX, int ldo, int n_seg, float *const *h_dW, float *const *h_db, int ld_dw, int64_t M,
+                  void *workspace, int64_t workspace_bytes, void *stream);
+
 /* several dW problems over the SAME M tokens in one launch (bf16; the four weight gradients of an encoder layer):
  * the ~256 workgroups of the split are shared by all problems, so every output tile has ~256 / (total tiles)
  * partial sums, and the group needs one main + one reduce kernel.  Problem i: dW_i[K][n_seg * seg_width] split into
