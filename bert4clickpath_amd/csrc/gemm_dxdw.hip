@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
     for (int ks = 0; ks < NK; ++ks)
         wcf[ks] = *reinterpret_cast<const bf16x8 *>(a.Wc + (int64_t)(16 * wave + li) * a.ldw + ks * 32 + 8 * g);
 
-    constexpr int NT = NG == 3 ? 3 : 1;                 // gradient 32-column tiles per wave: 12 / 4 or 4 / 4
+    constexpr int NT = NG;                              // gradient 32-column tiles per wave: 4 NG / 4
     f32x16 acc[2][NT];                                  // [input-feature tiles of this wave][gradient-column tiles of this wave]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
     fetch(t0 + 1, 1);
     fetch(t0 + 2, 2);
     // (1 + NG) DMA instructions per thread and tile; the first tile must have landed: all but the two younger ones' are waited for
-    if (NG == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (NG == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (NG == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __syncthreads();
     // ---- pipeline of one tile: [residual chunk of this tile requested] [DMA of tile t + 3] [dX rows of tile t - 1: staged tile +
     // residual -> global] [dW, dX of tile t -> staged] [tile t + 1 landed?] [barrier].  ONE barrier per tile: the staged dX tile is
@@ -363,7 +363,7 @@ static int dxdw_grid(int64_t M, int64_t *tiles_per_wg) {
 }
 
 extern "C" int64_t b4c_gemm_dxdw_workspace_bytes(int64_t M, int n_seg) {
-    if (M <= 0 || (n_seg != 1 && n_seg != 3)) return 0;
+    if (M <= 0 || n_seg < 1 || n_seg > 3) return 0;
     int64_t per;
     const int grid = dxdw_grid(M, &per);
     return (int64_t)grid * (128 * n_seg + n_seg) * 128 * 4;      // dW^T rows + n_seg rows for the 128 n_seg db sums, per workgroup
@@ -386,7 +386,7 @@ extern "C" int b4c_gemm_dxdw(const void *X, int ldx, const void *G, int ldg, con
                              void *dX, int ldo, int n_seg, float *const *h_dW, float *const *h_db, int ld_dw, int64_t M,
                              void *workspace, int64_t workspace_bytes, void *stream) {
     B4C_REQUIRE(X && G && Wc && dX && h_dW && workspace, "gemm_dxdw: null pointer");
-    B4C_REQUIRE(n_seg == 1 || n_seg == 3, "gemm_dxdw: %d column segments (1 or 3)", n_seg);
+    B4C_REQUIRE(n_seg >= 1 && n_seg <= 3, "gemm_dxdw: %d column segments (1 to 3)", n_seg);
     B4C_REQUIRE(M > 0 && ldx >= 128 && ldg >= 128 * n_seg && ldw >= 128 * n_seg && ldo >= 128 && (!residual || ldr >= 128), "gemm_dxdw: shape");
     B4C_REQUIRE(ldx % 8 == 0 && ldg % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0 && ldr % 8 == 0 &&
                 ((((uintptr_t)X | (uintptr_t)G | (uintptr_t)Wc | (uintptr_t)dX | (uintptr_t)residual | (uintptr_t)workspace) & 15) == 0),
@@ -403,5 +403,6 @@ extern "C" int b4c_gemm_dxdw(const void *X, int ldx, const void *G, int ldg, con
         out.db[s] = h_db ? h_db[s] : nullptr;
     }
     out.ldw = ld_dw;
-    return n_seg == 3 ? dxdw_launch<3>(a, out, (hipStream_t)stream) : dxdw_launch<1>(a, out, (hipStream_t)stream);
+    return n_seg == 3 ? dxdw_launch<3>(a, out, (hipStream_t)stream) : n_seg == 2 ? dxdw_launch<2>(a, out, (hipStream_t)stream) :
+                        dxdw_launch<1>(a, out, (hipStream_t)stream);
 }

@@ -456,12 +456,15 @@ def _gemm_tn_impl(a, g, K, N, want_bias, into):
 
 
 # ---- the whole backward of a Dense layer in one pass over its gradient (csrc/gemm_dxdw.hip) -----------------------------------
-fused_dxdw = os.environ.get('B4C_FUSED_DXDW', '0') == '1'
+# Used where it measures faster than b4c_gemm_nt + b4c_gemm_tn: the fused Q | K | V projection (three column blocks: 217 us
+# against 111 + 147 us inside the C2 step).  One block: 151 against 102 us, two: 176 against 175 us -- those keep the two kernels.
+# B4C_FUSED_DXDW=0 switches it off.
+fused_dxdw = os.environ.get('B4C_FUSED_DXDW', '1') != '0'
 
 
 def dxdw_supported(x, g, n_seg):
-    """bf16, 128-wide layer input, gradient of 128 x n_seg columns (n_seg 1 or 3), rows the kernels' 16-B accesses can take"""
-    return x.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and x.shape[1] == 128 and n_seg in (1, 3) and \
+    """bf16, 128-wide layer input, gradient of 128 x n_seg columns (n_seg 1 to 3), rows the kernels' 16-B accesses can take"""
+    return x.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and x.shape[1] == 128 and n_seg in (1, 2, 3) and \
         g.shape[1] == 128 * n_seg and x.stride(0) % 8 == 0 and g.stride(0) % 8 == 0 and x.shape[0] >= 4096
 
 
@@ -1394,12 +1397,15 @@ class MQAttnBlockFn(torch.autograd.Function):
         if inplace:
             queue_dw(actx, x_m, dq, d, d, [wq.grad], [bq.grad], (wq, bq))
             flush_pending_dw(actx)                  # (the query-row problems have R rows, the key / value problem T)
-            queue_dw(actx, x, dkv, d, 2 * d, [wk.grad, wv.grad], [bk.grad, bv.grad], (wk, bk, wv, bv))
         else:
             dWq, dbq = gemm_tn(x_m, dq, d, d)
-            dWkv, dbkv = gemm_tn(x, dkv, d, 2 * d)
         dx_m = gemm_nt(dq, wc_qkv[:, :d], d, residual=dz, out_dtype=torch.float32)      # query rows: through Wq + the residual branch (kept in fp32 until it joins dx)
-        dx = gemm_nt(dkv, wc_qkv[:, d:3 * d], d)               # every token: through Wk | Wv
+        # every token: through Wk | Wv (b4c_gemm_dxdw with two column blocks measures 176 us against 84 + 91 us here: not used)
+        if inplace:
+            queue_dw(actx, x, dkv, d, 2 * d, [wk.grad, wv.grad], [bk.grad, bv.grad], (wk, bk, wv, bv))
+        else:
+            dWkv, dbkv = gemm_tn(x, dkv, d, 2 * d)
+        dx = gemm_nt(dkv, wc_qkv[:, d:3 * d], d)
         rows_add_(dx, midx, dx_m)
         if inplace:
             _ready(gam, bet)

@@ -152,7 +152,7 @@ int b4c_gemm_tn_seg(const void *A, int lda, const void *G, int ldg, int n_seg, f
 
 /* (ABI 9) the whole backward of one Dense layer of the encoder in ONE pass over its output gradient (transformer.py:112-116,
  * 158, 163-167 seen from the backward pass):   dX = G Wc^T (+ residual)   dW_s += X^T G_s   db_s += colsum(G_s)
- * X [M][128] the layer's input, G [M][128 n_seg] (n_seg = 3: q | k | v column blocks, 1: a plain layer), Wc [128][128 n_seg]
+ * X [M][128] the layer's input, G [M][128 n_seg] (n_seg = 3: q | k | v column blocks, 2: k | v, 1: a plain layer), Wc [128][128 n_seg]
  * (row = input feature, the dX operand of b4c_gemm_nt), residual [M][128] or NULL, dX [M][128]; dW_s fp32 [128][ld_dw] Keras
  * layout, db_s fp32 [128] or NULL (h_dW / h_db: HOST arrays of n_seg device pointers).  bf16, 128-wide layers only; G is read from
  * HBM once (as b4c_gemm_nt + b4c_gemm_tn it is read twice).  Deterministic: per-workgroup partial sums meet in workgroup order

@@ -24,7 +24,7 @@ def _case(M, n_seg, seed, integer=True):
     return [t.cuda().bfloat16() for t in (x, G, W, res)]
 
 
-@pytest.mark.parametrize('n_seg', [1, 3])
+@pytest.mark.parametrize('n_seg', [1, 2, 3])
 @pytest.mark.parametrize('M', [4096, 4097, 64 * 300 + 1, 100001, 456123])
 @pytest.mark.parametrize('with_residual', [True, False])
 def test_fused_dense_backward_is_exact_on_integer_data(M, n_seg, with_residual):
@@ -95,7 +95,7 @@ def test_the_model_step_with_the_fused_backward_matches_the_default_step():
             ops.join_side_work(t.opt.arena.ctx)
             torch.cuda.synchronize()
             out[flag] = (float(loss.detach()), {n: p.grad.detach().float().clone() for n, p in t.model.named_parameters()})
-            # one per encoder layer but the last (evaluated at the [MASK] rows only: MQAttnBlockFn), none without the switch
+            # one per encoder layer but the last (evaluated at the [MASK] rows only: MQAttnBlockFn), none when switched off
             assert len(calls) == (2 if flag else 0), calls
     finally:
         ops.fused_dxdw, ops.gemm_dxdw = prev, real
