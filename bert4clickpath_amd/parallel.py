@@ -78,6 +78,7 @@ class GradReducer:
         self.sparse = []
         self.sparse_max_fill = sparse_max_fill
         self._touched = {}
+        self.launched = []
         self.last_exchange = {}           # param name/id -> 'sparse' | 'dense' (what the last finish() did; for tests / logs)
         dense_end = arena.numel
         if sparse_params:
@@ -142,12 +143,14 @@ class GradReducer:
 
     def _launch(self, b):
         lo, hi = self.buckets[b]
+        self.launched.append(b)           # (the order this rank issued its collectives in: the same on every rank, tests check it)
         self._handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def begin_backward(self):
         """Call before loss.backward(): arms the per-bucket countdowns."""
         self.arena.ctx.reset()        # (a failed step's leftover side-stream work must not announce into this one)
         self._handles = []
+        self.launched = []
         self._seen = set()
         self._next = 0
         self._pending = list(self._sizes) if self.overlap else None

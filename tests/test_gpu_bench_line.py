@@ -62,23 +62,26 @@ def test_bench_line_without_cpu_leg_still_parses():
     assert line['value'] > 0 and 'roofline' in line
 
 
-def test_bench_starts_its_own_ranks():
-    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: bench.py starts the two ranks itself (a parent that
-    has made no GPU call; torch.distributed.run on 127.0.0.1) and prints ONE line with n_gpus = 2 whose value counts both
-    ranks' items.  On a one-GPU box both ranks share the card and the exchange goes over gloo; the line says so."""
+@pytest.mark.parametrize('n', [2, 4])
+def test_bench_starts_its_own_ranks(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: bench.py starts the N ranks itself (a parent that
+    has made no GPU call; torch.distributed.run on 127.0.0.1) and prints ONE line with n_gpus = N whose value counts every
+    rank's items.  On a one-GPU box the ranks share the card and the exchange goes over gloo; the line says so.  N = 4 is the
+    largest rehearsal a one-GPU box of this pool takes (at most 6 processes on the card, this one included); the reducer itself
+    is rehearsed at world size 8 on CPU tensors (tests/test_parallel_cpu.py)."""
     import torch
     env = dict(os.environ)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--batch', '256',
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '4', '--warmup', '2', '--batch', '256',
            '--vocab', '8192', '--layers', '2', '--n_batches', '2', '--record_steps', '1']
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, 'one JSON line from rank 0, got %d' % len(lines)
     line = json.loads(lines[0])
-    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 512 and line['config']['parallelism'].startswith('dp2')
-    assert ('REHEARSAL' in line['config']['parallelism']) == (torch.cuda.device_count() < 2)
+    assert line['n_gpus'] == n and line['config']['global_batch'] == 256 * n and line['config']['parallelism'].startswith('dp%d' % n)
+    assert ('REHEARSAL' in line['config']['parallelism']) == (torch.cuda.device_count() < n)
     items_per_step = line['value'] * line['ms_per_step'] / 1e3
-    assert 0.5 * 512 < items_per_step < 512 * 11, items_per_step        # both ranks' masked items
+    assert 0.5 * 256 * n < items_per_step < 256 * n * 11, items_per_step        # every rank's masked items
     assert 'eval' not in line and 'cpu_baseline' not in line            # N = 1 legs only

@@ -143,6 +143,8 @@ def _random_worker(rank, world, port, q):
         overlap, mode = bool(rng.integers(0, 2)), ('sum', 'mean')[int(rng.integers(0, 2))]
         red = parallel.GradReducer(arena, bucket_bounds=inner, reduce=mode, overlap=overlap)
         has = rng.random((world, n_par)) < 0.8                     # which rank produces which gradient
+        if world >= 4:
+            has[case % world, :] = False                           # an empty replica every case (a shard without one masked row)
         coef = rng.standard_normal((world, n_par))
         arena.zero_grad()
         red.begin_backward()
@@ -152,6 +154,11 @@ def _random_worker(rank, world, port, q):
         red.finish()
         if mode == 'mean':                                         # 'mean' multiplies the summed arena by 1 / world at the optimizer
             assert red.grad_mul == 1.0 / world
+        # every rank issued its collectives in bucket order, whatever order (and whether) its gradients arrived in
+        assert red.launched == list(range(len(red.buckets))), (case, red.launched)
+        flat = [torch.empty_like(arena.grad) for _ in range(world)]
+        dist.all_gather(flat, arena.grad)
+        assert all(torch.equal(f, flat[0]) for f in flat), case     # replicas hold the same bits
         for i, p in enumerate(params):
             want = sum(float(coef[r, i]) for r in range(world) if has[r, i]) * 2.0 * p.detach()
             got = p.grad if p.grad is not None else torch.zeros_like(p)
@@ -162,7 +169,7 @@ def _random_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_random_arenas_reduce_to_the_sum_on_every_rank(world):
     port = _free_port()
     ctx = mp.get_context('spawn')
@@ -175,3 +182,72 @@ def test_random_arenas_reduce_to_the_sum_on_every_rank(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(res[r] == 12 for r in range(world))
+
+
+def _sparse_worker(rank, world, port, q):
+    """The row-sparse exchange of an embedding table's gradient at world size 8: ranks that touched a few rows, one that
+    touched many, one that touched none.  Whether the table travels as (indices, rows) or falls back to the dense all-reduce is
+    decided from the GATHERED row counts, so every rank takes the same branch (a rank deciding on its own count would pair an
+    all-gather with the others' all-reduce: a hang); either way every replica ends with the same bits -- the ranks' sum."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import numpy as np
+    from bert4clickpath_amd import optim, parallel
+    parallel.init_distributed(backend='gloo')
+    rows, width = 400, 8
+    torch.manual_seed(3)                                           # the same weights on every rank
+    dense_p = torch.nn.Parameter(torch.randn(33))
+    table = torch.nn.Parameter(torch.randn(rows, width))
+    arena = optim.FlatArena([dense_p, table])
+    seen = []
+    for case, (fill, expect) in enumerate(((0.2, 'dense'), (4.0, 'sparse'), (0.2, 'sparse'))):
+        rng = np.random.default_rng(50 + case)                     # the same draw on every rank
+        counts = [int(rng.integers(1, 6)) for _ in range(world)]
+        counts[3] = 0                                              # an empty replica
+        if case < 2:
+            counts[6] = 60                                         # one heavy rank: 60 x 8 ranks > 0.2 x 400 rows -> dense for ALL
+        ids_all = [rng.integers(0, rows, size=c) for c in counts]
+        ids = torch.from_numpy(ids_all[rank]).to(torch.int64)
+        red = parallel.GradReducer(arena, reduce='sum', overlap=bool(case & 1), sparse_params=[table], sparse_max_fill=fill)
+        arena.zero_grad()
+        red.begin_backward()
+        loss = (rank + 1.0) * dense_p.sum()
+        if ids.numel():
+            loss = loss + (rank + 2.0) * (table[ids] * table[ids]).sum()
+        loss.backward()
+        local = table.grad.clone() if table.grad is not None else torch.zeros_like(table)
+        red.set_touched_rows(table, ids)
+        red.finish()
+        assert red.last_exchange[id(table)] == expect, (case, red.last_exchange)
+        took = [None] * world
+        dist.all_gather_object(took, red.last_exchange[id(table)])
+        assert len(set(took)) == 1, took                           # decided alike everywhere
+        every = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(every, local)
+        want = torch.zeros_like(local)
+        for r in range(world):                                     # rank order: the order the exchange adds in
+            want += every[r]
+        assert torch.allclose(table.grad, want, rtol=1e-6, atol=1e-7), case
+        if expect == 'sparse':
+            assert torch.equal(table.grad, want), case
+        reps = [torch.empty_like(table.grad) for _ in range(world)]
+        dist.all_gather(reps, table.grad.contiguous())
+        assert all(torch.equal(t, reps[0]) for t in reps), case     # bit-identical replicas
+        assert torch.allclose(dense_p.grad, torch.full_like(dense_p, float(sum(range(1, world + 1)))))
+        seen.append(expect)
+    q.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_row_sparse_exchange_decides_alike_on_every_rank():
+    world, port = 8, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res[r] == ['dense', 'sparse', 'sparse'] for r in range(world))
