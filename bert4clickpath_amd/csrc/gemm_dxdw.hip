@@ -88,6 +88,9 @@ struct DxDwArgs {
     const bf16_t *Wc;     // [128][ldw] rows = input features, 128 NG columns (the dX operand: K-contiguous)
     const bf16_t *Res;    // [M][ldr] or NULL: added to dX (the residual branch's gradient)
     bf16_t *dX;           // [M][ldo]
+#ifdef DD_EXPERIMENT
+    int debug;            // scratch builds only: 1 = no MFMA work (memory alone), 2 = no DMA past the first tiles (compute alone), 3 = no dX stores
+#endif
     float *part;          // [workgroups][128 NG + NG][128]: dW^T partials (row n = gradient column, 128 input features), then the 128 NG db sums
     int ldx, ldg, ldw, ldr, ldo;
     int64_t M;
@@ -193,6 +196,9 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
     // rows of tile tp (staged in so, residual chunk res) -> global
     auto store_rows = [&](int64_t tp, const char *so, dd_u32x4 res) {
         const int64_t tk = (gfirst + tp * gstep) * DD_TOK + orow;
+#ifdef DD_EXPERIMENT
+        if (a.debug == 3) return;
+#endif
         if (tk < a.M) {
             const dd_u32x4 w4 = *reinterpret_cast<const dd_u32x4 *>(so + orow * DD_OSTR + opart * 16);
             const bf16x8 cv = __builtin_bit_cast(bf16x8, w4);
@@ -216,6 +222,9 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
         dd_u32x4 &res_cur = (slot & 1) ? res1 : res0;
         dd_u32x4 &res_prev = (slot & 1) ? res0 : res1;
         res_load(t, res_cur);
+#ifdef DD_EXPERIMENT
+        if (a.debug == 2) { for (int i_ = 0; i_ < ND; ++i_) dd_dma(a.X, a.ldx, 0, 0, 0, lds0, wave, lane); } else
+#endif
         fetch(t + 3, (slot + 3) % DD_RING);             // that stage held tile t - 1: every wave is past it (the barrier below)
         if (k > 0) {
             // the dX rows of tile t - 1 leave now.  Its residual chunk was requested at the top of tile t - 1; issued since:
@@ -229,6 +238,9 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
         }
         DSTAMP(0);
         // ---- dW += X^T G: two 16-token steps ----
+#ifdef DD_EXPERIMENT
+        if (a.debug != 1)
+#endif
 #pragma unroll
         for (int kk = 0; kk < DD_TOK / 16; ++kk) {
             const char *bx = sx + kk * 16 * 256;
@@ -256,6 +268,9 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
         f32x4 ax[NMI];
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) ax[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef DD_EXPERIMENT
+        if (a.debug != 1)
+#endif
 #pragma unroll
         for (int sb = 0; sb < NG; ++sb) {
             bf16x8 fg[NMI][4];
@@ -340,13 +355,24 @@ struct DxDwOut {
     float *db[3];
     int ldw;
 };
+// The workgroups' partial sums meet here in a fixed order (bit-repeatable for a given grid).  A block owns 32 consecutive entries;
+// its eight 32-lane groups each add every eighth workgroup's partial (128-B rows, 32 independent loads per thread), the groups'
+// sums meet in group order.  (One thread per entry walking all 256 partials took 63 - 68 us -- as long as half the main kernel.)
 template <int NG>
 __global__ void __launch_bounds__(256) dxdw_reduce_kernel(const float *__restrict__ part, int nwg, DxDwOut out) {
     constexpr int ROWS = 128 * NG + NG;
-    const int idx = blockIdx.x * 256 + threadIdx.x;      // over ROWS x 128
-    if (idx >= ROWS * 128) return;
+    __shared__ float sh[8][32];
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + c;                 // over ROWS x 128 (a multiple of 32)
     float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += part[(int64_t)w * ROWS * 128 + idx];
+#pragma unroll 8
+    for (int w = q; w < nwg; w += 8) s += part[(int64_t)w * ROWS * 128 + idx];
+    sh[q][c] = s;
+    __syncthreads();
+    if (q != 0) return;
+    s = sh[0][c];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += sh[k][c];
     const int row = idx >> 7, k = idx & 127;
     if (row < 128 * NG) {
         out.dW[row >> 7][(int64_t)k * out.ldw + (row & 127)] += s;
@@ -378,7 +404,7 @@ static int dxdw_launch(DxDwArgs a, DxDwOut out, hipStream_t st) {
     static thread_local bool done = false;
     if (!done) { (void)hipFuncSetAttribute((const void *)gemm_dxdw_kernel<NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
     gemm_dxdw_kernel<NG><<<grid, 512, lds, st>>>(a);
-    dxdw_reduce_kernel<NG><<<((128 * NG + NG) * 128 + 255) / 256, 256, 0, st>>>(a.part, grid, out);
+    dxdw_reduce_kernel<NG><<<(128 * NG + NG) * 128 / 32, 256, 0, st>>>(a.part, grid, out);
     return b4c_check_launch("gemm_dxdw");
 }
 
@@ -396,6 +422,9 @@ extern "C" int b4c_gemm_dxdw(const void *X, int ldx, const void *G, int ldg, con
     a.X = (const bf16_t *)X; a.G = (const bf16_t *)G; a.Wc = (const bf16_t *)Wc; a.Res = (const bf16_t *)residual; a.dX = (bf16_t *)dX;
     a.part = (float *)workspace;
     a.ldx = ldx; a.ldg = ldg; a.ldw = ldw; a.ldr = ldr; a.ldo = ldo; a.M = M;
+#ifdef DD_EXPERIMENT
+    { static const char *e = getenv("B4C_DXDW_DEBUG"); a.debug = e ? atoi(e) : 0; }
+#endif
     DxDwOut out = {};
     for (int s = 0; s < n_seg; ++s) {
         B4C_REQUIRE(h_dW[s], "gemm_dxdw: null dW segment %d", s);

@@ -456,10 +456,12 @@ def _gemm_tn_impl(a, g, K, N, want_bias, into):
 
 
 # ---- the whole backward of a Dense layer in one pass over its gradient (csrc/gemm_dxdw.hip) -----------------------------------
-# Used where it measures faster than b4c_gemm_nt + b4c_gemm_tn: the fused Q | K | V projection (three column blocks: 217 us
-# against 111 + 147 us inside the C2 step).  One block: 151 against 102 us, two: 176 against 175 us -- those keep the two kernels.
-# B4C_FUSED_DXDW=0 switches it off.
-fused_dxdw = os.environ.get('B4C_FUSED_DXDW', '1') != '0'
+# Inside the C2 step (456 k token rows; main kernel + the fixed-order reduction of the workgroups' partial sums):
+#   Q | K | V projection (three column blocks)   ~150 us against 111 + 147 us for b4c_gemm_nt + its share of the grouped b4c_gemm_tn
+#   K | V of the masked-query last layer (two)    ~100 us against 84 + 91
+#   attention output projection (one, no residual) ~70 us against 50 + 50
+# B4C_FUSED_DXDW: 0 = off, 1 = Q | K | V only, 2 = + K | V, 3 (default) = + the output projection.
+fused_dxdw = int(os.environ.get('B4C_FUSED_DXDW', '3'))
 
 
 def dxdw_supported(x, g, n_seg):
@@ -1304,11 +1306,15 @@ class AttnBlockFn(torch.autograd.Function):
                                                           into=(gam.grad, bet.grad) if inplace else None)
         _, wc_o, _ = pk_o.get(x.dtype, d, True)
         _, wc_qkv, _ = pk_qkv.get(x.dtype, d, True)
-        if inplace:
-            queue_dw(actx, o, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
+        if inplace and fused_dxdw >= 3 and dxdw_supported(o, dy, 1):
+            d_o = gemm_dxdw(o, dy, wc_o, [wo.grad], [bo.grad])
+            _ready(wo, bo)
         else:
-            dWo, dbo = gemm_tn(o, dy, d, d)
-        d_o = gemm_nt(dy, wc_o, d)
+            if inplace:
+                queue_dw(actx, o, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
+            else:
+                dWo, dbo = gemm_tn(o, dy, d, d)
+            d_o = gemm_nt(dy, wc_o, d)
         with _timed('attn_bwd'):
             dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, ctx.cu, actx)
         if inplace and fused_dxdw and dxdw_supported(x, dqkv, 3):
@@ -1400,12 +1406,16 @@ class MQAttnBlockFn(torch.autograd.Function):
         else:
             dWq, dbq = gemm_tn(x_m, dq, d, d)
         dx_m = gemm_nt(dq, wc_qkv[:, :d], d, residual=dz, out_dtype=torch.float32)      # query rows: through Wq + the residual branch (kept in fp32 until it joins dx)
-        # every token: through Wk | Wv (b4c_gemm_dxdw with two column blocks measures 176 us against 84 + 91 us here: not used)
-        if inplace:
-            queue_dw(actx, x, dkv, d, 2 * d, [wk.grad, wv.grad], [bk.grad, bv.grad], (wk, bk, wv, bv))
+        # every token: through Wk | Wv
+        if inplace and fused_dxdw >= 2 and dxdw_supported(x, dkv, 2):
+            dx = gemm_dxdw(x, dkv, wc_qkv[:, d:3 * d], [wk.grad, wv.grad], [bk.grad, bv.grad])
+            _ready(wk, bk, wv, bv)
         else:
-            dWkv, dbkv = gemm_tn(x, dkv, d, 2 * d)
-        dx = gemm_nt(dkv, wc_qkv[:, d:3 * d], d)
+            if inplace:
+                queue_dw(actx, x, dkv, d, 2 * d, [wk.grad, wv.grad], [bk.grad, bv.grad], (wk, bk, wv, bv))
+            else:
+                dWkv, dbkv = gemm_tn(x, dkv, d, 2 * d)
+            dx = gemm_nt(dkv, wc_qkv[:, d:3 * d], d)
         rows_add_(dx, midx, dx_m)
         if inplace:
             _ready(gam, bet)

@@ -68,7 +68,7 @@ def test_fused_dense_backward_on_random_data_agrees_with_the_two_kernel_path():
 
 
 def test_the_model_step_with_the_fused_backward_matches_the_default_step():
-    """The whole training step with the QKV projection's backward through b4c_gemm_dxdw (arena mode, >= 4,096 token rows: below
+    """The whole training step with the attention block's projections' backward through b4c_gemm_dxdw (arena mode, >= 4,096 token rows: below
     that the fused kernel is not chosen): same loss; the weight gradients of the projection are the same fp32 sums in another
     order, everything upstream of it sees dX within a bf16 rounding."""
     from bert4clickpath_amd import input_pipeline, ops
@@ -85,7 +85,7 @@ def test_the_model_step_with_the_fused_backward_matches_the_default_step():
         return real(*a, **k)
     ops.gemm_dxdw = counted
     try:
-        for flag in (False, True):
+        for flag in (0, 3):
             ops.fused_dxdw = flag
             t = _ArenaAdam(_model(6, 3))
             t.opt.zero_grad()
@@ -95,12 +95,13 @@ def test_the_model_step_with_the_fused_backward_matches_the_default_step():
             ops.join_side_work(t.opt.arena.ctx)
             torch.cuda.synchronize()
             out[flag] = (float(loss.detach()), {n: p.grad.detach().float().clone() for n, p in t.model.named_parameters()})
-            # one per encoder layer but the last (evaluated at the [MASK] rows only: MQAttnBlockFn), none when switched off
-            assert len(calls) == (2 if flag else 0), calls
+            # two per full encoder layer (output projection, Q | K | V) and one for the last (K | V: it is evaluated at the
+            # [MASK] rows only, MQAttnBlockFn), none when switched off
+            assert len(calls) == (5 if flag else 0), calls
     finally:
         ops.fused_dxdw, ops.gemm_dxdw = prev, real
-    assert out[True][0] == out[False][0]                        # (the forward pass is the same code)
-    for n, gd in out[False][1].items():
-        gf = out[True][1][n]
+    assert out[3][0] == out[0][0]                        # (the forward pass is the same code)
+    for n, gd in out[0][1].items():
+        gf = out[3][1][n]
         assert float((gf - gd).abs().max()) <= 2e-2 * float(gd.abs().max()) + 1e-9, n
         assert float((gf - gd).norm()) <= 5e-3 * float(gd.norm()) + 1e-9, n
