@@ -111,11 +111,12 @@ def build_model(a, device):
 def backward_order(model):
     """Arena order = the order gradients COMPLETE in backward: head trunk, encoder layers last -> first, embedding -- and
     the vocabulary projection with the embedding when its dW sweep runs as a background job beside the encoder backward
-    (ops.overlap_vocab_dw: it is announced when backward ends), so that the buckets before it go out as they complete."""
+    (ops.background_dw_expected: it is announced when backward ends), so that the buckets before it go out as they complete."""
     from bert4clickpath_amd import ops
     names = {id(p): n for n, p in model.named_parameters()}
     L = model.num_encoder_layers
-    late = ('head.output_layer.',) if (ops.overlap_vocab_dw and ops.flash_ce) else ()
+    background = ops.background_dw_expected(model.transformer.d_model, model.encoder_ff_dim, model.compute_dtype)
+    late = ('head.output_layer.',) if (background and ops.flash_ce) else ()
 
     def key(p):
         n = names[id(p)]
@@ -320,7 +321,7 @@ class Training:
         self.opt = optim.Adam(model.parameters(), order=backward_order(model), lazy_rows=lazy)
         arena = self.opt.arena
         emb_start = min(arena.slice_of(p)[0] for n, p in model.named_parameters() if 'embedding_layers' in n)
-        # (head parameters placed behind the tables -- the projection under ops.overlap_vocab_dw -- belong to the last bucket)
+        # (head parameters placed behind the tables -- the projection when its sweep runs in the background -- belong to the last bucket)
         head_end = max(arena.slice_of(p)[1] for n, p in model.named_parameters()
                        if n.startswith('head.') and n != 'head.output_embedding' and arena.slice_of(p)[0] < emb_start)
         self.tables = [p for n, p in model.named_parameters() if 'embedding_layers' in n]
@@ -519,8 +520,10 @@ def main():
                                       'the padding-free layout (%.0f %% of the B x S positions are real tokens)%s'
                                       % (100.0 * sum(b['n_real'] for b in batches) / (len(batches) * a.batch * a.seq),
                                          (', last layer evaluated at the [MASK] rows only' if ops.mq_last_layer else '') +
-                                         (', vocabulary dW sweep as a background kernel beside the encoder backward'
-                                          if ops.overlap_vocab_dw and ops.flash_ce and not a.sampled else ''))),
+                                         ((', vocabulary dW sweep as a background kernel beside the encoder backward'
+                                           if ops.background_dw_expected(a.d_model, a.dff, model.compute_dtype) else
+                                           ', feed-forward and projection backward as fused single-pass kernels, vocabulary dW sweep in the foreground')
+                                          if ops.flash_ce and not a.sampled else ''))),
                        'global_batch': a.batch * world, 'seq_len': a.seq,
                        'parallelism': ('dp%d' % world) + (' (REHEARSAL: %d ranks share %d device(s), gradient exchange over gloo -- not an '
                                                            'RCCL / xGMI measurement)' % (world, ndev) if shared else ''),

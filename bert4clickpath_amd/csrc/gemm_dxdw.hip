@@ -22,55 +22,7 @@
 
 #include "common.h"
 
-typedef __attribute__((ext_vector_type(4))) unsigned dd_u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned dd_u32x2;
-typedef __attribute__((ext_vector_type(4))) short dd_s16x4;
-typedef __attribute__((ext_vector_type(8))) short dd_s16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 dd_bf16x4;
-
-#define DD_TOK 32                    // tokens per tile
-#define DD_SUB (DD_TOK * 256)        // one [32][128] bf16 sub-tile: 8 KB
-#define DD_RING 4                    // LDS stages: the tile in work + three on their way (one tile of cover leaves the memory
-                                     // system idle while the workgroup computes and waits in turn: 2.7 TB/s measured)
-#define DD_OSTR 272                  // bytes per staged dX row (256 + 16)
-
-// 16-B chunk c of row j of a [rows][128] bf16 sub-tile sits at chunk c ^ swz(j): the direct 16-B fragment reads and the
-// transposed 8-B reads both spread over the 64 banks (same image as csrc/vocab_ce.hip's VTile<128>)
-__device__ __forceinline__ int dd_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-__device__ __forceinline__ int dd_chunk_off(int row, int chunk) { return row * 256 + ((chunk ^ dd_swz(row)) << 4); }
-// transposed fragment piece of MFMA 32x32x16 (A or B operand: feature `32 dt + r`, tokens 8 hf + 0..7 of a 16-token step):
-// the lane's address is token row 4 hf + (li >> 2) (+ 8 for the second piece), features 32 dt + 16 (g & 1) + 4 (li & 3)
-__device__ __forceinline__ int dd_tr_off(int hf, int li, int g, int dt, int second) {
-    const int row = 4 * hf + (li >> 2) + 8 * second;
-    const int e = dt * 32 + 16 * (g & 1) + 4 * (li & 3);
-    return dd_chunk_off(row, e >> 3) + (e & 7) * 2;
-}
-__device__ __forceinline__ bf16x8 dd_frag_tr(const char *p0, const char *p1) {
-    const dd_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dd_s16x4 __attribute__((address_space(3))) *)(p0));
-    const dd_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dd_s16x4 __attribute__((address_space(3))) *)(p1));
-    const dd_s16x8 w = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    return __builtin_bit_cast(bf16x8, w);
-}
-// rows [tok0, tok0 + 32) x columns [c0, c0 + 128) of P (row pitch ld) -> LDS sub-tile at byte address lds_dst, this wave's share
-// (one of the 8 wave instructions of 1 KiB: 4 rows); rows >= M arrive as zeros.
-// Inline assembly, not __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler cannot tell the DMA's destination from the stages the
-// loop's ds_reads address and drains the vector-memory counter right behind every request (s_waitcnt vmcnt(0): the four-stage ring
-// ran as one stage).  The kernel orders a tile's arrival against its first read itself (counted s_waitcnt + barrier).
-__device__ __forceinline__ void dd_dma(const bf16_t *__restrict__ P, int ld, int c0, int64_t tok0, int64_t M, unsigned lds_dst, int wave, int lane) {
-    const int64_t left = M - tok0;
-    const int64_t rows = left < 0 ? 0 : (left < DD_TOK ? left : DD_TOK);
-    const int64_t bytes = rows > 0 ? (rows - 1) * (int64_t)ld * 2 + 256 : 0;
-    const uint64_t base = (uint64_t)(P + tok0 * ld + c0);
-    dd_u32x4 rs;
-    rs[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
-    rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xFFFFu);
-    rs[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);
-    rs[3] = 0x00020000u;
-    const int row = wave * 4 + (lane >> 4), slot = lane & 15;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst + (unsigned)(wave * 1024));
-    const unsigned voff = (unsigned)((row * ld + ((slot ^ dd_swz(row)) << 3)) * 2);
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(voff), "s"(rs) : "m0");
-}
+#include "dxdw_common.h"
 
 #ifdef DD_STAMPS
 __device__ unsigned long long g_dd_stamps[256 * 8 * 8];
@@ -168,33 +120,43 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
     // (1 + NG) DMA instructions per thread and tile; the first tile must have landed: all but the two younger ones' are waited for
     if (NG == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (NG == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __syncthreads();
-    // ---- pipeline of one tile: [residual chunk of this tile requested] [DMA of tile t + 3] [dX rows of tile t - 1: staged tile +
-    // residual -> global] [dW, dX of tile t -> staged] [tile t + 1 landed?] [barrier].  ONE barrier per tile: the staged dX tile is
-    // double-buffered and leaves a tile late.
-    // The vector-memory counter retires in issue order and the compiler knows nothing of the inline-assembly requests, so every
-    // wait is counted by hand: s_waitcnt vmcnt(N) with N = the operations issued AFTER the one waited for.
+    // ---- pipeline of one tile: [DMA of tile t + 3] [everything older landed?] [dX rows of tile t - 1: staged tile + residual ->
+    // global] [residual chunk of this tile requested] [dW, dX of tile t -> staged] [barrier].  ONE barrier per tile: the staged dX tile
+    // is double-buffered and leaves a tile late.
+    // The vector-memory counter retires in issue order (loads, stores and LDS-DMA alike: scratch/vmcnt_order.hip) and the compiler
+    // knows nothing of the inline-assembly requests, so every wait is counted by hand: s_waitcnt vmcnt(N) with N = the operations
+    // issued AFTER the one waited for.
     const int orow = tid >> 4, opart = tid & 15;
-#define DD_WAIT_VM(n) do { switch (n) { case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break; case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break; \
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break; case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break; \
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break; case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break; \
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break; case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break; \
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break; case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break; \
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break; } } while (0)
     constexpr int ND = 1 + NG;                          // DMA requests per thread and tile
-    // The residual chunk of a tile is requested a tile ahead of its use, by inline assembly, INTO a register quadruple that stays
-    // where it is ("+v": the request overwrites its operand in place).  A chunk returned by value would be copied to wherever the
-    // compiler merges the unrolled tiles' values -- a v_mov of registers whose load is still in flight, which no s_waitcnt of
-    // ours covers: the last tile of a workgroup then left with stale registers in place of its residual.
-    auto res_load = [&](int64_t t, dd_u32x4 &v) {
+#define DD_WAIT_VM(n) do { switch (n) { case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break; case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break; \
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break; case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break; \
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break; case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break; \
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break; } } while (0)
+    // The residual chunk of a tile lands in LDS too (LDS-DMA, 16 B per thread at thread * 16; the thread reads back its own piece, so
+    // the issuing wave's counted wait is all the ordering it needs).  It landed in REGISTERS first (an inline-assembly global load
+    // a tile ahead): the compiler knows nothing of a load in flight and copies such a register whenever it likes -- a chunk returned
+    // by value was copied to wherever the unrolled tiles' values merge, a workgroup's last tile then left with stale registers; in
+    // csrc/ffn_bwd.hip hipcc 7.2 hoisted a copy above the counted s_waitcnt, and naming the registers on the wait made it copy all
+    // of them in front of it.  Nothing can copy LDS.
+    char *sRes = sOut + 2 * DD_TOK * DD_OSTR;           // [512 threads][16 B]
+    dd_u32x4 ds_res = {0u, 0u, 0u, 0x00020000u};
+    if (a.Res) {
+        const uint64_t br = (uint64_t)a.Res;
+        ds_res[0] = __builtin_amdgcn_readfirstlane((unsigned)br); ds_res[1] = __builtin_amdgcn_readfirstlane((unsigned)(br >> 32) & 0xFFFFu);
+        ds_res[2] = __builtin_amdgcn_readfirstlane((unsigned)((a.M - 1) * a.ldr * 2 + 256));
+    }
+    const unsigned res_lds = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(sRes - smem) + (unsigned)(wave * 1024));
+    auto res_load = [&](int64_t t) {
         if (a.Res) {                                    // (workgroup-uniform; rows past M read the last row: never stored)
             const int64_t tk = (gfirst + t * gstep) * DD_TOK + orow;
-            const int64_t row = tk < a.M ? tk : a.M - 1;
-            const bf16_t *ptr = a.Res + row * a.ldr + opart * 8;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(v) : "v"(ptr));
+            const unsigned row = (unsigned)(tk < a.M ? tk : a.M - 1);
+            const unsigned vo = row * (unsigned)(a.ldr * 2) + (unsigned)opart * 16u;      // (< 4 GB: checked by the host)
+            // lgkmcnt(0): this thread's read of the previous chunk is done before anything can land on it
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(res_lds), "v"(vo), "s"(ds_res) : "m0", "memory");
         }
     };
     // rows of tile tp (staged in so, residual chunk res) -> global
-    auto store_rows = [&](int64_t tp, const char *so, dd_u32x4 res) {
+    auto store_rows = [&](int64_t tp, const char *so) {
         const int64_t tk = (gfirst + tp * gstep) * DD_TOK + orow;
 #ifdef DD_EXPERIMENT
         if (a.debug == 3) return;
@@ -202,14 +164,13 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
         if (tk < a.M) {
             const dd_u32x4 w4 = *reinterpret_cast<const dd_u32x4 *>(so + orow * DD_OSTR + opart * 16);
             const bf16x8 cv = __builtin_bit_cast(bf16x8, w4);
-            const bf16x8 rv = __builtin_bit_cast(bf16x8, res);
+            const bf16x8 rv = a.Res ? *reinterpret_cast<const bf16x8 *>(sRes + tid * 16) : cv;
             float v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = (float)cv[k] + (a.Res ? (float)rv[k] : 0.f);
             Vec8<bf16_t>::template store_sel<B4C_NT(B4C_NT_GEMM)>(a.dX + tk * a.ldo + opart * 8, v);
         }
     };
-    dd_u32x4 res0 = {0u, 0u, 0u, 0u}, res1 = {0u, 0u, 0u, 0u};     // residual chunks of the even / odd tiles (as counted from t0)
 #ifdef DD_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -218,24 +179,20 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
         constexpr int slot = decltype(SLOT)::value;
         const char *sx = smem + slot * STAGE;
         const char *sg = sx + DD_SUB;
-        const int k = (int)(t - t0 < 3 ? t - t0 : 3);   // tiles behind this one (saturated): how many stores / residual chunks are in the queue
-        dd_u32x4 &res_cur = (slot & 1) ? res1 : res0;
-        dd_u32x4 &res_prev = (slot & 1) ? res0 : res1;
-        res_load(t, res_cur);
+        // Vector-memory operations per thread and tile, in issue order: [ND DMA of tile t + 3] [store of tile t - 1] [residual chunk
+        // of tile t].  One counted wait, behind this tile's DMA: everything older than them is done -- tile t - 1's residual chunk
+        // and the x | g images of tiles t + 1 and t + 2 (the barrier at the end of the tile makes that true for every wave).
 #ifdef DD_EXPERIMENT
         if (a.debug == 2) { for (int i_ = 0; i_ < ND; ++i_) dd_dma(a.X, a.ldx, 0, 0, 0, lds0, wave, lane); } else
 #endif
         fetch(t + 3, (slot + 3) % DD_RING);             // that stage held tile t - 1: every wave is past it (the barrier below)
-        if (k > 0) {
-            // the dX rows of tile t - 1 leave now.  Its residual chunk was requested at the top of tile t - 1; issued since:
-            // tile t + 2's DMA, the store of tile t - 2 (if there was one), this tile's chunk and DMA
-            if (a.Res) {
-                const int n = 2 * ND + 1 + (k >= 2 ? 1 : 0);
-                DD_WAIT_VM(n);
-                asm volatile("" : "+v"(res_prev));      // (no use of the chunk above the wait)
-            }
-            store_rows(t - 1, sOut + ((slot + 1) & 1) * (DD_TOK * DD_OSTR), res_prev);
+        if (t > t0) {
+            if (ND == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (ND == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            store_rows(t - 1, sOut + ((slot + 1) & 1) * (DD_TOK * DD_OSTR));      // the dX rows of tile t - 1 leave now
         }
+        res_load(t);
         DSTAMP(0);
         // ---- dW += X^T G: two 16-token steps ----
 #ifdef DD_EXPERIMENT
@@ -295,11 +252,11 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
             for (int j = 0; j < 4; ++j) w[j] = (bf16_t)ax[mi][j];
             *reinterpret_cast<dd_bf16x4 *>(so + (16 * mi + li) * DD_OSTR + (16 * wave + 4 * g) * 2) = w;
         }
-        // tile t + 1 must have landed before the next tile reads it.  Issued after its DMA (top of tile t - 2): the DMA of tiles
-        // t + 2 and t + 3, the stores of tiles t - 3 .. t - 1 and the residual chunks of tiles t - 1 and t, as far as they exist
+        // tile t + 1 must have landed before the next tile reads it: the wait at the top of this tile saw to that, except in the
+        // workgroup's first tile -- issued after tile t0 + 1's DMA: the DMA of tiles t0 + 2 and t0 + 3 and this tile's residual chunk
         DSTAMP(3);
-        {
-            const int n = 2 * ND + k + (a.Res ? (k >= 1 ? 2 : 1) : 0);
+        if (t == t0) {
+            const int n = 2 * ND + (a.Res ? 1 : 0);
             DD_WAIT_VM(n);
         }
         DSTAMP(4);
@@ -312,14 +269,8 @@ __global__ void __launch_bounds__(512, 1) gemm_dxdw_kernel(DxDwArgs a) {
         if (t + 2 < t1) tile(std::integral_constant<int, 2>{}, t + 2);
         if (t + 3 < t1) tile(std::integral_constant<int, 3>{}, t + 3);
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(res0), "+v"(res1));    // the last residual chunk; requests past the last tile (zero rows, still LDS writes)
-    {
-        const bool odd = ((t1 - 1 - t0) & 1) != 0;
-        dd_u32x4 res_last;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) res_last[k] = odd ? res1[k] : res0[k];
-        store_rows(t1 - 1, sOut + (odd ? DD_TOK * DD_OSTR : 0), res_last);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the last residual chunk; requests past the last tile (zero rows, still LDS writes)
+    store_rows(t1 - 1, sOut + (((t1 - 1 - t0) & 1) != 0 ? DD_TOK * DD_OSTR : 0));
 #undef DD_WAIT_VM
 #ifdef DD_STAMPS
     if (lane == 0) for (int k = 0; k < 8; ++k) g_dd_stamps[(blockIdx.x * 8 + wave) * 8 + k] = st_[k];
@@ -400,7 +351,7 @@ static int dxdw_launch(DxDwArgs a, DxDwOut out, hipStream_t st) {
     int64_t per;
     const int grid = dxdw_grid(a.M, &per);
     a.tiles_per_wg = per;
-    const size_t lds = DD_RING * (size_t)(1 + NG) * DD_SUB + 2 * DD_TOK * DD_OSTR;
+    const size_t lds = DD_RING * (size_t)(1 + NG) * DD_SUB + 2 * DD_TOK * DD_OSTR + 8192;
     static thread_local bool done = false;
     if (!done) { (void)hipFuncSetAttribute((const void *)gemm_dxdw_kernel<NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
     gemm_dxdw_kernel<NG><<<grid, 512, lds, st>>>(a);
@@ -418,6 +369,7 @@ extern "C" int b4c_gemm_dxdw(const void *X, int ldx, const void *G, int ldg, con
                 ((((uintptr_t)X | (uintptr_t)G | (uintptr_t)Wc | (uintptr_t)dX | (uintptr_t)residual | (uintptr_t)workspace) & 15) == 0),
                 "gemm_dxdw: operands must be 16-byte aligned with pitches % 8 == 0");
     B4C_REQUIRE(workspace_bytes >= b4c_gemm_dxdw_workspace_bytes(M, n_seg), "gemm_dxdw: workspace too small");
+    B4C_REQUIRE(!residual || M * (int64_t)ldr * 2 < ((int64_t)1 << 32), "gemm_dxdw: residual of %lld rows x %d (its chunks are addressed with 32-bit byte offsets)", (long long)M, ldr);
     DxDwArgs a = {};
     a.X = (const bf16_t *)X; a.G = (const bf16_t *)G; a.Wc = (const bf16_t *)Wc; a.Res = (const bf16_t *)residual; a.dX = (bf16_t *)dX;
     a.part = (float *)workspace;

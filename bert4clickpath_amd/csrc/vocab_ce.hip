@@ -120,7 +120,8 @@ template <int KD> struct VTile {
         const int c = wave * 64 + lane + i * NT, row = c / CH, slot = c % CH;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((wave * 64 + i * NT) << 4));
         const unsigned voff = (unsigned)((row * ld + ((slot ^ swz(row)) << 3)) * 2);
-        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(voff), "s"(rs) : "m0");
+        // (s_nop 0: one wait state between a SALU write of M0 and an LDS-DMA that reads it -- csrc/dxdw_common.h dd_dma)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(voff), "s"(rs) : "m0");
     }
     // per-lane offsets, relative to a row base that is a multiple of 16 rows:
     //   direct fragment (row r, k-step ks, half hf): 16 B

@@ -486,6 +486,33 @@ def gemm_dxdw(x, g, wc, dWs, dbs, residual=None):
     return dx
 
 
+# ---- the feed-forward block's whole backward in one pass (csrc/ffn_bwd.hip): LayerNorm + dropout backward, both Dense layers' dX,
+# dW and db.  B4C_FUSED_FFN_BWD=0 keeps the five kernels.
+fused_ffn_bwd = os.environ.get('B4C_FUSED_FFN_BWD', '1') != '0'
+
+
+def ffn_bwd_supported(x, h, z):
+    return x.dtype == torch.bfloat16 and h.dtype == torch.bfloat16 and z.dtype == torch.bfloat16 and x.shape[1] == 128 and \
+        h.shape[1] <= 128 and h.shape[1] % 8 == 0 and x.stride(0) % 8 == 0 and h.stride(0) % 8 == 0 and z.is_contiguous() and \
+        x.shape[0] >= 4096
+
+
+def ffn_bwd(dout, z, stats, gamma, rate, seed, h, x, wc2, wc1, F, dW1, db1, dW2, db2, dgamma, dbeta):
+    """dX of the feed-forward block; dW1 / db1 / dW2 / db2 / dgamma / dbeta += (b4c_ffn_bwd).  wc2 [Fp][>= 128], wc1 [128][>= Fp]:
+    the dX operands of gemm_nt for the second / first Dense layer."""
+    M, Fp = x.shape[0], h.shape[1]
+    dx = torch.empty(M, 128, dtype=x.dtype, device=x.device)
+    ws = _workspace('ffn_bwd', x.device, L.lib().b4c_ffn_bwd_workspace_bytes(M))
+    es = 2
+    with _record('ffn_bwd' if 2 * M >= rec_hints.get('token_rows', 0) else 'ffn_bwd_rows', M * ((4 * 128 + Fp) * es + 8),
+                 8 * M * 128 * Fp):
+        L.check(L.lib().b4c_ffn_bwd(_p(dout), _p(z), _p(stats), _p(gamma), rate, seed, _p(h), h.stride(0), _p(x), x.stride(0),
+                                    _p(wc2), wc2.stride(0), _p(wc1), wc1.stride(0), F, Fp, _p(dx), dx.stride(0),
+                                    _p(dW1), dW1.stride(0), _p(db1), _p(dW2), dW2.stride(0), _p(db2), _p(dgamma), _p(dbeta),
+                                    M, ws.data_ptr(), ws.numel(), _st()), 'ffn_bwd')
+    return dx
+
+
 # ---- grouped weight gradients: the dW GEMMs of an encoder layer are off the critical path (nothing in backward
 # consumes them), so in arena mode they are queued and launched together (b4c_gemm_tn_group: one main + one reduce
 # kernel per layer instead of four of each, and ~6x less partial-tile traffic).
@@ -554,6 +581,9 @@ class ArenaContext:
         self.kicks = 0                # attention-backward launches seen in this pass
         self.kicks_expected = 0       # ... in the previous backward pass: the plan of the next one
         self.side_launched = None     # device whose side stream has been given work since the last join (None: nothing in flight)
+        # the model's feed-forward blocks take the fused backward (FFNBlockFn.forward sets it; the head's backward then runs its dW
+        # sweep in the foreground: _background_dw_for)
+        self.fused_blocks = False
 
     def reset(self):
         """Drop what a failed step left behind: queued weight-gradient GEMMs and side-stream closures hold that step's tensors
@@ -1448,6 +1478,10 @@ class FFNBlockFn(torch.autograd.Function):
             ctx.pk = (pk1, pk2)
             ctx.dims = (rate, seed)
             ctx.params = (w1, b1, w2, b2, gamma, beta)
+            if fused_ffn_bwd and ffn_bwd_supported(x, h, z):
+                actx = arena_context(w1, b1, w2, b2, gamma, beta)
+                if actx is not None:
+                    actx.fused_blocks = True        # (the head's backward reads it: _background_dw_for)
         return out
 
     @staticmethod
@@ -1459,10 +1493,15 @@ class FFNBlockFn(torch.autograd.Function):
         d, Fp = x.shape[1], h.shape[1]
         actx = arena_context(*ctx.params)
         inplace = actx is not None
-        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
-                                                          into=(gam.grad, bet.grad) if inplace else None)
         _, wc1, _ = pk1.get(x.dtype, d, True)
         _, wc2, _ = pk2.get(x.dtype, Fp, True)
+        if inplace and fused_ffn_bwd and ffn_bwd_supported(x, h, z):
+            dx = ffn_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed, h, x, wc2, wc1, pk1.N, w1.grad, b1.grad,
+                         w2.grad, b2.grad, gam.grad, bet.grad)
+            _ready(w1, b1, w2, b2, gam, bet)
+            return (dx,) + (None,) * 11
+        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
+                                                          into=(gam.grad, bet.grad) if inplace else None)
         if inplace:
             queue_dw(actx, h, dy, pk2.K, d, [w2.grad], [b2.grad], (w2, b2))
         else:
@@ -1549,8 +1588,26 @@ class MLPFn(torch.autograd.Function):
 # cannot start on a CU that holds a sweep workgroup.  A piece is launched on the side stream right after every attention
 # backward launch (ops.attn_bwd -> _background_kick); how many such launches a backward pass has is learned from the
 # previous pass.  The main stream joins, and the gradient is announced to a reducer, when backward ends (join_side_work).
-# B4C_OVERLAP_DW=0 switches it off (the sweep then runs in the foreground, first thing in backward).
-overlap_vocab_dw = os.environ.get('B4C_OVERLAP_DW', '1') == '1'
+# B4C_OVERLAP_DW=0 switches it off (the sweep then runs in the foreground, first thing in backward), =1 forces it on.
+# Unset (None): decided per model.  The fused backward kernels of the d_model = 128 encoder (b4c_ffn_bwd, b4c_gemm_dxdw) hold a
+# whole CU like the resident attention backward -- 97 - 145 KB of LDS, 2 x 255 registers per SIMD lane -- so a background sweep
+# finds no CU to share and the two only block each other (C2, interleaved on one box: fused + foreground 8.92 - 9.00 ms, five
+# kernels + background 9.02 - 9.04, fused + background 9.18 - 9.25, five kernels + foreground 9.59).  A model whose feed-forward
+# blocks take the fused backward runs the sweep in the foreground; every other model keeps the background form.
+overlap_vocab_dw = {'1': True, '0': False}.get(os.environ.get('B4C_OVERLAP_DW', ''), None)
+
+
+def background_dw_expected(d_model, dff, dtype):
+    """Will a model of this shape run the vocabulary head's dW sweep as a background job (see overlap_vocab_dw)?"""
+    if overlap_vocab_dw is not None:
+        return overlap_vocab_dw
+    return not (fused_ffn_bwd and d_model == 128 and dff <= 128 and dtype == torch.bfloat16)
+
+
+def _background_dw_for(actx):
+    if overlap_vocab_dw is not None:
+        return overlap_vocab_dw
+    return not getattr(actx, 'fused_blocks', False)
 background_workgroups = int(os.environ.get('B4C_VCE_DW_BG', '0'))      # 0: one per CU of the device
 # deterministic_vocab_dw: the projection's dW / db are summed in a fixed order (no float atomics: one workgroup per
 # vocabulary tile walks every token, the label term goes through a stable sort of the rows by label) -- two identical steps
@@ -1732,7 +1789,7 @@ class VocabCEFn(torch.autograd.Function):
             return dh, None, None, None, None, None, dtab, db, None
         actx = arena_context(kernel, bias)
         if actx is not None:
-            if overlap_vocab_dw and h.is_cuda:
+            if h.is_cuda and _background_dw_for(actx):
                 _queue_background_dw(actx, h, wt, b, labels_i32, rowscal, ctx.V, kernel, bias)
             else:
                 vocab_ce_dw(h, wt, b, labels_i32, rowscal, ctx.V, kernel.grad, bias.grad)

@@ -162,6 +162,23 @@ int b4c_gemm_dxdw(const void *X, int ldx, const void *G, int ldg, const void *Wc
                   void *dX, int ldo, int n_seg, float *const *h_dW, float *const *h_db, int ld_dw, int64_t M,
                   void *workspace, int64_t workspace_bytes, void *stream);
 
+/* (ABI 10) the whole backward of the position-wise feed-forward block of one encoder layer (transformer.py:154-170 seen from the
+ * backward pass: LayerNormalization, dropout, residual add, Dense(d_model), Dense(dff, relu)) in ONE pass:
+ *   dz, dy   = LayerNorm / dropout backward of dout (as b4c_add_dropout_layernorm_bwd: z [M][128] the saved LayerNorm input,
+ *              stats [M][2], gamma [128]; dropout_rate / seed of the forward pass's mask)          -- never written to HBM
+ *   dW2 += H^T dy,  db2 += colsum(dy),  dh = (dy W2c^T) o [H > 0]                                  -- dh never written to HBM
+ *   dW1 += X^T dh,  db1 += colsum(dh),  dX = dh W1c^T + dz,   dgamma / dbeta += the LayerNorm's parameter gradients
+ * H [M][ldh] = relu(X W1 + b1) with Fp stored columns (F valid, Fp = F rounded up to 8, <= 128), X [M][ldx] (128 columns),
+ * W2c [Fp][ldw2] (row = hidden column, 128 entries) and W1c [128][ldw1] (row = input feature, Fp entries): the dX operands of
+ * b4c_gemm_nt for the two layers.  dW1 fp32 [128][ld_dw1], dW2 fp32 [F][ld_dw2] (Keras layouts), db1 [F] / db2 [128] or NULL.
+ * bf16, d_model = 128 only.  Reads dout, z, H, X once and writes dX: 1,240 B per token against 3,340 for the five kernels it
+ * replaces.  Deterministic (no float atomics: per-workgroup partial sums meet in a fixed order through the caller's scratch). */
+int64_t b4c_ffn_bwd_workspace_bytes(int64_t M);
+int b4c_ffn_bwd(const void *dout, const void *z, const float *stats, const float *gamma, float dropout_rate, uint64_t seed,
+                const void *H, int ldh, const void *X, int ldx, const void *W2c, int ldw2, const void *W1c, int ldw1,
+                int F, int Fp, void *dX, int ldo, float *dW1, int ld_dw1, float *db1, float *dW2, int ld_dw2, float *db2,
+                float *dgamma, float *dbeta, int64_t M, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* several dW problems over the SAME M tokens in one launch (bf16; the four weight gradients of an encoder layer):
  * the ~256 workgroups of the split are shared by all problems, so every output tile has ~256 / (total tiles)
  * partial sums, and the group needs one main + one reduce kernel.  Problem i: dW_i[K][n_seg * seg_width] split into

@@ -206,15 +206,21 @@ def test_a_failed_backward_leaves_nothing_for_the_next_step(monkeypatch):
         ops.background_workgroups = prev
 
 
-def test_a_failed_backward_leaves_no_queued_weight_gradient(monkeypatch):
-    """The grouped weight-gradient queue (ops.queue_dw: the dW GEMMs of a layer wait for one launch) belongs to the arena's
+@pytest.mark.parametrize('route', ['queued', 'fused'])
+def test_a_failed_backward_leaves_no_queued_weight_gradient(monkeypatch, route):
+    """route 'queued': the five-kernel feed-forward backward, projections as b4c_gemm_nt + queued b4c_gemm_tn, background sweep
+    (what every model outside d_model = 128 / dff <= 128 / bf16 runs); 'fused': this model's defaults (b4c_ffn_bwd, b4c_gemm_dxdw,
+    foreground sweep: nothing is queued, the step after the failure must still be an undisturbed one).
+    The grouped weight-gradient queue (ops.queue_dw: the dW GEMMs of a layer wait for one launch) belongs to the arena's
     context: a backward pass that raises between FFNBlockFn.backward (queues two problems) and the flush at the end of the
     attention block's backward leaves entries that hold the failed step's tensors; the next zero_grad() drops them.  The batch has
     >= 4,096 token rows (below that queue_dw launches at once and there is nothing to leave behind).  The gradients of the
     step after the failure are those of an undisturbed run -- bit for bit where the summation order is fixed."""
     from bert4clickpath_amd import input_pipeline, ops
-    prev = ops.background_workgroups
+    prev = (ops.background_workgroups, ops.fused_ffn_bwd, ops.fused_dxdw, ops.overlap_vocab_dw)
     ops.background_workgroups = 8
+    if route == 'queued':
+        ops.fused_ffn_bwd, ops.fused_dxdw, ops.overlap_vocab_dw = False, 0, True
     try:
         def big(seed):
             b = input_pipeline.synthetic_cloze_batch(256, S, V, seed=seed, min_len=20)
@@ -251,8 +257,11 @@ def test_a_failed_backward_leaves_no_queued_weight_gradient(monkeypatch):
             loss.backward()
         ctx = t.opt.arena.ctx
         queued = len(ctx.pending_dw)
-        assert queued >= 2, 'the injected failure found no queued weight gradient: the test checks nothing (%d)' % queued
-        assert ctx.side_launched is not None          # the first piece of the background sweep is on the side stream already
+        if route == 'queued':
+            assert queued >= 2, 'the injected failure found no queued weight gradient: the test checks nothing (%d)' % queued
+            assert ctx.side_launched is not None      # the first piece of the background sweep is on the side stream already
+        else:
+            assert queued == 0 and ctx.fused_blocks and ctx.side_launched is None
         monkeypatch.setattr(ops, 'attn_bwd', real)
         got_loss, got = grads_of(t, batches[1])       # zero_grad() -> ctx.reset()
         assert not ctx.pending_dw and not ctx.queue and not ctx.pending and ctx.side_launched is None
@@ -263,4 +272,4 @@ def test_a_failed_backward_leaves_no_queued_weight_gradient(monkeypatch):
                     assert torch.equal(got[n], g), n
             assert float((got[n] - g).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-9, n
     finally:
-        ops.background_workgroups = prev
+        ops.background_workgroups, ops.fused_ffn_bwd, ops.fused_dxdw, ops.overlap_vocab_dw = prev

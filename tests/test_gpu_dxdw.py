@@ -100,8 +100,26 @@ def test_the_model_step_with_the_fused_backward_matches_the_default_step():
             assert len(calls) == (5 if flag else 0), calls
     finally:
         ops.fused_dxdw, ops.gemm_dxdw = prev, real
-    assert out[3][0] == out[0][0]                        # (the forward pass is the same code)
+    assert out[3][0] == out[0][0]
+    floor = 1e-6 * max(float(g.abs().max()) for g in out[0][1].values())           # (the key bias's gradient is rounding noise around 0)                        # (the forward pass is the same code)
     for n, gd in out[0][1].items():
         gf = out[3][1][n]
-        assert float((gf - gd).abs().max()) <= 2e-2 * float(gd.abs().max()) + 1e-9, n
-        assert float((gf - gd).norm()) <= 5e-3 * float(gd.norm()) + 1e-9, n
+        assert float((gf - gd).abs().max()) <= 2e-2 * float(gd.abs().max()) + floor, n
+        assert float((gf - gd).norm()) <= 5e-3 * float(gd.norm()) + floor * gd.numel() ** 0.5, n
+
+
+def test_many_launches_at_the_full_token_count_are_exact():
+    """as tests/test_gpu_ffn_bwd.py::test_many_launches...: 25 launches of the three-block form at 456 k rows on integer data, every
+    one exact (a race in the counted-wait pipeline shows on some launches only)"""
+    from bert4clickpath_amd import ops
+    M, n_seg = 456123, 3
+    x, G, W, res = _case(M, n_seg, seed=77)
+    ref_dx = ops.gemm_nt(G, W, 128, residual=res)
+    exact_dw = x.double().T @ G.double()
+    for rep in range(25):
+        dWs = [torch.zeros(128, 128, device='cuda') for _ in range(n_seg)]
+        dbs = [torch.zeros(128, device='cuda') for _ in range(n_seg)]
+        dx = ops.gemm_dxdw(x, G, W, dWs, dbs, residual=res)
+        wrong = (dx != ref_dx).any(1).nonzero().reshape(-1)
+        assert wrong.numel() == 0, (rep, wrong.numel(), wrong[:8].tolist())
+        assert torch.equal(torch.cat(dWs, 1).double(), exact_dw), rep

@@ -147,7 +147,7 @@ def _bench_worker(rank, world, port, out_dir, dropout):
     tr = bench.Training(a, rank, world, torch.device('cuda', rank if multi else 0))
     # what bench.py runs at N > 1: bf16, padding-free layout, arena in backward order, the projection's dW as a background
     # sweep announced when backward ends, its gradient in the LAST bucket, hook-overlapped reducer
-    assert tr.model.compute_dtype == torch.bfloat16 and ops.overlap_vocab_dw and ops.flash_ce and ops.mq_last_layer
+    assert tr.model.compute_dtype == torch.bfloat16 and ops.overlap_vocab_dw is not False and ops.flash_ce and ops.mq_last_layer
     assert tr.reducer.overlap and len(tr.reducer.buckets) == 3
     proj = tr.model.head.output_layer.kernel
     assert tr.opt.arena.slice_of(proj)[0] >= tr.reducer.buckets[2][0], 'the projection belongs to the last bucket'
