@@ -491,10 +491,15 @@ def gemm_dxdw(x, g, wc, dWs, dbs, residual=None):
 fused_ffn_bwd = os.environ.get('B4C_FUSED_FFN_BWD', '1') != '0'
 
 
-def ffn_bwd_supported(x, h, z):
+def ffn_bwd_shape_ok(x, h, z):
+    """the model shapes b4c_ffn_bwd takes: bf16, d_model = 128, dff <= 128 (padded to 8)"""
     return x.dtype == torch.bfloat16 and h.dtype == torch.bfloat16 and z.dtype == torch.bfloat16 and x.shape[1] == 128 and \
-        h.shape[1] <= 128 and h.shape[1] % 8 == 0 and x.stride(0) % 8 == 0 and h.stride(0) % 8 == 0 and z.is_contiguous() and \
-        x.shape[0] >= 4096
+        h.shape[1] <= 128 and h.shape[1] % 8 == 0 and x.stride(0) % 8 == 0 and h.stride(0) % 8 == 0 and z.is_contiguous()
+
+
+def ffn_bwd_supported(x, h, z):
+    """... and enough rows for a persistent kernel (below 4,096 the five kernels are launched)"""
+    return ffn_bwd_shape_ok(x, h, z) and x.shape[0] >= 4096
 
 
 def ffn_bwd(dout, z, stats, gamma, rate, seed, h, x, wc2, wc1, F, dW1, db1, dW2, db2, dgamma, dbeta):
@@ -1478,10 +1483,13 @@ class FFNBlockFn(torch.autograd.Function):
             ctx.pk = (pk1, pk2)
             ctx.dims = (rate, seed)
             ctx.params = (w1, b1, w2, b2, gamma, beta)
-            if fused_ffn_bwd and ffn_bwd_supported(x, h, z):
+            # A model of the fused kernels' shape runs the head's dW sweep in the foreground (_background_dw_for) -- decided by the
+            # SHAPE, whatever the batch's row count, so that it agrees with background_dw_expected(), by which callers order their
+            # gradient arenas (a background sweep's gradient completes last and belongs to the reducer's last bucket)
+            if fused_ffn_bwd and ffn_bwd_shape_ok(x, h, z):
                 actx = arena_context(w1, b1, w2, b2, gamma, beta)
                 if actx is not None:
-                    actx.fused_blocks = True        # (the head's backward reads it: _background_dw_for)
+                    actx.fused_blocks = True
         return out
 
     @staticmethod

@@ -64,7 +64,9 @@ def _rows_scatter_add(table_grad, idx, rows):
 class GradReducer:
     def __init__(self, arena, bucket_bounds=None, reduce='sum', group=None, overlap=True, sparse_params=(),
                  sparse_max_fill=0.2):
-        """bucket_bounds: increasing element offsets into the arena (default: one bucket).
+        """bucket_bounds: increasing element offsets into the arena (default: one bucket).  The arena is expected in the order
+        gradients COMPLETE in backward; a gradient that completes when backward ends -- the vocabulary projection's, when its dW
+        sweep runs as a background job (ops.background_dw_expected) -- belongs to the LAST bucket (bench.backward_order).
         sparse_params: 2-D (rows, width) parameters whose gradient is row-sparse (embedding tables; SURVEY 8e / H4:
         a dense all-reduce of a 2M-row table is 2 GB per step).  They must be the LAST parameters of the arena.  Each
         step, tell the reducer which rows this rank touched with set_touched_rows(param, ids) before finish(); the

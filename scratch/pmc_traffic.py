@@ -20,6 +20,8 @@ GROUPS = [
     (('gemm_nt_ln', 'gemm_nt_ln_rows'), ('gemm_nt_ln_kernel', 'gemm_nt_ln256_kernel'), None),
     (('gemm_tn', 'gemm_tn_rows'), ('gemm_tn_', 'tn_reduce_kernel'), 'gemm_tn_'),
     (('add_ln_bwd', 'add_ln_bwd_rows'), ('add_ln_bwd_kernel', 'ln_bwd_reduce_kernel'), 'add_ln_bwd_kernel'),
+    (('gemm_dxdw',), ('gemm_dxdw_kernel', 'dxdw_reduce_kernel'), 'gemm_dxdw_kernel'),
+    (('ffn_bwd', 'ffn_bwd_rows'), ('ffn_bwd_kernel', 'ffn_bwd_reduce_kernel'), 'ffn_bwd_kernel'),
     (('add_ln_fwd',), ('add_ln_fwd',), None),
     (('attn_mq_fwd',), ('attn_mq_fwd',), None), (('attn_mq_bwd',), ('attn_mq_bwd',), None),
     (('attn_bwd',), ('attn_bwd',), None), (('attn_fwd',), ('attn_fwd',), None),

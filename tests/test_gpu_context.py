@@ -12,6 +12,18 @@ pytestmark = pytest.mark.gpu
 V, B, S = 3000, 48, 40
 
 
+@pytest.fixture(autouse=True)
+def _background_sweep():
+    """These tests are about the per-arena state of the vocabulary head's BACKGROUND dW sweep.  A bf16 model of d_model 128 and
+    dff <= 128 -- the test models -- would run the sweep in the foreground by default (ops.overlap_vocab_dw = None: its fused
+    backward kernels leave a background sweep nothing to share); the background form is what every other shape runs."""
+    from bert4clickpath_amd import ops
+    prev = ops.overlap_vocab_dw
+    ops.overlap_vocab_dw = True
+    yield
+    ops.overlap_vocab_dw = prev
+
+
 def _model(seed, layers):
     from bert4clickpath_amd.clickstream_transformer import ClickstreamTransformer, SoftMaxHead
     torch.manual_seed(seed)
@@ -221,6 +233,8 @@ def test_a_failed_backward_leaves_no_queued_weight_gradient(monkeypatch, route):
     ops.background_workgroups = 8
     if route == 'queued':
         ops.fused_ffn_bwd, ops.fused_dxdw, ops.overlap_vocab_dw = False, 0, True
+    else:
+        ops.overlap_vocab_dw = None
     try:
         def big(seed):
             b = input_pipeline.synthetic_cloze_batch(256, S, V, seed=seed, min_len=20)
