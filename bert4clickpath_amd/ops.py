@@ -518,6 +518,30 @@ def ffn_bwd(dout, z, stats, gamma, rate, seed, h, x, wc2, wc1, F, dW1, db1, dW2,
     return dx
 
 
+# ---- the attention block's tail in one pass (csrc/attn_out_bwd.hip): LayerNorm + dropout backward and the output projection's dX /
+# dW / db.  B4C_FUSED_ATTN_OUT_BWD=0 keeps add_ln_bwd + the projection's own kernels.
+fused_attn_out_bwd = os.environ.get('B4C_FUSED_ATTN_OUT_BWD', '1') != '0'
+
+
+def attn_out_bwd_supported(o, z):
+    return o.dtype == torch.bfloat16 and z.dtype == torch.bfloat16 and o.shape[1] == 128 and z.shape[1] == 128 and \
+        o.stride(0) % 8 == 0 and z.is_contiguous() and o.shape[0] >= 4096
+
+
+def attn_out_bwd(dout, z, stats, gamma, rate, seed, o, wc, dW, db, dgamma, dbeta):
+    """-> dz [M, 128] (residual branch), d_o [M, 128];  dW / db / dgamma / dbeta += (b4c_attn_out_bwd).  wc [128][>= 128]: the dX
+    operand of gemm_nt for the output projection."""
+    M = o.shape[0]
+    dz = torch.empty(M, 128, dtype=o.dtype, device=o.device)
+    d_o = torch.empty(M, 128, dtype=o.dtype, device=o.device)
+    ws = _workspace('attn_out_bwd', o.device, L.lib().b4c_attn_out_bwd_workspace_bytes(M))
+    with _record('attn_out_bwd' if 2 * M >= rec_hints.get('token_rows', 0) else 'attn_out_bwd_rows', M * (5 * 128 * 2 + 8), 4 * M * 128 * 128):
+        L.check(L.lib().b4c_attn_out_bwd(_p(dout), _p(z), _p(stats), _p(gamma), rate, seed, _p(o), o.stride(0), _p(wc), wc.stride(0),
+                                         _p(dz), _p(d_o), d_o.stride(0), _p(dW), dW.stride(0), _p(db), _p(dgamma), _p(dbeta),
+                                         M, ws.data_ptr(), ws.numel(), _st()), 'attn_out_bwd')
+    return dz, d_o
+
+
 # ---- grouped weight gradients: the dW GEMMs of an encoder layer are off the critical path (nothing in backward
 # consumes them), so in arena mode they are queued and launched together (b4c_gemm_tn_group: one main + one reduce
 # kernel per layer instead of four of each, and ~6x less partial-tile traffic).
@@ -1337,19 +1361,23 @@ class AttnBlockFn(torch.autograd.Function):
         d = H * dh
         actx = arena_context(*ctx.params)
         inplace = actx is not None
-        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
-                                                          into=(gam.grad, bet.grad) if inplace else None)
         _, wc_o, _ = pk_o.get(x.dtype, d, True)
         _, wc_qkv, _ = pk_qkv.get(x.dtype, d, True)
-        if inplace and fused_dxdw >= 3 and dxdw_supported(o, dy, 1):
-            d_o = gemm_dxdw(o, dy, wc_o, [wo.grad], [bo.grad])
+        if inplace and fused_attn_out_bwd and attn_out_bwd_supported(o, z):
+            dz, d_o = attn_out_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed, o, wc_o, wo.grad, bo.grad, gam.grad, bet.grad)
             _ready(wo, bo)
         else:
-            if inplace:
-                queue_dw(actx, o, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
+            dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
+                                                              into=(gam.grad, bet.grad) if inplace else None)
+            if inplace and fused_dxdw >= 3 and dxdw_supported(o, dy, 1):
+                d_o = gemm_dxdw(o, dy, wc_o, [wo.grad], [bo.grad])
+                _ready(wo, bo)
             else:
-                dWo, dbo = gemm_tn(o, dy, d, d)
-            d_o = gemm_nt(dy, wc_o, d)
+                if inplace:
+                    queue_dw(actx, o, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
+                else:
+                    dWo, dbo = gemm_tn(o, dy, d, d)
+                d_o = gemm_nt(dy, wc_o, d)
         with _timed('attn_bwd'):
             dqkv = attn_bwd(qkv, key_pad, o, d_o, lse, B, S, H, dh, ctx.cu, actx)
         if inplace and fused_dxdw and dxdw_supported(x, dqkv, 3):
@@ -1425,15 +1453,19 @@ class MQAttnBlockFn(torch.autograd.Function):
         d = H * dh
         actx = arena_context(*ctx.params)
         inplace = actx is not None
-        dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
-                                                          into=(gam.grad, bet.grad) if inplace else None)
         _, wc_o, _ = pk_o.get(x.dtype, d, True)
         _, wc_qkv, _ = pk_qkv.get(x.dtype, d, True)
-        if inplace:
-            queue_dw(actx, o_m, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
+        if inplace and fused_attn_out_bwd and attn_out_bwd_supported(o_m, z):
+            dz, d_o = attn_out_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed, o_m, wc_o, wo.grad, bo.grad, gam.grad, bet.grad)
+            _ready(wo, bo)
         else:
-            dWo, dbo = gemm_tn(o_m, dy, d, d)
-        d_o = gemm_nt(dy, wc_o, d)
+            dz, dy, dgamma, dbeta = add_dropout_layernorm_bwd(dout.contiguous(), z, stats, gamma.detach(), rate, seed,
+                                                              into=(gam.grad, bet.grad) if inplace else None)
+            if inplace:
+                queue_dw(actx, o_m, dy, d, d, [wo.grad], [bo.grad], (wo, bo))
+            else:
+                dWo, dbo = gemm_tn(o_m, dy, d, d)
+            d_o = gemm_nt(dy, wc_o, d)
         dq, dkv = attn_mq_bwd(q_m, kv, cu, moff, o_m, d_o, lse, B, max_len, H, dh, key_pad)
         if inplace:
             queue_dw(actx, x_m, dq, d, d, [wq.grad], [bq.grad], (wq, bq))

@@ -179,6 +179,20 @@ int b4c_ffn_bwd(const void *dout, const void *z, const float *stats, const float
                 int F, int Fp, void *dX, int ldo, float *dW1, int ld_dw1, float *db1, float *dW2, int ld_dw2, float *db2,
                 float *dgamma, float *dbeta, int64_t M, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* (ABI 11) the backward of the attention block's tail (transformer.py:158-162, 204-207 seen from the backward pass: LayerNormalization,
+ * dropout, residual add, the output projection Dense(d_model)) in ONE pass:
+ *   dz, dy = LayerNorm / dropout backward of dout (z, stats, gamma, dropout_rate, seed as b4c_add_dropout_layernorm_bwd);
+ *   dZ [M][128] = dz (the residual branch's gradient: the caller adds it to the block input's gradient);   dy never reaches HBM;
+ *   dO [M][ld_do] = dy Wc^T,   dW += O^T dy,   db += colsum(dy),   dgamma / dbeta += the LayerNorm's parameter gradients.
+ * O [M][ldo_in] the projection's input (128 columns), Wc [128][ldw] (row = input feature of the projection: the dX operand of
+ * b4c_gemm_nt), dW fp32 [128][ld_dw] Keras layout, db fp32 [128] or NULL.  bf16, d_model = 128 only.  1,288 B per token against 1,800 for
+ * b4c_add_dropout_layernorm_bwd + b4c_gemm_dxdw.  Deterministic (fixed-order reduction through the caller's scratch). */
+int64_t b4c_attn_out_bwd_workspace_bytes(int64_t M);
+int b4c_attn_out_bwd(const void *dout, const void *z, const float *stats, const float *gamma, float dropout_rate, uint64_t seed,
+                     const void *O, int ldo_in, const void *Wc, int ldw, void *dZ, void *dO, int ld_do,
+                     float *dW, int ld_dw, float *db, float *dgamma, float *dbeta, int64_t M,
+                     void *workspace, int64_t workspace_bytes, void *stream);
+
 /* several dW problems over the SAME M tokens in one launch (bf16; the four weight gradients of an encoder layer):
  * the ~256 workgroups of the split are shared by all problems, so every output tile has ~256 / (total tiles)
  * partial sums, and the group needs one main + one reduce kernel.  Problem i: dW_i[K][n_seg * seg_width] split into

@@ -6,7 +6,7 @@ from bert4clickpath_amd import ops
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 456000
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 Fp = (F + 7) // 8 * 8
-rate, seed = 0.1, 77
+rate, seed = (float(sys.argv[3]) if len(sys.argv) > 3 else 0.1), 77
 dev = 'cuda'
 dout = (torch.randn(M, 128, device=dev) * 0.05).bfloat16(); z = torch.randn(M, 128, device=dev).bfloat16()
 zf = z.float(); stats = torch.stack([zf.mean(1), 1.0 / torch.sqrt(zf.var(1, unbiased=False) + 1e-6)], 1).contiguous()

@@ -77,7 +77,8 @@ def test_the_model_step_with_the_fused_backward_matches_the_default_step():
     items, labels, n_real = (torch.from_numpy(b['ids'])[:, 2:S - 1].contiguous().cuda(), torch.from_numpy(b['labels_padded']).cuda(),
                              int((b['ids'] != 0).sum()))
     assert n_real >= 4096
-    prev, out, calls = ops.fused_dxdw, {}, []
+    prev, out, calls = (ops.fused_dxdw, ops.fused_attn_out_bwd), {}, []
+    ops.fused_attn_out_bwd = False          # (the output projection through b4c_gemm_dxdw: what this test is about)
     real = ops.gemm_dxdw
 
     def counted(*a, **k):
@@ -99,7 +100,7 @@ def test_the_model_step_with_the_fused_backward_matches_the_default_step():
             # [MASK] rows only, MQAttnBlockFn), none when switched off
             assert len(calls) == (5 if flag else 0), calls
     finally:
-        ops.fused_dxdw, ops.gemm_dxdw = prev, real
+        (ops.fused_dxdw, ops.fused_attn_out_bwd), ops.gemm_dxdw = prev, real
     assert out[3][0] == out[0][0]
     floor = 1e-6 * max(float(g.abs().max()) for g in out[0][1].values())           # (the key bias's gradient is rounding noise around 0)                        # (the forward pass is the same code)
     for n, gd in out[0][1].items():
