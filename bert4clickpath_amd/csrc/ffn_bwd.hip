@@ -166,6 +166,12 @@ __global__ void __launch_bounds__(512, 1) ffn_bwd_kernel(FfnBwdArgs a) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(ln_lds + 8192u), "v"(vo), "s"(ds_z) : "m0", "memory");
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(ln_lds + 16384u), "v"(vs), "s"(ds_st) : "m0", "memory");
     };
+    // the compiler's own loads (W fragments, gamma) are consumed HERE: its wait for them would otherwise sit at their first use inside
+    // the tile loop, where it counts none of the requests below and drains them every iteration
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { asm volatile("" : "+v"(w1f[ks])); asm volatile("" : "+v"(w2f[ks])); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(gm[k]));
     fetch(0, 0);
     fetch(1, 1);
     fetch(2, 2);
@@ -227,11 +233,12 @@ __global__ void __launch_bounds__(512, 1) ffn_bwd_kernel(FfnBwdArgs a) {
     // Vector-memory operations per thread in issue order: ... [3 row loads of t + 1] [2 DMA of t + 3] [1 store of t - 1] ...
     // The only counted wait: tile t's row loads at the top of iteration t -- issued since: 2 DMA + 1 store (none / no store in
     // the first iterations).  Everything older has landed with them: the h | x tiles t and t + 1.
-    auto tile = [&](auto SLOT, int64_t t) {
-        constexpr int slot = decltype(SLOT)::value;
+    auto tile = [&](auto ODD, int64_t t) {
+        constexpr bool odd_tile = decltype(ODD)::value;  // (dz of a tile waits in one of two register quadruples: the parity is compile time)
+        const int slot = (int)(t & 3);
         const bool body = t < t1;
-        dd_u32x4 &dz_cur = (slot & 1) ? dz1 : dz0;
-        dd_u32x4 &dz_prev = (slot & 1) ? dz0 : dz1;
+        dd_u32x4 &dz_cur = odd_tile ? dz1 : dz0;
+        dd_u32x4 &dz_prev = odd_tile ? dz0 : dz1;
         if (body) {
             if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (t == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -345,11 +352,9 @@ __global__ void __launch_bounds__(512, 1) ffn_bwd_kernel(FfnBwdArgs a) {
         }
         __syncthreads();
     };
-    for (int64_t t = 0; t <= t1; t += DD_RING) {
-        tile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 <= t1) tile(std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 <= t1) tile(std::integral_constant<int, 2>{}, t + 2);
-        if (t + 3 <= t1) tile(std::integral_constant<int, 3>{}, t + 3);
+    for (int64_t t = 0; t <= t1; t += 2) {
+        tile(std::false_type{}, t);
+        if (t + 1 <= t1) tile(std::true_type{}, t + 1);
     }
 
     // ---- this workgroup's partial sums ----
