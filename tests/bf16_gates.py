@@ -24,6 +24,7 @@ def grad_errors(named_params, ref_grads):
 class GateRecorder:
     def __init__(self, ops):
         self.ops, self.patterns = ops, []
+        self.rows_only_last = False       # the pass ran its last encoder layer at the [MASK] rows only (ops.MQAttnBlockFn)
 
     def __enter__(self):
         from bert4clickpath_amd import _lib as L
@@ -35,10 +36,22 @@ class GateRecorder:
                 self.patterns.append((out.detach() > 0).cpu())
             return out
         self.ops.gemm_nt = gemm_nt
+        # which form the last layer took cannot be read off its pattern's row count: B x max_masked_per_row rows of the masked-query
+        # form and T rows of a packed full layer can coincide (B = 4, S = 16, 40 real tokens, 10 masks per row: found by a drawn case)
+        self._orig_mq = self.ops.MQAttnBlockFn
+        rec = self
+
+        class Noting(self._orig_mq):
+            @staticmethod
+            def apply(*a, **k):
+                rec.rows_only_last = True
+                return rec._orig_mq.apply(*a, **k)
+        self.ops.MQAttnBlockFn = Noting
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm_nt = self._orig
+        self.ops.MQAttnBlockFn = self._orig_mq
 
     def relu_for(self, num_layers, n_head_layers, rows_flat, B, S, token_rows=None):
         """-> relu(name, z) for the oracle.  patterns: one per FFN in layer order ([B*S or T or R rows][F padded]), then one per head
@@ -60,10 +73,11 @@ class GateRecorder:
             if kind == 'ffn':
                 F = z.shape[-1]
                 flat = own.reshape(-1, F).clone()
-                if pat.shape[0] == flat.shape[0]:
+                rows_only = self.rows_only_last and int(i) == num_layers - 1
+                if not rows_only and pat.shape[0] == flat.shape[0]:
                     rows = None
                     flat = pat[:, :F]
-                elif token_rows is not None and pat.shape[0] == token_rows.shape[0]:
+                elif not rows_only and token_rows is not None and pat.shape[0] == token_rows.shape[0]:
                     rows = token_rows
                     flat[rows] = pat[:, :F]
                 else:                                   # rows-only pattern of the last layer
