@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('B4C_LIB_PATH') or os.path.join(_HERE, 'libb4c_hip.so')     # override: A/B of two builds (scratch)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'b4c.h')
 
-ABI_VERSION = 11      # include/b4c.h; b4c_abi_version() of the library must agree
+ABI_VERSION = 12      # include/b4c.h; b4c_abi_version() of the library must agree
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
 CE_TF, CE_PLAIN = 0, 1
@@ -78,6 +78,7 @@ def lib():
             'b4c_gemm_dxdw': (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, pp, pp, i32, i64, vp, i64, vp]),
             'b4c_ffn_bwd_workspace_bytes': (i64, [i64]),
             'b4c_ffn_bwd': (i32, [vp, vp, vp, vp, f32, u64, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, i64, vp, i64, vp]),
+            'b4c_ffn_fwd': (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, i64, f32, f32, u64, vp]),
             'b4c_attn_out_bwd_workspace_bytes': (i64, [i64]),
             'b4c_attn_out_bwd': (i32, [vp, vp, vp, vp, f32, u64, vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i64, vp, i64, vp]),
             'b4c_gemm_tn_group_workspace_bytes': (i64, [vp, i32, i32]),

@@ -24,7 +24,7 @@ int b4c_check_launch(const char *what) {
     return B4C_OK;
 }
 extern "C" const char *b4c_last_error(void) { return g_err; }
-extern "C" int b4c_abi_version(void) { return 11; }
+extern "C" int b4c_abi_version(void) { return 12; }
 extern "C" int b4c_keep(uint64_t seed, uint64_t e, float rate) { return b4c_keep_elem(seed, e, rate) ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------

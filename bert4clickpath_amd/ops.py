@@ -518,6 +518,29 @@ def ffn_bwd(dout, z, stats, gamma, rate, seed, h, x, wc2, wc1, F, dW1, db1, dW2,
     return dx
 
 
+# ---- the feed-forward block's forward in one pass (csrc/ffn_fwd.hip).  B4C_FUSED_FFN_FWD=0 keeps gemm_nt + gemm_nt_add_ln.
+fused_ffn_fwd = os.environ.get('B4C_FUSED_FFN_FWD', '1') != '0'
+
+
+def ffn_fwd_supported(x, Fp):
+    return x.dtype == torch.bfloat16 and x.shape[1] == 128 and Fp <= 128 and Fp % 8 == 0 and x.stride(0) % 8 == 0 and x.shape[0] >= 4096
+
+
+def ffn_fwd(x, wt1, b1, wt2, b2, gamma, beta, F, Fp, rate, seed, save=True):
+    """-> h [M, Fp], z (None unless save), out, stats (None unless save) of LayerNorm(x + dropout(relu(x W1 + b1) W2 + b2)) (b4c_ffn_fwd).
+    wt1 [Fp][128], wt2 [128][Fp]: the forward operands of gemm_nt for the two layers; b1 [Fp], b2 [128] fp32."""
+    M = x.shape[0]
+    h = torch.empty(M, Fp, dtype=x.dtype, device=x.device)
+    z = torch.empty(M, 128, dtype=x.dtype, device=x.device) if save else None
+    out = torch.empty(M, 128, dtype=x.dtype, device=x.device)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device) if save else None
+    with _record('ffn_fwd' if 2 * M >= rec_hints.get('token_rows', 0) else 'ffn_fwd_rows',
+                 M * ((128 * (3 if save else 2) + Fp) * 2 + (8 if save else 0)), 4 * M * 128 * Fp):
+        L.check(L.lib().b4c_ffn_fwd(_p(x), x.stride(0), _p(wt1), wt1.stride(0), _p(b1), _p(wt2), wt2.stride(0), _p(b2), _p(gamma), _p(beta),
+                                    F, Fp, _p(h), h.stride(0), _p(z), _p(out), _p(stats), M, LN_EPS, rate, seed, _st()), 'ffn_fwd')
+    return h, z, out, stats
+
+
 # ---- the attention block's tail in one pass (csrc/attn_out_bwd.hip): LayerNorm + dropout backward and the output projection's dX /
 # dW / db.  B4C_FUSED_ATTN_OUT_BWD=0 keeps add_ln_bwd + the projection's own kernels.
 fused_attn_out_bwd = os.environ.get('B4C_FUSED_ATTN_OUT_BWD', '1') != '0'
@@ -1502,8 +1525,10 @@ class FFNBlockFn(torch.autograd.Function):
         wt1, _, bb1 = pk1.get(x.dtype, d, training)
         Fp = pk1.Np
         wt2, _, bb2 = pk2.get(x.dtype, Fp, training)
-        h = gemm_nt(x, wt1, Fp, bb1, act=L.ACT_RELU)
-        if gemm_ln_supported(h, d):
+        if fused_ffn_fwd and ffn_fwd_supported(x, Fp):
+            h, z, out, stats = ffn_fwd(x, wt1, bb1, wt2, bb2, gamma.detach(), beta.detach(), pk1.N, Fp, rate if training else 0.0, seed,
+                                       save=training)
+        elif gemm_ln_supported((h := gemm_nt(x, wt1, Fp, bb1, act=L.ACT_RELU)), d):
             z, out, stats = gemm_nt_add_ln(h, wt2, bb2, x, gamma.detach(), beta.detach(), rate if training else 0.0, seed,
                                            save=training)
         else:

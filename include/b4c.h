@@ -193,6 +193,16 @@ int b4c_attn_out_bwd(const void *dout, const void *z, const float *stats, const 
                      float *dW, int ld_dw, float *db, float *dgamma, float *dbeta, int64_t M,
                      void *workspace, int64_t workspace_bytes, void *stream);
 
+/* (ABI 12) the forward of the position-wise feed-forward block (transformer.py:154-170) in ONE pass:
+ *   H = relu(X W1 + b1) [M][ldh] (Fp stored columns, F valid; the backward pass reads it),   Z = X + dropout(H W2 + b2) (or NULL),
+ *   Out = LayerNorm(Z) gamma + beta,   stats [M][2] = (mean, 1 / std) of Z's rows (or NULL).
+ * W1t [Fp][ldw1] (row = hidden column, 128 entries) and W2t [128][ldw2] (row = output column, Fp entries): the forward operands of
+ * b4c_gemm_nt for the two layers; b1 [Fp], b2 / gamma / beta [128] fp32.  bf16, d_model = 128, F <= 128 only.  X is read once and H is
+ * not read back: 446 MB per launch at 456 k rows against 658 for b4c_gemm_nt + b4c_gemm_nt_add_ln. */
+int b4c_ffn_fwd(const void *X, int ldx, const void *W1t, int ldw1, const float *b1, const void *W2t, int ldw2, const float *b2,
+                const float *gamma, const float *beta, int F, int Fp, void *H, int ldh, void *Z, void *Out, float *stats,
+                int64_t M, float eps, float dropout_rate, uint64_t seed, void *stream);
+
 /* several dW problems over the SAME M tokens in one launch (bf16; the four weight gradients of an encoder layer):
  * the ~256 workgroups of the split are shared by all problems, so every output tile has ~256 / (total tiles)
  * partial sums, and the group needs one main + one reduce kernel.  Problem i: dW_i[K][n_seg * seg_width] split into

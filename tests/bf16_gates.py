@@ -36,6 +36,14 @@ class GateRecorder:
                 self.patterns.append((out.detach() > 0).cpu())
             return out
         self.ops.gemm_nt = gemm_nt
+        # the fused feed-forward forward (ops.ffn_fwd, bf16 / d_model 128 / >= 4,096 rows) never calls gemm_nt: its h is the pattern
+        self._orig_ffn = self.ops.ffn_fwd
+
+        def ffn_fwd(*a, **kw):
+            res = self._orig_ffn(*a, **kw)
+            self.patterns.append((res[0].detach() > 0).cpu())
+            return res
+        self.ops.ffn_fwd = ffn_fwd
         # which form the last layer took cannot be read off its pattern's row count: B x max_masked_per_row rows of the masked-query
         # form and T rows of a packed full layer can coincide (B = 4, S = 16, 40 real tokens, 10 masks per row: found by a drawn case)
         self._orig_mq = self.ops.MQAttnBlockFn
@@ -51,6 +59,7 @@ class GateRecorder:
 
     def __exit__(self, *exc):
         self.ops.gemm_nt = self._orig
+        self.ops.ffn_fwd = self._orig_ffn
         self.ops.MQAttnBlockFn = self._orig_mq
 
     def relu_for(self, num_layers, n_head_layers, rows_flat, B, S, token_rows=None):

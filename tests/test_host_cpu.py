@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)          # loads without a GPU: no device call at load time
     for n in names:
         assert hasattr(L, n), 'libb4c_hip.so does not export %s' % n
-    assert _lib.lib().b4c_abi_version() == _lib.ABI_VERSION == 11
+    assert _lib.lib().b4c_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_keep_mask_hash_host_vs_library():
