@@ -23,6 +23,7 @@ GROUPS = [
     (('gemm_dxdw',), ('gemm_dxdw_kernel', 'dxdw_reduce_kernel'), 'gemm_dxdw_kernel'),
     (('ffn_bwd', 'ffn_bwd_rows'), ('ffn_bwd_kernel', 'ffn_bwd_reduce_kernel'), 'ffn_bwd_kernel'),
     (('attn_out_bwd', 'attn_out_bwd_rows'), ('ao_bwd_kernel', 'ao_bwd_reduce_kernel'), 'ao_bwd_kernel'),
+    (('ffn_fwd', 'ffn_fwd_rows'), ('ffn_fwd_kernel',), None),
     (('add_ln_fwd',), ('add_ln_fwd',), None),
     (('attn_mq_fwd',), ('attn_mq_fwd',), None), (('attn_mq_bwd',), ('attn_mq_bwd',), None),
     (('attn_bwd',), ('attn_bwd',), None), (('attn_fwd',), ('attn_fwd',), None),
