@@ -12,9 +12,10 @@
 //
 // A persistent 512-thread workgroup per CU walks 32-token tiles (tile i of a workgroup = global tile blockIdx.x + i gridDim.x):
 //   LDS-DMA     h tile [32][Fp] and x tile [32][128] into a four-stage ring of XOR-swizzled images (three tiles ahead)
-//   registers   16 threads per token row hold 8 columns each of dOut and z (requested a tile ahead by inline assembly: the counted
-//               s_waitcnt of gemm_dxdw.hip), LayerNorm backward with 16-lane sums -> dz (kept, bf16, for the residual add two
-//               phases later) and dy -> LDS image; dgamma / dbeta partial sums stay in registers over all tiles
+//   rows        dOut / z chunks and the rows' statistics arrive by LDS-DMA too, a tile ahead, 16 B per thread at thread * 16 (every
+//               request lands in LDS: a register that a load is still filling gets copied by the compiler -- see ln_load below);
+//               16 threads per token row hold 8 columns each: LayerNorm backward with 16-lane sums -> dz (kept, bf16, for the
+//               residual add two phases later) and dy -> LDS image; dgamma / dbeta partial sums stay in registers over all tiles
 //   phase 2     dW2 += h^T dy (MFMA 32x32x16, fragments by transposed LDS reads), dh = (dy W2^T) o [h > 0] (MFMA 16x16x32, the
 //               wave's 16 hidden columns of W2 resident in registers) -> LDS image
 //   phase 1'    (with the NEXT tile's LayerNorm phase) dW1 += x^T dh, dx = dh W1^T -> staged fp32 tile

@@ -10,7 +10,8 @@
 //               (8 waves x (2 x 3) MFMA 32x32x16 tiles = 96 registers per lane), fragments through ds_read_b64_tr_b16
 //   dX          G W^T: wave w owns 16 output columns, its W fragments (128 NG x 16: 48 registers) resident for the whole
 //               kernel, MFMA 16x16x32 with the G rows straight from the LDS image
-//   epilogue    dX tile -> bf16 -> LDS transpose -> 16-B row chunks (+ residual, added in fp32) -> global
+//   epilogue    dX tile -> bf16 -> LDS transpose -> 16-B row chunks (+ residual: its chunk arrives by LDS-DMA a tile ahead; added in
+//               fp32) -> global, a tile late (the staged tile is double-buffered: ONE barrier per tile)
 //   end         the workgroup's dW / db partial -> scratch; dxdw_reduce_kernel adds the partials in workgroup order
 //               (deterministic) into the Keras-layout gradient tensors, column segments (q | k | v) apart.
 //
